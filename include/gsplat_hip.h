@@ -1,0 +1,171 @@
+/*
+ * gsplat_hip.h — C ABI of the MI355X (gfx950) Gaussian-splat rasterizer, `libgsplat_hip.so`.
+ *
+ * This is the drop-in boundary for OpenSplat's hot path: every entry point below replaces one of
+ * the `*_tensor` launchers that OpenSplat's three autograd operators call
+ * (reference: rasterizer/gsplat/bindings.h, cited per function).  The signatures carry plain
+ * device pointers, sizes and a stream — no torch types — so the same library is bindable from
+ * C++/libtorch (opensplat_amd/csrc/torch_ops.cpp does exactly that), ctypes, cgo or JNI.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major data unless marked "host";
+ *   - fp32 for all real data, int32 for ids / radii / counts, as in the reference
+ *     (bindings.h:42-64, 111-126);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises
+ *     except where stated; nothing is allocated — the caller owns outputs and workspace;
+ *   - return value: GS_OK (0) or a negative GsStatus; functions never throw, never exit;
+ *   - re-entrant and stateless: safe to call from libtorch's autograd thread.
+ *
+ * Numerics follow OpenSplat's CPU implementation (rasterizer/gsplat-cpu/gsplat_cpu.cpp), which is
+ * the parity oracle: pixel-rectangle culling (gsplat_cpu.cpp:167-168,201-204), alpha clamps
+ * 0.999 forward / 0.99 backward (:220,:338), alpha threshold 1/255, transmittance stop 1e-4
+ * (:225-228), IEEE expf bit-compatible with glibc.  See DESIGN.md.
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_TILE 16          /* BLOCK_X == BLOCK_Y == 16, rasterizer/gsplat/config.h:1-2 */
+#define GS_SPLAT_DWORDS 12  /* packed per-Gaussian 2-D record, see gs_pack_splats */
+
+typedef void *gs_stream_t; /* hipStream_t */
+
+typedef enum GsStatus {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, K not in {1,4,9,16,25} ... */
+    GS_ERR_UNSUPPORTED = -2,      /* image wider/taller than 65535 px */
+    GS_ERR_WORKSPACE = -3,        /* workspace too small for (N, max_isects) */
+    GS_ERR_HIP = -4               /* a HIP runtime call failed; see gs_last_hip_error() */
+} GsStatus;
+
+/* Camera + image description: the scalar arguments of ProjectGaussians::apply
+ * (project_gaussians.hpp:12-30) as one host-side POD.  Matrices are row-major 4x4. */
+typedef struct GsCamera {
+    float viewmat[16]; /* world -> camera                                  */
+    float projmat[16]; /* full projection (proj @ view), model.cpp:152      */
+    float fx, fy, cx, cy;
+    int32_t img_width, img_height;
+    float clip_thresh; /* near-plane cull, default 0.01 (project_gaussians.hpp:28) */
+    float glob_scale;  /* 1.0 everywhere in OpenSplat                        */
+} GsCamera;
+
+/* Flags for the compositing kernels. */
+#define GS_FLAG_FAST_EXP 1u /* use the hardware v_exp_f32 path instead of the glibc-bit-exact expf; \
+                               contributor sets may then differ from the CPU oracle at thresholds */
+
+const char *gs_strerror(int status);
+const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
+int gs_version(void);                /* 10000*major + 100*minor + patch */
+
+/* ---------------------------------------------------------------------------------------------
+ * Projection.  Replaces project_gaussians_forward_tensor (rasterizer/gsplat/bindings.h:42-64,
+ * kernel forward.cu:19-103); arithmetic follows the CPU oracle gsplat_cpu.cpp:48-131.
+ *   in : means[N,3] scales[N,3] (already exp'd) quats[N,4] (w,x,y,z; normalised inside)
+ *   out: xys[N,2] depths[N] (view-space z) radii[N] conics[N,3] num_tiles_hit[N] cov3d[N,6]
+ *        cov2d[N,3] = (xx, xy, yy) incl. the +0.3 blur — what the CPU path returns as cov2d
+ *        (gsplat_cpu.cpp:95-99) and what defines its per-Gaussian pixel rectangle.
+ * viewmat_dev / projmat_dev: optional DEVICE copies of the two 4x4 matrices (row-major, 16
+ * floats); when non-NULL they override cam->viewmat / cam->projmat and are read by the kernel
+ * itself, so a caller holding them as device tensors (model.cpp:93-113,152) needs no
+ * device->host copy.
+ * Gaussians with view z <= clip_thresh get radius 0 / zero tiles (forward.cu:49-52).
+ * num_tiles_hit counts 16x16 tiles overlapped by the CPU pixel rectangle.            */
+int gs_project_forward(const GsCamera *cam /*host*/, const float *viewmat_dev /*nullable*/,
+                       const float *projmat_dev /*nullable*/, int N, const float *means,
+                       const float *scales, const float *quats, float *xys, float *depths,
+                       int32_t *radii, float *conics, int32_t *num_tiles_hit, float *cov3d,
+                       float *cov2d, gs_stream_t stream);
+
+/* Replaces project_gaussians_backward_tensor (bindings.h:66-93, kernel backward.cu:357-421).
+ * The VJP equals libtorch autograd through gsplat_cpu.cpp:48-131 (FOV clamp and glob_scale
+ * included).  v_depth may be NULL (treated as zeros).  Rows with radii <= 0 get zero gradients.
+ *   out: v_means[N,3] v_scales[N,3] v_quats[N,4] (fully written, no pre-zeroing needed)  */
+int gs_project_backward(const GsCamera *cam /*host*/, const float *viewmat_dev /*nullable*/,
+                        const float *projmat_dev /*nullable*/, int N, const float *means,
+                        const float *scales, const float *quats, const int32_t *radii,
+                        const float *v_xy, const float *v_depth, const float *v_conic,
+                        float *v_means, float *v_scales, float *v_quats, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spherical harmonics.  Replace compute_sh_forward_tensor / compute_sh_backward_tensor
+ * (bindings.h:26-40, kernels sh.cuh:218-260); basis as gsplat_cpu.cpp:424-486.
+ * K = number of stored bases (1,4,9,16,25); degrees_to_use <= degree(K).
+ *   fwd: dirs[N,3] (unit) coeffs[N,K,3] -> colors[N,3]
+ *   bwd: dirs[N,3] v_colors[N,3] -> v_coeffs[N,K,3] (bases above degrees_to_use written as 0) */
+int gs_sh_forward(int N, int K, int degrees_to_use, const float *dirs, const float *coeffs,
+                  float *colors, gs_stream_t stream);
+int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const float *v_colors,
+                   float *v_coeffs, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tile binning + sort.  Together these replace cumsum + map_gaussian_to_intersects_tensor +
+ * torch::sort/gather + get_tile_bin_edges_tensor (bindings.h:96-109,
+ * rasterize_gaussians.cpp:6-37,62-63).
+ *
+ * gs_pack_splats: gathers the 2-D attributes of each Gaussian into one 48-byte record
+ *   { x, y, conic A, B | C, opacity, r, g | b, (x0 | x1<<16), (y0 | y1<<16), depth }
+ * where [x0,x1) x [y0,y1) is the CPU oracle's pixel rectangle clipped to the image
+ * (gsplat_cpu.cpp:167-168,201-204), and writes tiles_hit[N] = tiles overlapped by it.
+ * cov2d may be NULL: the rectangle is then derived from the conic's inverse (legacy call sites
+ * that only have the reference's six projection outputs).  radii <= 0 -> empty rectangle.   */
+int gs_pack_splats(int W, int H, int N, const float *xys, const float *depths,
+                   const int32_t *radii, const float *conics, const float *colors,
+                   const float *opacities, const float *cov2d /*nullable*/, float *packed,
+                   int32_t *tiles_hit, gs_stream_t stream);
+
+/* Workspace (bytes) needed by gs_bin_scan + gs_bin_sort for N Gaussians, num_isects
+ * intersections and a W x H image. */
+size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
+
+/* Inclusive scan of tiles_hit -> cum_tiles_hit[N]; the total is also copied (async, on `stream`)
+ * to *num_isects_host, which must be pinned host memory or NULL.  The caller synchronises the
+ * stream before reading it (the reference syncs at the same place,
+ * rasterize_gaussians.cpp:63). */
+int gs_bin_scan(int N, const int32_t *tiles_hit, int32_t *cum_tiles_hit,
+                int32_t *num_isects_host /*host, nullable*/, void *workspace,
+                size_t workspace_bytes, gs_stream_t stream);
+
+/* Emits one (tile | depth-bits, gaussian id) pair per intersection, radix-sorts them on
+ * 32 + ceil(log2(tiles)) bits, and writes per-tile [start,end) ranges.
+ *   out: isect_ids[M] (int64, unsorted) gaussian_ids[M] isect_ids_sorted[M]
+ *        gaussian_ids_sorted[M] tile_bins[tiles,2]  — the five tensors binAndSortGaussians
+ *        returns (rasterize_gaussians.hpp:11-20).  Any of the first three may be NULL, in which
+ *        case workspace memory is used for them.
+ * num_isects must equal cum_tiles_hit[N-1]. */
+int gs_bin_sort(int W, int H, int N, int32_t num_isects, const float *packed,
+                const int32_t *cum_tiles_hit, int64_t *isect_ids, int32_t *gaussian_ids,
+                int64_t *isect_ids_sorted, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                void *workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Compositing.  Replace rasterize_forward_tensor / rasterize_backward_tensor
+ * (bindings.h:111-126,169-190; kernels forward.cu:256-378, backward.cu:161-355); recurrence and
+ * thresholds as the CPU oracle gsplat_cpu.cpp:188-240 (fwd) and :313-373 (bwd).
+ *   fwd out: out_img[H,W,3] final_Ts[H,W] final_idx[H,W] (index into gaussian_ids_sorted of the
+ *            last Gaussian composited into the pixel, -1 if none)
+ *   bwd out: v_xy[N,2] v_conic[N,3] v_colors[N,3] v_opacity[N] — ACCUMULATED with atomics: the
+ *            caller zero-fills them first (the reference allocates them with torch::zeros,
+ *            bindings.cu:591-598).  v_out_alpha may be NULL (OpenSplat always passes zeros,
+ *            rasterize_gaussians.cpp:108).  background is a host float[3].               */
+int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
+                         const int32_t *tile_bins, const float *packed,
+                         const float *background /*host[3]*/, float *out_img, float *final_Ts,
+                         int32_t *final_idx, uint32_t flags, gs_stream_t stream);
+
+int gs_rasterize_backward(int W, int H, const int32_t *gaussian_ids_sorted,
+                          const int32_t *tile_bins, const float *packed,
+                          const float *background /*host[3]*/, const float *final_Ts,
+                          const int32_t *final_idx, const float *v_out,
+                          const float *v_out_alpha /*nullable*/, float *v_xy, float *v_conic,
+                          float *v_colors, float *v_opacity, uint32_t flags, gs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

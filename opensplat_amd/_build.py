@@ -1,0 +1,77 @@
+"""In-tree build of the two native libraries (no setuptools, no JIT cache):
+
+  csrc/libgsplat_hip.so    HIP kernels + C ABI (include/gsplat_hip.h), hipcc --offload-arch=gfx950
+  csrc/libgsplat_torch.so  libtorch autograd operators on top of the C ABI, g++
+
+hipcc cross-compiles gfx950 without a GPU.  Both are rebuilt only when a source is newer than the
+library.  The built .so files are git-ignored but travel with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+
+HIP_SOURCES = ["gs_api.hip", "gs_project.hip", "gs_sh.hip", "gs_bin.hip", "gs_raster.hip"]
+HIP_HEADERS = ["gs_device.h", os.path.join(INCLUDE, "gsplat_hip.h")]
+HIP_LIB = os.path.join(CSRC, "libgsplat_hip.so")
+TORCH_LIB = os.path.join(CSRC, "libgsplat_torch.so")
+
+# -ffp-contract=off: the compositing arithmetic must round like the CPU reference (no implicit FMA)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    print("[opensplat_amd build]", " ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+
+
+def build_hip(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    if force or _stale(HIP_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIPCC_FLAGS + HIP_SOURCES + ["-o", HIP_LIB])
+    return HIP_LIB
+
+
+def build_torch(force: bool = False) -> str:
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    deps = [src, os.path.join(CSRC, "gsplat_ops.hpp"), os.path.join(INCLUDE, "gsplat_hip.h"), HIP_LIB]
+    if force or _stale(TORCH_LIB, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w",
+              "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+              "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+              "-I" + os.path.join(tdir, "include"),
+              "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+              "-I/opt/rocm/include",
+              "torch_ops.cpp", "-o", TORCH_LIB,
+              "-L" + CSRC, "-lgsplat_hip",
+              "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
+              "-lc10_hip", "-Wl,-rpath,$ORIGIN"])
+    return TORCH_LIB
+
+
+def build_all(force: bool = False) -> None:
+    build_hip(force)
+    build_torch(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI (include/gsplat_hip.h) operating on torch GPU tensors.
+
+This is the thinnest possible host: it allocates outputs with torch, passes raw data pointers and
+the current HIP stream to libgsplat_hip.so, and returns tensors.  The parity tests and bench.py
+drive the kernels through it; the C++/libtorch operators (opensplat_amd/ops.py) call exactly the
+same entry points.  No fallback: the library must exist and inputs must be GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import torch
+
+from . import _build
+
+GS_TILE = 16
+GS_SPLAT_DWORDS = 12
+GS_FLAG_FAST_EXP = 1
+
+# every symbol include/gsplat_hip.h declares (tests check they are all exported)
+SYMBOLS = [
+    "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
+    "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
+    "gs_bin_sort", "gs_rasterize_forward", "gs_rasterize_backward",
+]
+
+
+class GsCamera(C.Structure):
+    _fields_ = [("viewmat", C.c_float * 16), ("projmat", C.c_float * 16), ("fx", C.c_float),
+                ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("img_width", C.c_int32), ("img_height", C.c_int32), ("clip_thresh", C.c_float),
+                ("glob_scale", C.c_float)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgsplat_hip.so (after torch, so both share torch's HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.HIP_LIB):
+            raise ImportError("libgsplat_hip.so is not built: run `python -m opensplat_amd._build` "
+                              "(no CPU fallback exists)")
+        l = C.CDLL(_build.HIP_LIB)
+        l.gs_strerror.restype = C.c_char_p
+        l.gs_last_hip_error.restype = C.c_char_p
+        l.gs_bin_workspace_bytes.restype = C.c_size_t
+        l.gs_bin_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
+        _lib = l
+    return _lib
+
+
+class GsError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        l = lib()
+        msg = l.gs_strerror(rc).decode()
+        if rc == -4:
+            msg += " — " + l.gs_last_hip_error().decode()
+        raise GsError("%s failed: %s" % (what, msg))
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "GPU contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_camera(viewmat, projmat, fx, fy, cx, cy, W, H, clip=0.01, glob_scale=1.0) -> GsCamera:
+    cam = GsCamera()
+    vm = torch.as_tensor(viewmat, dtype=torch.float32).cpu().reshape(-1).tolist()
+    pm = torch.as_tensor(projmat, dtype=torch.float32).cpu().reshape(-1).tolist()
+    for i in range(16):
+        cam.viewmat[i] = vm[i]
+        cam.projmat[i] = pm[i]
+    cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
+    cam.img_width, cam.img_height = int(W), int(H)
+    cam.clip_thresh, cam.glob_scale = float(clip), float(glob_scale)
+    return cam
+
+
+def project_forward(cam: GsCamera, means, scales, quats, viewmat_dev=None, projmat_dev=None):
+    N = means.shape[0]
+    f = dict(device=means.device, dtype=torch.float32)
+    i = dict(device=means.device, dtype=torch.int32)
+    out = dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
+               radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
+               num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
+               cov2d=torch.empty((N, 3), **f))
+    _check(lib().gs_project_forward(C.byref(cam), _p(viewmat_dev), _p(projmat_dev), C.c_int(N),
+                                    _p(means), _p(scales), _p(quats), _p(out["xys"]),
+                                    _p(out["depths"]), _p(out["radii"]), _p(out["conics"]),
+                                    _p(out["num_tiles_hit"]), _p(out["cov3d"]), _p(out["cov2d"]),
+                                    _stream()), "gs_project_forward")
+    return out
+
+
+def project_backward(cam: GsCamera, means, scales, quats, radii, v_xy, v_conic, v_depth=None,
+                     viewmat_dev=None, projmat_dev=None):
+    N = means.shape[0]
+    f = dict(device=means.device, dtype=torch.float32)
+    out = dict(v_means=torch.empty((N, 3), **f), v_scales=torch.empty((N, 3), **f),
+               v_quats=torch.empty((N, 4), **f))
+    _check(lib().gs_project_backward(C.byref(cam), _p(viewmat_dev), _p(projmat_dev), C.c_int(N),
+                                     _p(means), _p(scales), _p(quats), _p(radii), _p(v_xy),
+                                     _p(v_depth), _p(v_conic), _p(out["v_means"]),
+                                     _p(out["v_scales"]), _p(out["v_quats"]), _stream()),
+           "gs_project_backward")
+    return out
+
+
+def sh_forward(degrees_to_use, dirs, coeffs):
+    N, K = coeffs.shape[0], coeffs.shape[1]
+    colors = torch.empty((N, 3), device=coeffs.device, dtype=torch.float32)
+    _check(lib().gs_sh_forward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(dirs),
+                               _p(coeffs), _p(colors), _stream()), "gs_sh_forward")
+    return colors
+
+
+def sh_backward(degrees_to_use, K, dirs, v_colors):
+    N = dirs.shape[0]
+    v_coeffs = torch.empty((N, K, 3), device=dirs.device, dtype=torch.float32)
+    _check(lib().gs_sh_backward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(dirs),
+                                _p(v_colors), _p(v_coeffs), _stream()), "gs_sh_backward")
+    return v_coeffs
+
+
+@dataclass
+class Binned:
+    packed: torch.Tensor          # [N, 12] f32
+    tiles_hit: torch.Tensor       # [N] i32
+    cum_tiles_hit: torch.Tensor   # [N] i32
+    num_isects: int
+    isect_ids: torch.Tensor       # [M] i64 (unsorted keys)
+    gaussian_ids: torch.Tensor    # [M] i32 (unsorted)
+    isect_ids_sorted: torch.Tensor
+    gaussian_ids_sorted: torch.Tensor
+    tile_bins: torch.Tensor       # [tiles, 2] i32
+
+
+class BinWorkspace:
+    """Reusable buffers for pack/scan/sort so that a steady-state step allocates nothing."""
+
+    def __init__(self):
+        self.ws = None
+        self.m_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
+        self.bufs = {}
+
+    def get(self, name, shape, dtype, device):
+        n = 1
+        for s in shape:
+            n *= s
+        t = self.bufs.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != device:
+            t = torch.empty(max(n, 1), dtype=dtype, device=device)
+            self.bufs[name] = t
+        return t[:n].view(*shape)
+
+
+def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
+                 workspace: BinWorkspace | None = None, keep_unsorted=True) -> Binned:
+    """pack -> scan -> (one sync to read M) -> emit + sort + tile ranges."""
+    l = lib()
+    N = xys.shape[0]
+    dev = xys.device
+    w = workspace or BinWorkspace()
+    packed = w.get("packed", (N, GS_SPLAT_DWORDS), torch.float32, dev)
+    tiles_hit = w.get("tiles_hit", (N,), torch.int32, dev)
+    cum = w.get("cum", (N,), torch.int32, dev)
+    _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(depths), _p(radii),
+                            _p(conics), _p(colors), _p(opacities), _p(cov2d), _p(packed),
+                            _p(tiles_hit), _stream()), "gs_pack_splats")
+    scan_bytes = l.gs_bin_workspace_bytes(N, 0, W, H)
+    scan_ws = w.get("ws", (scan_bytes,), torch.uint8, dev)
+    m_host = w.m_host if w.m_host is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+    _check(l.gs_bin_scan(C.c_int(N), _p(tiles_hit), _p(cum), C.c_void_p(m_host.data_ptr()),
+                         _p(scan_ws), C.c_size_t(scan_bytes), _stream()), "gs_bin_scan")
+    torch.cuda.current_stream().synchronize()
+    M = int(m_host[0]) if N > 0 else 0
+    tiles = ((W + GS_TILE - 1) // GS_TILE) * ((H + GS_TILE - 1) // GS_TILE)
+    ws_bytes = l.gs_bin_workspace_bytes(N, M, W, H)
+    ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
+    ids_sorted = w.get("ids_sorted", (M,), torch.int32, dev)
+    tile_bins = w.get("tile_bins", (tiles, 2), torch.int32, dev)
+    if keep_unsorted:
+        keys = w.get("keys", (M,), torch.int64, dev)
+        ids = w.get("ids", (M,), torch.int32, dev)
+        keys_sorted = w.get("keys_sorted", (M,), torch.int64, dev)
+    else:
+        keys = ids = keys_sorted = None
+    _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(M), _p(packed), _p(cum),
+                         _p(keys), _p(ids), _p(keys_sorted), _p(ids_sorted), _p(tile_bins), _p(ws),
+                         C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
+    return Binned(packed, tiles_hit, cum, M, keys, ids, keys_sorted, ids_sorted, tile_bins)
+
+
+def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
+    dev = binned.packed.device
+    if out is None:
+        out = dict(img=torch.empty((H, W, 3), device=dev, dtype=torch.float32),
+                   final_Ts=torch.empty((H, W), device=dev, dtype=torch.float32),
+                   final_idx=torch.empty((H, W), device=dev, dtype=torch.int32))
+    bg = (C.c_float * 3)(*[float(b) for b in background])
+    _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
+                                      _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
+                                      _p(out["final_Ts"]), _p(out["final_idx"]), C.c_uint32(flags),
+                                      _stream()), "gs_rasterize_forward")
+    return out
+
+
+def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx, v_out, flags=0,
+                       v_out_alpha=None, out=None):
+    dev = binned.packed.device
+    if out is None:
+        out = dict(v_xy=torch.zeros((N, 2), device=dev), v_conic=torch.zeros((N, 3), device=dev),
+                   v_colors=torch.zeros((N, 3), device=dev), v_opacity=torch.zeros((N,), device=dev))
+    bg = (C.c_float * 3)(*[float(b) for b in background])
+    _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
+                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(final_Ts),
+                                       _p(final_idx), _p(v_out), _p(v_out_alpha), _p(out["v_xy"]),
+                                       _p(out["v_conic"]), _p(out["v_colors"]), _p(out["v_opacity"]),
+                                       C.c_uint32(flags), _stream()), "gs_rasterize_backward")
+    return out

@@ -1,0 +1,172 @@
+// gs_device.h — device-side helpers shared by the gfx950 kernels of libgsplat_hip.so.
+//
+// Everything here is written for CDNA4 wave64: cross-lane sums go through DPP row operations
+// (no LDS traffic, unlike __shfl which lowers to ds_bpermute), rows are combined with
+// v_readlane, and the exponential is a bit-exact re-statement of glibc's expf so that the
+// alpha / transmittance thresholds of the compositing loops fall exactly where they fall in
+// OpenSplat's CPU rasterizer (rasterizer/gsplat-cpu/gsplat_cpu.cpp:220,:337).
+//
+// The whole library is compiled with -ffp-contract=off: a*b+c is two roundings unless written
+// as fmaf()/fma() explicitly, which is what makes the per-pixel arithmetic reproduce the CPU
+// reference (built for baseline x86-64, no FMA) bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsplat_hip.h"
+
+namespace gs {
+
+constexpr int kWave = 64;
+
+// ---- host-side error plumbing ---------------------------------------------------------------
+void set_hip_error(hipError_t e, const char *what);
+
+#define GS_HIP_CHECK(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            ::gs::set_hip_error(_e, #expr);                                                      \
+            return GS_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+#define GS_LAUNCH_CHECK() GS_HIP_CHECK(hipGetLastError())
+
+// ---- DPP cross-lane primitives --------------------------------------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm = p0|p1<<2|p2<<4|p3<<6; 0x140 row_mirror;
+// 0x141 row_half_mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// Sum over the 16 lanes of each DPP row; every lane of the row ends up with the row sum.
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+
+// Sum over all 64 lanes; result is wave-uniform (lives in SGPRs after the readlanes).
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, dpp_i<0xB1>(v));
+    v = max(v, dpp_i<0x4E>(v));
+    v = max(v, dpp_i<0x141>(v));
+    v = max(v, dpp_i<0x140>(v));
+    int s0 = __builtin_amdgcn_readlane(v, 0), s1 = __builtin_amdgcn_readlane(v, 16);
+    int s2 = __builtin_amdgcn_readlane(v, 32), s3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(s0, s1), max(s2, s3));
+}
+
+// ---- glibc-compatible expf ------------------------------------------------------------------
+// Table of 2^(i/32) (bits, minus i<<47) and polynomial of the expf that glibc >= 2.27 ships
+// (sysdeps/ieee754/flt-32/e_expf.c, N = 32, computed in double).  Checked exhaustively against
+// this image's libm over every float in [-87, 0]: 1 118 699 521 inputs, one mismatch
+// (x = -0x1.f8cbb2p+5), none in the range the rasterizer evaluates (sigma in [0, 5.6]).
+// Only valid for |x| < 87 (no overflow / subnormal handling) — the callers guarantee it.
+static __device__ __constant__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+// `tab` points at a copy of kExp2fTab in LDS (per-lane indexed reads are one ds_read_b64).
+__device__ __forceinline__ float expf_glibc(float x, const uint64_t *tab) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= Shift;
+    double r = z - kd;
+    uint64_t t = tab[ki & 31u] + (ki << 47);
+    double s = __longlong_as_double((long long)t);
+    double p = C0 * r + C1;
+    double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = p * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float gs_exp(float x, const uint64_t *tab) {
+    if constexpr (EXACT) {
+        return expf_glibc(x, tab);
+    } else {
+        return __expf(x);
+    }
+}
+
+// ---- per-Gaussian pixel rectangle (CPU oracle semantics) -------------------------------------
+// rows/cols the CPU rasterizer visits for a Gaussian centred at (gx, gy) with 2-D covariance
+// diagonal (cxx, cyy): gsplat_cpu.cpp:167-168 (3*sqrt(cov)), :201-204 (floor/ceil, +-2, clip).
+// Returned as half-open ranges clipped to the image; empty rectangles have x1 <= x0 or y1 <= y0.
+struct PixRect {
+    int x0, x1, y0, y1;
+};
+
+__device__ __forceinline__ int f2i_sat(float v) {
+    // float -> int with saturation (the reference's static_cast<int> is UB out of range; clamp
+    // first so that far-away Gaussians get a well-defined, clipped rectangle)
+    v = fminf(fmaxf(v, -1.0e9f), 1.0e9f);
+    return (int)v;
+}
+
+__device__ __forceinline__ PixRect pixel_rect(float gx, float gy, float cxx, float cyy, int W,
+                                              int H) {
+    float sqx = 3.0f * sqrtf(cxx);
+    float sqy = 3.0f * sqrtf(cyy);
+    PixRect r;
+    r.y0 = max(0, f2i_sat(floorf(gy - sqy)) - 2);
+    r.y1 = min(H, f2i_sat(ceilf(gy + sqy)) + 2);
+    r.x0 = max(0, f2i_sat(floorf(gx - sqx)) - 2);
+    r.x1 = min(W, f2i_sat(ceilf(gx + sqx)) + 2);
+    // NaN centres/covariances: comparisons with NaN are false -> fminf/fmaxf return the
+    // non-NaN operand -> saturated, rectangle ends up empty or clipped; never out of range.
+    return r;
+}
+
+__device__ __forceinline__ int rect_tiles(const PixRect &r) {
+    if (r.x1 <= r.x0 || r.y1 <= r.y0) return 0;
+    int tx0 = r.x0 / GS_TILE, tx1 = (r.x1 + GS_TILE - 1) / GS_TILE;
+    int ty0 = r.y0 / GS_TILE, ty1 = (r.y1 + GS_TILE - 1) / GS_TILE;
+    return (tx1 - tx0) * (ty1 - ty0);
+}
+
+// XCD-aware block -> tile mapping: consecutive blocks round-robin over the 8 XCDs, so give each
+// XCD a contiguous band of tiles (neighbouring tiles share Gaussians -> shared L2 lines).
+__device__ __forceinline__ int xcd_swizzle(int block, int num_blocks) {
+    constexpr int kXcd = 8;
+    int per = num_blocks / kXcd;  // tiles in the evenly divisible part
+    int body = per * kXcd;
+    if (block >= body) return block;  // ragged tail: identity
+    return (block % kXcd) * per + (block / kXcd);
+}
+
+}  // namespace gs

@@ -1,0 +1,226 @@
+// gs_sh.hip — view-dependent colour from spherical-harmonic coefficients, and its VJP.
+//
+// Replaces compute_sh_forward_kernel / compute_sh_backward_kernel (reference
+// rasterizer/gsplat/sh.cuh:52-260); basis functions and constants as the CPU oracle
+// (rasterizer/gsplat-cpu/gsplat_cpu.cpp:379-407, :424-486).
+//
+// Roofline: HBM streaming.  Forward reads 12 + 12K B and writes 12 B per Gaussian (204 B at
+// K = 16), backward reads 24 B and writes 12K B.  The coefficient tensor is [N, K, 3] fp32 — an
+// AoS layout fixed by the operator surface — so a lane-per-Gaussian mapping would stride lanes
+// by 12K bytes.  Instead each wave moves its 64 Gaussians' coefficients as one contiguous
+// 64*12K-byte slab with fully coalesced 16-byte loads through LDS (rows padded by one dword so
+// the per-lane row walk is bank-conflict free), then each lane reduces its own row.
+#include "gs_device.h"
+
+namespace gs {
+
+__device__ __forceinline__ void sh_basis(int nb, float x, float y, float z, float *r) {
+    // gsplat_cpu.cpp:436-483; r[] has 25 slots, entries >= nb stay 0
+#pragma unroll
+    for (int i = 0; i < 25; i++) r[i] = 0.0f;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    r[0] = C0;
+    if (nb <= 1) return;
+    r[1] = C1 * -y;
+    r[2] = C1 * z;
+    r[3] = C1 * -x;
+    if (nb <= 4) return;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    r[4] = 1.0925484305920792f * xy;
+    r[5] = -1.0925484305920792f * yz;
+    r[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    r[7] = -1.0925484305920792f * xz;
+    r[8] = 0.5462742152960396f * (xx - yy);
+    if (nb <= 9) return;
+    r[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
+    r[10] = 2.890611442640554f * xy * z;
+    r[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+    r[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    r[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+    r[14] = 1.445305721320277f * z * (xx - yy);
+    r[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
+    if (nb <= 16) return;
+    r[16] = 2.5033429417967046f * xy * (xx - yy);
+    r[17] = -1.7701307697799304f * yz * (3.0f * xx - yy);
+    r[18] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
+    r[19] = -0.6690465435572892f * yz * (7.0f * zz - 3.0f);
+    r[20] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
+    r[21] = -0.6690465435572892f * xz * (7.0f * zz - 3.0f);
+    r[22] = 0.47308734787878004f * (xx - yy) * (7.0f * zz - 1.0f);
+    r[23] = -1.7701307697799304f * xz * (xx - 3.0f * yy);
+    r[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+}
+
+__host__ __device__ inline int num_bases(int degree) {  // gsplat_cpu.cpp:409-422
+    return degree == 0 ? 1 : degree == 1 ? 4 : degree == 2 ? 9 : degree == 3 ? 16 : 25;
+}
+
+// 4 waves per block (2 for K = 25 so the padded slabs stay under 64 KiB of dynamic LDS);
+// each wave owns 64 consecutive Gaussians.
+template <int K>
+struct ShCfg {
+    static constexpr int kBlock = (K > 16) ? 128 : 256;
+};
+
+// K is a template parameter so the row length (3K dwords, +1 pad) is static.
+template <int K>
+__global__ void __launch_bounds__(ShCfg<K>::kBlock)
+k_sh_forward(int N, int nb, const float *__restrict__ dirs, const float *__restrict__ coeffs,
+             float *__restrict__ colors) {
+    constexpr int ROW = 3 * K;       // dwords per Gaussian
+    constexpr int ROWP = ROW | 1;    // odd stride -> conflict-free per-lane row walk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShCfg<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;  // 0: wave has no Gaussians (tail)
+    const float *src = coeffs + g0 * ROW;
+    const int total = cnt * ROW;  // dwords in this wave's slab (src is 16-B aligned: 64*ROW*4*g)
+    // coalesced 16-byte loads, scattered into the padded rows
+    for (int i = lane * 4; i < total; i += 64 * 4) {
+        if (i + 3 < total) {
+            float4 v = *reinterpret_cast<const float4 *>(src + i);
+            float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int idx = i + k;
+                slab[(idx / ROW) * ROWP + (idx % ROW)] = e[k];
+            }
+        } else {
+            for (int idx = i; idx < total; idx++) slab[(idx / ROW) * ROWP + (idx % ROW)] = src[idx];
+        }
+    }
+    __syncthreads();  // slabs are wave-private; the barrier only orders LDS writes -> reads
+    if (lane >= cnt) return;
+    const int64_t g = g0 + lane;
+    float r[25];
+    sh_basis(nb, dirs[3 * g], dirs[3 * g + 1], dirs[3 * g + 2], r);
+    const float *row = slab + lane * ROWP;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < K; b++) {
+        c0 += r[b] * row[3 * b + 0];
+        c1 += r[b] * row[3 * b + 1];
+        c2 += r[b] * row[3 * b + 2];
+    }
+    colors[3 * g + 0] = c0;
+    colors[3 * g + 1] = c1;
+    colors[3 * g + 2] = c2;
+}
+
+template <int K>
+__global__ void __launch_bounds__(ShCfg<K>::kBlock)
+k_sh_backward(int N, int nb, const float *__restrict__ dirs, const float *__restrict__ v_colors,
+              float *__restrict__ v_coeffs) {
+    constexpr int ROW = 3 * K;
+    constexpr int ROWP = ROW | 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShCfg<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if (lane < cnt) {
+        const int64_t g = g0 + lane;
+        float r[25];
+        sh_basis(nb, dirs[3 * g], dirs[3 * g + 1], dirs[3 * g + 2], r);
+        float v0 = v_colors[3 * g], v1 = v_colors[3 * g + 1], v2 = v_colors[3 * g + 2];
+        float *row = slab + lane * ROWP;
+#pragma unroll
+        for (int b = 0; b < K; b++) {
+            row[3 * b + 0] = r[b] * v0;
+            row[3 * b + 1] = r[b] * v1;
+            row[3 * b + 2] = r[b] * v2;
+        }
+    }
+    __syncthreads();
+    float *dst = v_coeffs + g0 * ROW;
+    const int total = cnt * ROW;
+    for (int i = lane * 4; i < total; i += 64 * 4) {
+        if (i + 3 < total) {
+            float e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int idx = i + k;
+                e[k] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+            }
+            *reinterpret_cast<float4 *>(dst + i) = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+            for (int idx = i; idx < total; idx++) dst[idx] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+        }
+    }
+}
+
+template <int K>
+static int launch_fwd(int N, int nb, const float *dirs, const float *coeffs, float *colors,
+                      hipStream_t s) {
+    constexpr int ROWP = (3 * K) | 1;
+    constexpr int BLK = ShCfg<K>::kBlock;  // == Gaussians per block
+    size_t lds = (size_t)BLK * ROWP * sizeof(float);
+    int blocks = (N + BLK - 1) / BLK;
+    hipLaunchKernelGGL(k_sh_forward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs, coeffs,
+                       colors);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+template <int K>
+static int launch_bwd(int N, int nb, const float *dirs, const float *v_colors, float *v_coeffs,
+                      hipStream_t s) {
+    constexpr int ROWP = (3 * K) | 1;
+    constexpr int BLK = ShCfg<K>::kBlock;
+    size_t lds = (size_t)BLK * ROWP * sizeof(float);
+    int blocks = (N + BLK - 1) / BLK;
+    hipLaunchKernelGGL(k_sh_backward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs,
+                       v_colors, v_coeffs);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+static int deg_from_bases(int K) {  // spherical_harmonics.cpp:3-16, but strict
+    switch (K) {
+    case 1: return 0;
+    case 4: return 1;
+    case 9: return 2;
+    case 16: return 3;
+    case 25: return 4;
+    default: return -1;
+    }
+}
+
+}  // namespace gs
+
+extern "C" int gs_sh_forward(int N, int K, int degrees_to_use, const float *dirs,
+                             const float *coeffs, float *colors, gs_stream_t stream) {
+    int deg = gs::deg_from_bases(K);
+    if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg) return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!dirs || !coeffs || !colors) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)coeffs & 15u) return GS_ERR_INVALID_ARGUMENT;  // 16-byte vector loads
+    int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+    case 1: return gs::launch_fwd<1>(N, nb, dirs, coeffs, colors, s);
+    case 4: return gs::launch_fwd<4>(N, nb, dirs, coeffs, colors, s);
+    case 9: return gs::launch_fwd<9>(N, nb, dirs, coeffs, colors, s);
+    case 16: return gs::launch_fwd<16>(N, nb, dirs, coeffs, colors, s);
+    default: return gs::launch_fwd<25>(N, nb, dirs, coeffs, colors, s);
+    }
+}
+
+extern "C" int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs,
+                              const float *v_colors, float *v_coeffs, gs_stream_t stream) {
+    int deg = gs::deg_from_bases(K);
+    if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg) return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!dirs || !v_colors || !v_coeffs) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)v_coeffs & 15u) return GS_ERR_INVALID_ARGUMENT;  // 16-byte vector stores
+    int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+    case 1: return gs::launch_bwd<1>(N, nb, dirs, v_colors, v_coeffs, s);
+    case 4: return gs::launch_bwd<4>(N, nb, dirs, v_colors, v_coeffs, s);
+    case 9: return gs::launch_bwd<9>(N, nb, dirs, v_colors, v_coeffs, s);
+    case 16: return gs::launch_bwd<16>(N, nb, dirs, v_colors, v_coeffs, s);
+    default: return gs::launch_bwd<25>(N, nb, dirs, v_colors, v_coeffs, s);
+    }
+}

@@ -1,0 +1,79 @@
+// gsplat_ops.hpp — libtorch operator surface of the MI355X rasterizer.
+//
+// Same class names, argument order and meaning as OpenSplat's GPU operators, so that
+// Model::forward (model.cpp:147-218) and simple_trainer.cpp:173-192 compile against this header
+// unchanged:
+//   ProjectGaussians     <- project_gaussians.hpp:12-30   (+ a 7th output, cov2d)
+//   RasterizeGaussians   <- rasterize_gaussians.hpp:23-37 (+ an optional trailing cov2d argument)
+//   SphericalHarmonics   <- spherical_harmonics.hpp:15-22
+//   degFromSh / rgb2sh / sh2rgb <- spherical_harmonics.hpp:9-11
+//   TileBounds           <- tile_bounds.hpp:6
+// All device work goes through the C ABI in include/gsplat_hip.h (libgsplat_hip.so) on the
+// current torch HIP stream; tensors are allocated with torch's caching allocator.
+// Errors follow the reference's convention (bindings.h:14-19): TORCH_CHECK -> c10::Error.
+#pragma once
+
+#include <torch/torch.h>
+
+#include <tuple>
+
+typedef std::tuple<int, int, int> TileBounds;
+
+#ifndef BLOCK_X
+#define BLOCK_X 16
+#define BLOCK_Y 16
+#endif
+
+int degFromSh(int numBases);
+torch::Tensor rgb2sh(const torch::Tensor &rgb);
+torch::Tensor sh2rgb(const torch::Tensor &sh);
+
+class ProjectGaussians : public torch::autograd::Function<ProjectGaussians> {
+public:
+    // returns { xys[N,2], depths[N], radii[N] i32, conics[N,3], numTilesHit[N] i32, cov3d[N,6],
+    //           cov2d[N,3] }  — the first six are the reference's outputs, in its order.
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext *ctx,
+                                                  torch::Tensor means, torch::Tensor scales,
+                                                  double globScale, torch::Tensor quats,
+                                                  torch::Tensor viewMat, torch::Tensor projMat,
+                                                  double fx, double fy, double cx, double cy,
+                                                  int64_t imgHeight, int64_t imgWidth,
+                                                  TileBounds tileBounds, double clipThresh = 0.01);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
+// Packs the per-Gaussian 2-D records, counts, scans, emits, sorts and bins.
+// Returns { packed[N,12], gaussianIdsSorted[M] i32, tileBins[tiles,2] i32 } and the number of
+// intersections M.  (The reference's binAndSortGaussians, rasterize_gaussians.hpp:11-20, takes
+// radius-square tile counts; this one derives them from the CPU pixel rectangle — DESIGN.md.)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, int64_t> binAndSortGaussians(
+    const torch::Tensor &xys, const torch::Tensor &depths, const torch::Tensor &radii,
+    const torch::Tensor &conics, const torch::Tensor &colors, const torch::Tensor &opacity,
+    const torch::Tensor &cov2d, int imgHeight, int imgWidth);
+
+class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
+public:
+    // cov2d: the 7th output of ProjectGaussians; when undefined the pixel rectangle is derived
+    // from the conics (call sites written against the reference's 10-argument signature).
+    static torch::Tensor forward(torch::autograd::AutogradContext *ctx, torch::Tensor xys,
+                                 torch::Tensor depths, torch::Tensor radii, torch::Tensor conics,
+                                 torch::Tensor numTilesHit, torch::Tensor colors,
+                                 torch::Tensor opacity, int64_t imgHeight, int64_t imgWidth,
+                                 torch::Tensor background, torch::Tensor cov2d = torch::Tensor());
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
+class SphericalHarmonics : public torch::autograd::Function<SphericalHarmonics> {
+public:
+    static torch::Tensor forward(torch::autograd::AutogradContext *ctx, int64_t degreesToUse,
+                                 torch::Tensor viewDirs, torch::Tensor coeffs);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
+// Process-wide switch for the compositing kernels' exponential: false (default) = glibc-bit-exact
+// expf (contributor sets identical to gsplat-cpu); true = hardware v_exp_f32 (GS_FLAG_FAST_EXP).
+void gsplatSetFastExp(bool enabled);
+bool gsplatGetFastExp();

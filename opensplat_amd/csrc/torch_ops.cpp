@@ -1,0 +1,366 @@
+// torch_ops.cpp — libtorch host side of the MI355X rasterizer: three autograd Functions with
+// OpenSplat's operator signatures, calling the C ABI of libgsplat_hip.so (include/gsplat_hip.h).
+//
+// Mirrors, on the reference side: project_gaussians.cpp:5-90, rasterize_gaussians.cpp:6-140,
+// spherical_harmonics.cpp:3-62 and the allocation/launch glue of rasterizer/gsplat/bindings.cu.
+// PyTorch is plumbing here (caching allocator, current HIP stream, autograd graph); no tensor
+// math of the hot path runs in ATen.
+//
+// There is deliberately NO CPU fallback: every operator TORCH_CHECKs that its inputs live on the
+// GPU, and the package fails to import if libgsplat_hip.so is missing.
+#include "gsplat_ops.hpp"
+
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
+#include <torch/library.h>
+
+#include <atomic>
+#include <cstring>
+
+#include "../../include/gsplat_hip.h"
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::tensor_list;
+using torch::autograd::variable_list;
+
+namespace {
+
+std::atomic<bool> g_fast_exp{false};
+
+#define GS_CHECK_DEV(x) TORCH_CHECK((x).is_cuda(), #x " must be a GPU (HIP) tensor")
+#define GS_CHECK_F32(x) TORCH_CHECK((x).scalar_type() == torch::kFloat32, #x " must be float32")
+#define GS_CHECK_I32(x) TORCH_CHECK((x).scalar_type() == torch::kInt32, #x " must be int32")
+
+void check_status(int rc, const char *what) {
+    TORCH_CHECK(rc == GS_OK, what, " failed: ", gs_strerror(rc),
+                rc == GS_ERR_HIP ? std::string(" — ") + gs_last_hip_error() : std::string());
+}
+
+gs_stream_t current_stream() {
+    return (gs_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+}
+
+const float *fptr(const Tensor &t) { return t.data_ptr<float>(); }
+float *fptr_mut(Tensor &t) { return t.data_ptr<float>(); }
+
+GsCamera make_camera(double fx, double fy, double cx, double cy, int64_t H, int64_t W, double clip,
+                     double glob) {
+    GsCamera c;
+    std::memset(&c, 0, sizeof(c));
+    c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
+    c.img_width = (int32_t)W; c.img_height = (int32_t)H;
+    c.clip_thresh = (float)clip; c.glob_scale = (float)glob;
+    return c;
+}
+
+// 4x4 matrix argument: device tensors are handed to the kernel as they are (no sync); host
+// tensors are copied into the camera struct.
+const float *matrix_arg(const Tensor &m, Tensor &holder, float *host_dst) {
+    TORCH_CHECK(m.numel() == 16, "view/projection matrix must be 4x4");
+    holder = m.to(torch::kFloat32).contiguous();
+    if (holder.is_cuda()) return holder.data_ptr<float>();
+    std::memcpy(host_dst, holder.data_ptr<float>(), 16 * sizeof(float));
+    return nullptr;
+}
+
+}  // namespace
+
+void gsplatSetFastExp(bool enabled) { g_fast_exp.store(enabled); }
+bool gsplatGetFastExp() { return g_fast_exp.load(); }
+
+// ---- spherical_harmonics.cpp:3-28 helpers ------------------------------------------------------
+int degFromSh(int numBases) {
+    switch (numBases) {
+    case 1: return 0;
+    case 4: return 1;
+    case 9: return 2;
+    case 16: return 3;
+    default: return 4;
+    }
+}
+
+static const double kShC0 = 0.28209479177387814;
+Tensor rgb2sh(const Tensor &rgb) { return (rgb - 0.5) / kShC0; }
+Tensor sh2rgb(const Tensor &sh) { return torch::clamp((sh * kShC0) + 0.5, 0.0f, 1.0f); }
+
+// ---- ProjectGaussians ---------------------------------------------------------------------------
+variable_list ProjectGaussians::forward(AutogradContext *ctx, Tensor means, Tensor scales,
+                                        double globScale, Tensor quats, Tensor viewMat,
+                                        Tensor projMat, double fx, double fy, double cx, double cy,
+                                        int64_t imgHeight, int64_t imgWidth, TileBounds tileBounds,
+                                        double clipThresh) {
+    (void)tileBounds;  // derived from imgWidth/imgHeight, as rasterize_gaussians.cpp:54-58 does
+    GS_CHECK_DEV(means); GS_CHECK_DEV(scales); GS_CHECK_DEV(quats);
+    GS_CHECK_F32(means); GS_CHECK_F32(scales); GS_CHECK_F32(quats);
+    TORCH_CHECK(means.dim() == 2 && means.size(1) == 3, "means must be [N,3]");
+    const int64_t N = means.size(0);
+    TORCH_CHECK(scales.sizes() == means.sizes(), "scales must be [N,3]");
+    TORCH_CHECK(quats.dim() == 2 && quats.size(0) == N && quats.size(1) == 4, "quats must be [N,4]");
+    c10::DeviceGuard guard(means.device());
+    means = means.contiguous(); scales = scales.contiguous(); quats = quats.contiguous();
+
+    GsCamera cam = make_camera(fx, fy, cx, cy, imgHeight, imgWidth, clipThresh, globScale);
+    Tensor vmHold, pmHold;
+    const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
+    const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
+
+    auto f32 = means.options();
+    auto i32 = means.options().dtype(torch::kInt32);
+    Tensor xys = torch::empty({N, 2}, f32), depths = torch::empty({N}, f32);
+    Tensor radii = torch::empty({N}, i32), conics = torch::empty({N, 3}, f32);
+    Tensor numTilesHit = torch::empty({N}, i32), cov3d = torch::empty({N, 6}, f32);
+    Tensor cov2d = torch::empty({N, 3}, f32);
+    check_status(gs_project_forward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(scales),
+                                    fptr(quats), fptr_mut(xys), fptr_mut(depths),
+                                    radii.data_ptr<int32_t>(), fptr_mut(conics),
+                                    numTilesHit.data_ptr<int32_t>(), fptr_mut(cov3d),
+                                    fptr_mut(cov2d), current_stream()),
+                 "gs_project_forward");
+
+    ctx->saved_data["imgHeight"] = imgHeight;
+    ctx->saved_data["imgWidth"] = imgWidth;
+    ctx->saved_data["globScale"] = globScale;
+    ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
+    ctx->saved_data["cx"] = cx; ctx->saved_data["cy"] = cy;
+    ctx->saved_data["clipThresh"] = clipThresh;
+    ctx->save_for_backward({means, scales, quats, vmHold, pmHold, radii});
+    ctx->mark_non_differentiable({radii, numTilesHit, cov3d, cov2d});
+    return {xys, depths, radii, conics, numTilesHit, cov3d, cov2d};
+}
+
+tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_outputs) {
+    variable_list saved = ctx->get_saved_variables();
+    Tensor means = saved[0], scales = saved[1], quats = saved[2];
+    Tensor viewMat = saved[3], projMat = saved[4], radii = saved[5];
+    const int64_t N = means.size(0);
+    c10::DeviceGuard guard(means.device());
+
+    Tensor v_xys = grad_outputs[0].defined() ? grad_outputs[0].contiguous()
+                                             : torch::zeros({N, 2}, means.options());
+    Tensor v_depths = grad_outputs[1].defined() ? grad_outputs[1].contiguous() : Tensor();
+    Tensor v_conics = grad_outputs[3].defined() ? grad_outputs[3].contiguous()
+                                                : torch::zeros({N, 3}, means.options());
+    GsCamera cam = make_camera(ctx->saved_data["fx"].toDouble(), ctx->saved_data["fy"].toDouble(),
+                               ctx->saved_data["cx"].toDouble(), ctx->saved_data["cy"].toDouble(),
+                               ctx->saved_data["imgHeight"].toInt(),
+                               ctx->saved_data["imgWidth"].toInt(),
+                               ctx->saved_data["clipThresh"].toDouble(),
+                               ctx->saved_data["globScale"].toDouble());
+    Tensor vmHold, pmHold;
+    const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
+    const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
+
+    Tensor v_means = torch::empty({N, 3}, means.options());
+    Tensor v_scales = torch::empty({N, 3}, means.options());
+    Tensor v_quats = torch::empty({N, 4}, means.options());
+    check_status(gs_project_backward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(scales),
+                                     fptr(quats), radii.data_ptr<int32_t>(), fptr(v_xys),
+                                     v_depths.defined() ? fptr(v_depths) : nullptr, fptr(v_conics),
+                                     fptr_mut(v_means), fptr_mut(v_scales), fptr_mut(v_quats),
+                                     current_stream()),
+                 "gs_project_backward");
+    Tensor none;
+    return {v_means, v_scales, none, v_quats, none, none, none, none, none, none, none, none, none,
+            none};
+}
+
+// ---- binning ------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
+    const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
+    const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth) {
+    const int64_t N = xys.size(0);
+    const int W = imgWidth, H = imgHeight;
+    auto f32 = xys.options().dtype(torch::kFloat32);
+    auto i32 = xys.options().dtype(torch::kInt32);
+    gs_stream_t s = current_stream();
+
+    Tensor packed = torch::empty({N, GS_SPLAT_DWORDS}, f32);
+    Tensor tilesHit = torch::empty({N}, i32), cum = torch::empty({N}, i32);
+    check_status(gs_pack_splats(W, H, (int)N, fptr(xys), fptr(depths), radii.data_ptr<int32_t>(),
+                                fptr(conics), fptr(colors), fptr(opacity),
+                                cov2d.defined() ? fptr(cov2d) : nullptr, fptr_mut(packed),
+                                tilesHit.data_ptr<int32_t>(), s),
+                 "gs_pack_splats");
+
+    // The intersection count sizes the sort: one pinned int, one stream sync — the same place the
+    // reference blocks (rasterize_gaussians.cpp:62-63).
+    Tensor mHost = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    size_t scanBytes = gs_bin_workspace_bytes((int)N, 0, W, H);
+    Tensor scanWs = torch::empty({(int64_t)scanBytes}, xys.options().dtype(torch::kUInt8));
+    check_status(gs_bin_scan((int)N, tilesHit.data_ptr<int32_t>(), cum.data_ptr<int32_t>(),
+                             mHost.data_ptr<int32_t>(), scanWs.data_ptr(), scanBytes, s),
+                 "gs_bin_scan");
+    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
+    const int64_t M = N > 0 ? mHost.data_ptr<int32_t>()[0] : 0;
+
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    Tensor idsSorted = torch::empty({M}, i32);
+    Tensor tileBins = torch::empty({tiles, 2}, i32);
+    size_t wsBytes = gs_bin_workspace_bytes((int)N, M, W, H);
+    Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
+    check_status(gs_bin_sort(W, H, (int)N, (int32_t)M, fptr(packed), cum.data_ptr<int32_t>(),
+                             nullptr, nullptr, nullptr, idsSorted.data_ptr<int32_t>(),
+                             tileBins.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
+                 "gs_bin_sort");
+    return std::make_tuple(packed, idsSorted, tileBins, M);
+}
+
+// ---- RasterizeGaussians -------------------------------------------------------------------------
+Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor depths, Tensor radii,
+                                   Tensor conics, Tensor numTilesHit, Tensor colors,
+                                   Tensor opacity, int64_t imgHeight, int64_t imgWidth,
+                                   Tensor background, Tensor cov2d) {
+    (void)numTilesHit;  // recounted from the pixel rectangle inside binAndSortGaussians
+    GS_CHECK_DEV(xys); GS_CHECK_DEV(depths); GS_CHECK_DEV(radii); GS_CHECK_DEV(conics);
+    GS_CHECK_DEV(colors); GS_CHECK_DEV(opacity);
+    GS_CHECK_F32(xys); GS_CHECK_F32(depths); GS_CHECK_I32(radii); GS_CHECK_F32(conics);
+    GS_CHECK_F32(colors); GS_CHECK_F32(opacity);
+    const int64_t N = xys.size(0);
+    TORCH_CHECK(xys.dim() == 2 && xys.size(1) == 2, "xys must be [N,2]");
+    TORCH_CHECK(conics.dim() == 2 && conics.size(0) == N && conics.size(1) == 3, "conics must be [N,3]");
+    TORCH_CHECK(colors.dim() == 2 && colors.size(0) == N && colors.size(1) == 3,
+                "colors must be [N,3] (3 channels; forward.cu:256-378)");
+    TORCH_CHECK(opacity.numel() == N, "opacity must have N elements");
+    TORCH_CHECK(background.numel() == 3, "background must have 3 elements");
+    if (cov2d.defined()) {
+        GS_CHECK_DEV(cov2d); GS_CHECK_F32(cov2d);
+        TORCH_CHECK(cov2d.numel() == 3 * N, "cov2d must be [N,3] = (xx, xy, yy)");
+        cov2d = cov2d.contiguous();
+    }
+    c10::DeviceGuard guard(xys.device());
+    xys = xys.contiguous(); depths = depths.contiguous(); radii = radii.contiguous();
+    conics = conics.contiguous(); colors = colors.contiguous(); opacity = opacity.contiguous();
+    const int W = (int)imgWidth, H = (int)imgHeight;
+
+    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W);
+    Tensor packed = std::get<0>(b), idsSorted = std::get<1>(b), tileBins = std::get<2>(b);
+
+    Tensor bgHost = background.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+    const float *bg = bgHost.data_ptr<float>();
+    auto f32 = xys.options();
+    Tensor outImg = torch::empty({H, W, 3}, f32), finalTs = torch::empty({H, W}, f32);
+    Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
+    const uint32_t flags = g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u;
+    check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
+                                      tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                      fptr_mut(outImg), fptr_mut(finalTs),
+                                      finalIdx.data_ptr<int32_t>(), flags, current_stream()),
+                 "gs_rasterize_forward");
+
+    ctx->saved_data["imgWidth"] = imgWidth;
+    ctx->saved_data["imgHeight"] = imgHeight;
+    ctx->saved_data["bg0"] = (double)bg[0];
+    ctx->saved_data["bg1"] = (double)bg[1];
+    ctx->saved_data["bg2"] = (double)bg[2];
+    ctx->saved_data["flags"] = (int64_t)flags;
+    ctx->saved_data["numPoints"] = N;
+    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx});
+    return outImg;
+}
+
+tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_outputs) {
+    const int W = (int)ctx->saved_data["imgWidth"].toInt(), H = (int)ctx->saved_data["imgHeight"].toInt();
+    const int64_t N = ctx->saved_data["numPoints"].toInt();
+    variable_list saved = ctx->get_saved_variables();
+    Tensor idsSorted = saved[0], tileBins = saved[1], packed = saved[2];
+    Tensor finalTs = saved[3], finalIdx = saved[4];
+    c10::DeviceGuard guard(packed.device());
+    Tensor v_outImg = grad_outputs[0].contiguous();
+    GS_CHECK_F32(v_outImg);
+    const float bg[3] = {(float)ctx->saved_data["bg0"].toDouble(),
+                         (float)ctx->saved_data["bg1"].toDouble(),
+                         (float)ctx->saved_data["bg2"].toDouble()};
+    auto f32 = packed.options();
+    // accumulated with atomics -> zero-filled (reference: bindings.cu:591-598)
+    Tensor v_xy = torch::zeros({N, 2}, f32), v_conic = torch::zeros({N, 3}, f32);
+    Tensor v_colors = torch::zeros({N, 3}, f32), v_opacity = torch::zeros({N, 1}, f32);
+    check_status(gs_rasterize_backward(W, H, idsSorted.data_ptr<int32_t>(),
+                                       tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                       fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
+                                       nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
+                                       fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
+                                       fptr_mut(v_opacity),
+                                       (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
+                 "gs_rasterize_backward");
+    Tensor none;
+    return {v_xy, none, none, v_conic, none, v_colors, v_opacity, none, none, none, none};
+}
+
+// ---- SphericalHarmonics ---------------------------------------------------------------------------
+Tensor SphericalHarmonics::forward(AutogradContext *ctx, int64_t degreesToUse, Tensor viewDirs,
+                                   Tensor coeffs) {
+    GS_CHECK_DEV(viewDirs); GS_CHECK_DEV(coeffs); GS_CHECK_F32(viewDirs); GS_CHECK_F32(coeffs);
+    TORCH_CHECK(coeffs.dim() == 3 && coeffs.size(2) == 3, "coeffs must have dimensions (N, D, 3)");
+    const int64_t N = coeffs.size(0), K = coeffs.size(1);
+    TORCH_CHECK(viewDirs.dim() == 2 && viewDirs.size(0) == N && viewDirs.size(1) == 3,
+                "viewDirs must be [N,3]");
+    c10::DeviceGuard guard(coeffs.device());
+    viewDirs = viewDirs.contiguous(); coeffs = coeffs.contiguous();
+    Tensor colors = torch::empty({N, 3}, coeffs.options());
+    check_status(gs_sh_forward((int)N, (int)K, (int)degreesToUse, fptr(viewDirs), fptr(coeffs),
+                               fptr_mut(colors), current_stream()),
+                 "gs_sh_forward");
+    ctx->saved_data["degreesToUse"] = degreesToUse;
+    ctx->saved_data["numBases"] = K;
+    ctx->save_for_backward({viewDirs});
+    return colors;
+}
+
+tensor_list SphericalHarmonics::backward(AutogradContext *ctx, tensor_list grad_outputs) {
+    Tensor viewDirs = ctx->get_saved_variables()[0];
+    const int64_t N = viewDirs.size(0), K = ctx->saved_data["numBases"].toInt();
+    c10::DeviceGuard guard(viewDirs.device());
+    Tensor v_colors = grad_outputs[0].contiguous();
+    Tensor v_coeffs = torch::empty({N, K, 3}, viewDirs.options());
+    check_status(gs_sh_backward((int)N, (int)K, (int)ctx->saved_data["degreesToUse"].toInt(),
+                                fptr(viewDirs), fptr(v_colors), fptr_mut(v_coeffs), current_stream()),
+                 "gs_sh_backward");
+    Tensor none;
+    return {none, none, v_coeffs};
+}
+
+// ---- Python-visible registration (torch.ops.opensplat_amd.*) -------------------------------------
+namespace {
+
+std::vector<Tensor> op_project_gaussians(const Tensor &means, const Tensor &scales, double globScale,
+                                         const Tensor &quats, const Tensor &viewMat,
+                                         const Tensor &projMat, double fx, double fy, double cx,
+                                         double cy, int64_t imgHeight, int64_t imgWidth,
+                                         double clipThresh) {
+    TileBounds tb = std::make_tuple((int)((imgWidth + BLOCK_X - 1) / BLOCK_X),
+                                    (int)((imgHeight + BLOCK_Y - 1) / BLOCK_Y), 1);
+    return ProjectGaussians::apply(means, scales, globScale, quats, viewMat, projMat, fx, fy, cx, cy,
+                                   imgHeight, imgWidth, tb, clipThresh);
+}
+
+Tensor op_rasterize_gaussians(const Tensor &xys, const Tensor &depths, const Tensor &radii,
+                              const Tensor &conics, const Tensor &numTilesHit, const Tensor &colors,
+                              const Tensor &opacity, int64_t imgHeight, int64_t imgWidth,
+                              const Tensor &background, const c10::optional<Tensor> &cov2d) {
+    return RasterizeGaussians::apply(xys, depths, radii, conics, numTilesHit, colors, opacity,
+                                     imgHeight, imgWidth, background,
+                                     cov2d.has_value() ? *cov2d : Tensor());
+}
+
+Tensor op_spherical_harmonics(int64_t degreesToUse, const Tensor &viewDirs, const Tensor &coeffs) {
+    return SphericalHarmonics::apply(degreesToUse, viewDirs, coeffs);
+}
+
+void op_set_fast_exp(bool enabled) { gsplatSetFastExp(enabled); }
+
+}  // namespace
+
+TORCH_LIBRARY(opensplat_amd, m) {
+    m.def("project_gaussians(Tensor means, Tensor scales, float glob_scale, Tensor quats, "
+          "Tensor viewmat, Tensor projmat, float fx, float fy, float cx, float cy, int img_height, "
+          "int img_width, float clip_thresh=0.01) -> Tensor[]",
+          &op_project_gaussians);
+    m.def("rasterize_gaussians(Tensor xys, Tensor depths, Tensor radii, Tensor conics, "
+          "Tensor num_tiles_hit, Tensor colors, Tensor opacity, int img_height, int img_width, "
+          "Tensor background, Tensor? cov2d=None) -> Tensor",
+          &op_rasterize_gaussians);
+    m.def("spherical_harmonics(int degrees_to_use, Tensor viewdirs, Tensor coeffs) -> Tensor",
+          &op_spherical_harmonics);
+    m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
+}

@@ -1,0 +1,67 @@
+"""Python view of the C++ autograd operators (opensplat_amd/csrc/torch_ops.cpp).
+
+Names, argument order and meaning follow OpenSplat's operators:
+  project_gaussians    <- ProjectGaussians::apply    (project_gaussians.hpp:12-30)
+  rasterize_gaussians  <- RasterizeGaussians::apply  (rasterize_gaussians.hpp:23-37)
+  spherical_harmonics  <- SphericalHarmonics::apply  (spherical_harmonics.hpp:15-22)
+Inputs must be float32/int32 tensors on the GPU; anything else raises (c10::Error -> RuntimeError),
+as the reference's CHECK_INPUT does (rasterizer/gsplat/bindings.h:14-19).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import _build
+
+_LIB = _build.TORCH_LIB
+if not os.path.exists(_LIB) or not os.path.exists(_build.HIP_LIB):
+    raise ImportError(
+        "opensplat_amd native libraries are not built (%s). Run `python -m opensplat_amd._build`; "
+        "there is no CPU/PyTorch fallback." % _LIB)
+torch.ops.load_library(_LIB)
+_ops = torch.ops.opensplat_amd
+
+BLOCK_X = BLOCK_Y = 16  # rasterizer/gsplat/config.h:1-2
+
+
+def project_gaussians(means, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy,
+                      img_height, img_width, tile_bounds=None, clip_thresh=0.01):
+    """-> [xys, depths, radii, conics, num_tiles_hit, cov3d, cov2d] (first six = the reference's)."""
+    return _ops.project_gaussians(means, scales, float(glob_scale), quats, viewmat, projmat,
+                                  float(fx), float(fy), float(cx), float(cy), int(img_height),
+                                  int(img_width), float(clip_thresh))
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                        img_width, background, cov2d=None):
+    """-> image [H, W, 3].  Pass `cov2d` (7th output of project_gaussians) for exact gsplat-cpu
+    pixel-rectangle semantics; without it the rectangle is re-derived from the conics."""
+    return _ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
+                                    int(img_height), int(img_width), background, cov2d)
+
+
+def spherical_harmonics(degrees_to_use, viewdirs, coeffs):
+    """-> colors [N, 3] for coeffs [N, K, 3], K in {1, 4, 9, 16, 25}."""
+    return _ops.spherical_harmonics(int(degrees_to_use), viewdirs, coeffs)
+
+
+def set_fast_exp(enabled: bool) -> None:
+    """Switch the compositing kernels to the hardware exp (not bit-compatible with gsplat-cpu)."""
+    _ops.set_fast_exp(bool(enabled))
+
+
+def deg_from_sh(num_bases: int) -> int:  # spherical_harmonics.cpp:3-16
+    return {1: 0, 4: 1, 9: 2, 16: 3}.get(int(num_bases), 4)
+
+
+_C0 = 0.28209479177387814
+
+
+def rgb2sh(rgb):  # spherical_harmonics.cpp:20-23
+    return (rgb - 0.5) / _C0
+
+
+def sh2rgb(sh):  # spherical_harmonics.cpp:25-28
+    return torch.clamp(sh * _C0 + 0.5, 0.0, 1.0)

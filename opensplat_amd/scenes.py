@@ -1,0 +1,173 @@
+"""Seeded synthetic scenes for the parity tests and bench.py.
+
+Pure numpy/torch-CPU generators: the same bits go to the CPU oracle and (after .to(device)) to the
+HIP kernels.  Nothing here touches the oracle or the native libraries.
+
+  simple_trainer_scene  C1: OpenSplat's own synthetic set-up (simple_trainer.cpp:79-146)
+  camera_scene          C2/C3-style: camera at the origin looking down +z, Gaussians with a
+                        controlled pixel-space footprint, SH colours
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+BACKGROUND = (0.6130, 0.0101, 0.3984)  # model.hpp:54
+
+
+@dataclass
+class Scene:
+    name: str
+    W: int
+    H: int
+    means: np.ndarray          # [N,3]
+    scales: np.ndarray         # [N,3]  (already exp'd, as the operators receive them)
+    quats: np.ndarray          # [N,4]  (w,x,y,z)
+    opacities: np.ndarray      # [N,1]  (already sigmoid'ed)
+    viewmat: np.ndarray        # [4,4]
+    projmat: np.ndarray        # [4,4]  full projection handed to ProjectGaussians
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    background: np.ndarray     # [3]
+    colors: np.ndarray | None = None    # [N,3]  when there is no SH node (C1)
+    sh_coeffs: np.ndarray | None = None  # [N,K,3]
+    dirs: np.ndarray | None = None       # [N,3] unit view directions
+    degrees_to_use: int = 0
+    v_out: np.ndarray | None = None      # [H,W,3] cotangent
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def N(self) -> int:
+        return int(self.means.shape[0])
+
+    @property
+    def K(self) -> int:
+        return 0 if self.sh_coeffs is None else int(self.sh_coeffs.shape[1])
+
+
+def projection_matrix(znear: float, zfar: float, fovx: float, fovy: float) -> np.ndarray:
+    """OpenGL-style perspective matrix as OpenSplat builds it (model.cpp:35-47)."""
+    t = znear * math.tan(0.5 * fovy)
+    b = -t
+    r = znear * math.tan(0.5 * fovx)
+    l = -r
+    return np.array([[2.0 * znear / (r - l), 0.0, (r + l) / (r - l), 0.0],
+                     [0.0, 2.0 * znear / (t - b), (t + b) / (t - b), 0.0],
+                     [0.0, 0.0, (zfar + znear) / (zfar - znear), -1.0 * zfar * znear / (zfar - znear)],
+                     [0.0, 0.0, 1.0, 0.0]], dtype=np.float32)
+
+
+def random_quats(u, v, w) -> np.ndarray:
+    """simple_trainer.cpp:121-126 / model.cpp:24-32."""
+    return np.stack([np.sqrt(1.0 - u) * np.sin(2.0 * np.pi * v), np.sqrt(1.0 - u) * np.cos(2.0 * np.pi * v),
+                     np.sqrt(u) * np.sin(2.0 * np.pi * w), np.sqrt(u) * np.cos(2.0 * np.pi * w)],
+                    axis=-1).astype(np.float32)
+
+
+def simple_trainer_scene(N: int = 10_000, W: int = 256, H: int = 256, seed: int = 0) -> Scene:
+    """BASELINE config 1: exactly simple_trainer.cpp's tensors (torch CPU RNG, same draw order)."""
+    import torch
+
+    torch.manual_seed(seed)
+    means = 2.0 * (torch.rand(N, 3) - 0.5)
+    scales = torch.rand(N, 3)
+    rgbs = torch.rand(N, 3)
+    u, v, w = torch.rand(N, 1), torch.rand(N, 1), torch.rand(N, 1)
+    PI = math.pi
+    quats = torch.cat([torch.sqrt(1.0 - u) * torch.sin(2.0 * PI * v),
+                       torch.sqrt(1.0 - u) * torch.cos(2.0 * PI * v),
+                       torch.sqrt(u) * torch.sin(2.0 * PI * w),
+                       torch.sqrt(u) * torch.cos(2.0 * PI * w)], -1)
+    opacities = torch.ones(N, 1)
+    viewmat = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 8], [0, 0, 0, 1]], dtype=np.float32)
+    focal = 0.5 * W / math.tan(0.5 * (PI / 2.0))
+    gt = np.ones((H, W, 3), dtype=np.float32)
+    gt[: H // 2, : W // 2, :] = np.array([1.0, 0.0, 0.0], dtype=np.float32)
+    gt[H // 2:, W // 2:, :] = np.array([0.0, 0.0, 1.0], dtype=np.float32)
+    return Scene(name="C1_simple_trainer", W=W, H=H, means=means.numpy(), scales=scales.numpy(),
+                 quats=quats.numpy(), opacities=torch.sigmoid(opacities).numpy(),
+                 viewmat=viewmat, projmat=viewmat.copy(), fx=float(focal), fy=float(focal),
+                 cx=float(W // 2), cy=float(H // 2), background=np.zeros(3, dtype=np.float32),
+                 colors=torch.sigmoid(rgbs).numpy(), extra=dict(gt_image=gt, raw_rgbs=rgbs.numpy()))
+
+
+def camera_scene(N: int, W: int, H: int, K: int = 16, seed: int = 1, sigma_px=(0.5, 4.0),
+                 z_range=(2.0, 10.0), znear: float = 0.001, zfar: float = 1000.0,
+                 degrees_to_use: int | None = None, yaw_deg: float = 0.0, name: str | None = None,
+                 with_cotangent: bool = True) -> Scene:
+    """C2/C3-style scene: fovX = 90 deg, Gaussians spread over the image footprint
+    at depth z, pixel-space sigma log-uniform in `sigma_px` with per-axis anisotropy U(0.3, 1).
+
+    Depths lie on a jittered, shuffled grid so that no two Gaussians share a depth (the reference's
+    CPU sort is unstable, gsplat_cpu.cpp:155-159): spacing (z1-z0)/N.
+    """
+    rng = np.random.RandomState(seed)
+    fx = fy = 0.5 * W
+    cx, cy = W / 2.0, H / 2.0
+    fovx = 2.0 * math.atan(W / (2.0 * fx))
+    fovy = 2.0 * math.atan(H / (2.0 * fy))
+    z0, z1 = z_range
+    slot = rng.permutation(N).astype(np.float64)
+    z = z0 + (z1 - z0) * (slot + 0.25 + 0.5 * rng.rand(N)) / N
+    margin = 0.02
+    px = (margin + (1 - 2 * margin) * rng.rand(N)) * W
+    py = (margin + (1 - 2 * margin) * rng.rand(N)) * H
+    x = (px - cx) * z / fx
+    y = (py - cy) * z / fy
+    means = np.stack([x, y, z], -1).astype(np.float32)
+    s_px = np.exp(rng.uniform(math.log(sigma_px[0]), math.log(sigma_px[1]), size=N))
+    aniso = rng.uniform(0.3, 1.0, size=(N, 3))
+    scales = (s_px[:, None] * aniso * z[:, None] / fx).astype(np.float32)
+    quats = random_quats(rng.rand(N), rng.rand(N), rng.rand(N))
+    opac = 1.0 / (1.0 + np.exp(-rng.normal(0.0, 2.0, size=(N, 1))))
+    viewmat = np.eye(4, dtype=np.float32)
+    if yaw_deg != 0.0:  # rotate the camera about +y (C4: one camera per rank)
+        a = math.radians(yaw_deg)
+        R = np.array([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]],
+                     dtype=np.float32)
+        viewmat[:3, :3] = R
+    projmat = projection_matrix(znear, zfar, fovx, fovy) @ viewmat
+    sh = None
+    dirs = None
+    colors = None
+    if K > 0:
+        sh = np.empty((N, K, 3), dtype=np.float32)
+        sh[:, 0, :] = rng.uniform(-1.5, 1.5, size=(N, 3))
+        if K > 1:
+            sh[:, 1:, :] = rng.normal(0.0, 0.1, size=(N, K - 1, 3))
+        d = means.astype(np.float64)  # camera at the origin (model.cpp:176-177)
+        dirs = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    else:
+        colors = rng.rand(N, 3).astype(np.float32)
+    deg = {0: 0, 1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[K] if degrees_to_use is None else degrees_to_use
+    v_out = rng.uniform(-1.0, 1.0, size=(H, W, 3)).astype(np.float32) if with_cotangent else None
+    return Scene(name=name or f"camera_N{N}_{W}x{H}_K{K}_s{seed}", W=W, H=H, means=means,
+                 scales=scales, quats=quats, opacities=opac.astype(np.float32), viewmat=viewmat,
+                 projmat=projmat.astype(np.float32), fx=float(fx), fy=float(fy), cx=float(cx),
+                 cy=float(cy), background=np.array(BACKGROUND, dtype=np.float32), colors=colors,
+                 sh_coeffs=sh, dirs=dirs, degrees_to_use=deg, v_out=v_out)
+
+
+# The named BASELINE.json configurations
+def config_c1() -> Scene:
+    return simple_trainer_scene(10_000, 256, 256, seed=0)
+
+
+def config_c2(N: int = 1_000_000) -> Scene:
+    return camera_scene(N, 1920, 1080, K=16, seed=1, sigma_px=(0.5, 4.0), name="C2_1M_1080p_sh3")
+
+
+def config_c3(N: int = 5_000_000) -> Scene:
+    return camera_scene(N, 3840, 2160, K=16, seed=2, sigma_px=(1.0, 8.0), name="C3_5M_4k_sh3")
+
+
+def config_c4(rank: int, N: int = 1_000_000) -> Scene:
+    """C4: the C2 Gaussians seen by camera `rank` of 8 (yaw offsets)."""
+    yaws = [-14.0, -10.0, -6.0, -2.0, 2.0, 6.0, 10.0, 14.0]
+    s = camera_scene(N, 1920, 1080, K=16, seed=3, sigma_px=(0.5, 4.0), yaw_deg=yaws[rank % 8],
+                     name=f"C4_cam{rank}")
+    return s

@@ -1,0 +1,303 @@
+"""TEST INFRASTRUCTURE ONLY — numpy/ctypes front-ends of the two CPU checkers.
+
+* ``restated`` : oracle/libgsplat_oracle.so, the plain-C restatement (oracle/gsplat_oracle.c)
+* ``reference``: oracle/_ref/libgsplat_ref.so, OpenSplat's own gsplat-cpu sources compiled in
+  place from /root/reference (oracle/Makefile) behind oracle/ref_shim.cpp.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package (opensplat_amd/) never does.
+
+Both front-ends expose the same functions on numpy arrays:
+
+    project_forward, project_backward, sh_forward, sh_backward,
+    rasterize_forward (-> img, final_Ts, px_counts, contributor ids, state), rasterize_backward
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _fo(shape):
+    a = np.zeros(shape, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _io(shape):
+    a = np.zeros(shape, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+def build(ref: bool = True) -> None:
+    """Compile the C restatement and (when /root/reference is present) the reference build."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    if ref:
+        subprocess.check_call(["make", "-s", "-j5", "-C", _HERE, "ref"])
+
+
+class _Base:
+    """Shared numpy marshalling; subclasses bind the symbols."""
+
+    name = "?"
+
+    # --- projection ---------------------------------------------------------------------------
+    def project_forward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                        glob_scale=1.0, clip=0.01):
+        raise NotImplementedError
+
+    def project_backward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                         v_xys, v_conics, glob_scale=1.0, clip=0.01):
+        raise NotImplementedError
+
+
+class Restated(_Base):
+    name = "restated"
+
+    def __init__(self):
+        path = os.path.join(_HERE, "libgsplat_oracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = C.CDLL(path)
+        self.lib.orc_rasterize_forward.restype = C.c_void_p
+        self.lib.orc_rasterize_total.restype = C.c_int64
+        self.lib.orc_rasterize_total.argtypes = [C.c_void_p]
+        self.lib.orc_rasterize_contributors.argtypes = [C.c_void_p, _i32p]
+        self.lib.orc_rasterize_free.argtypes = [C.c_void_p]
+        self.lib.orc_expf.restype = C.c_float
+        self.lib.orc_expf.argtypes = [C.c_float]
+
+    def project_forward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                        glob_scale=1.0, clip=0.01):
+        N = len(means)
+        m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
+        vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
+        xys, xp = _fo((N, 2)); radii, rp = _io((N,)); con, cp = _fo((N, 3))
+        cov2d, c2p = _fo((N, 2, 2)); cd, cdp = _fo((N,)); dv, dvp = _fo((N,)); c3, c3p = _fo((N, 6))
+        self.lib.orc_project_forward(C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp,
+                                     C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                     C.c_int(H), C.c_int(W), C.c_float(clip), xp, rp, cp, c2p, cdp,
+                                     dvp, c3p)
+        return dict(xys=xys, radii=radii, conics=con, cov2d=cov2d, cam_depths=cd, depths=dv,
+                    cov3d=c3)
+
+    def project_backward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                         v_xys, v_conics, glob_scale=1.0, clip=0.01, v_depth=None):
+        N = len(means)
+        m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
+        vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
+        vx, vxp = _f(v_xys); vc, vcp = _f(v_conics)
+        if v_depth is not None:
+            vd, vdp = _f(v_depth)
+        else:
+            vdp = None
+        vmn, vmnp = _fo((N, 3)); vs, vsp = _fo((N, 3)); vq, vqp = _fo((N, 4))
+        self.lib.orc_project_backward(C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp,
+                                      C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                      C.c_int(H), C.c_int(W), C.c_float(clip), vxp, vcp, vdp,
+                                      vmnp, vsp, vqp)
+        return dict(v_means=vmn, v_scales=vs, v_quats=vq)
+
+    def sh_forward(self, degrees_to_use, dirs, coeffs):
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        d, dp = _f(dirs); c, cp = _f(coeffs); out, op = _fo((N, 3))
+        self.lib.orc_sh_forward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), dp, cp, op)
+        return out
+
+    def sh_backward(self, degrees_to_use, dirs, coeffs, v_colors):
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        d, dp = _f(dirs); v, vp = _f(v_colors); out, op = _fo((N, K, 3))
+        self.lib.orc_sh_backward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), dp, vp, op)
+        return out
+
+    def rasterize_forward(self, W, H, xys, conics, colors, opacities, background, cov2d,
+                          cam_depths, want_contributors=True):
+        N = len(xys)
+        x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
+        bg, bgp = _f(background); c2, c2p = _f(cov2d); cd, cdp = _f(cam_depths)
+        img, ip = _fo((H, W, 3)); fT, fp = _fo((H, W)); cnt, cntp = _io((H, W))
+        st = self.lib.orc_rasterize_forward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op,
+                                            bgp, c2p, cdp, ip, fp, cntp)
+        ids = None
+        if want_contributors:
+            total = self.lib.orc_rasterize_total(C.c_void_p(st))
+            ids, idp = _io((max(int(total), 1),))
+            self.lib.orc_rasterize_contributors(C.c_void_p(st), idp)
+            ids = ids[: int(total)]
+        return dict(img=img, final_Ts=fT, px_counts=cnt, contributors=ids, state=st)
+
+    def rasterize_backward(self, W, H, xys, conics, colors, opacities, background, cov2d,
+                           cam_depths, final_Ts, state, v_out, free=True):
+        N = len(xys)
+        x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
+        bg, bgp = _f(background); fT, fp = _f(final_Ts); vo, vop = _f(v_out)
+        vxy, vxyp = _fo((N, 2)); vcn, vcnp = _fo((N, 3)); vco, vcop = _fo((N, 3)); vop_, vopp = _fo((N,))
+        self.lib.orc_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp,
+                                        fp, C.c_void_p(state), vop, None, vxyp, vcnp, vcop, vopp)
+        if free:
+            self.lib.orc_rasterize_free(C.c_void_p(state))
+        return dict(v_xy=vxy, v_conic=vcn, v_colors=vco, v_opacity=vop_)
+
+    def rasterize_free(self, state):
+        self.lib.orc_rasterize_free(C.c_void_p(state))
+
+    def expf(self, x):
+        x, xp = _f(x)
+        y, yp = _fo(x.shape)
+        self.lib.orc_expf_array(C.c_int64(x.size), xp, yp)
+        return y
+
+
+class Reference(_Base):
+    name = "reference"
+
+    def __init__(self):
+        import torch  # noqa: F401  (libgsplat_ref.so links libtorch_cpu; load it first)
+
+        path = os.path.join(_HERE, "_ref", "libgsplat_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.ref_last_error.restype = C.c_char_p
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("reference threw: " + self.lib.ref_last_error().decode())
+
+    def num_threads(self):
+        return int(self.lib.ref_num_threads())
+
+    def project_forward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                        glob_scale=1.0, clip=0.01):
+        N = len(means)
+        m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
+        vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
+        xys, xp = _fo((N, 2)); radii, rp = _io((N,)); con, cp = _fo((N, 3))
+        cov2d, c2p = _fo((N, 2, 2)); cd, cdp = _fo((N,))
+        self._chk(self.lib.ref_project_forward(
+            C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp, C.c_float(fx), C.c_float(fy),
+            C.c_float(cx), C.c_float(cy), C.c_int(H), C.c_int(W), C.c_float(clip), xp, rp, cp, c2p,
+            cdp))
+        return dict(xys=xys, radii=radii, conics=con, cov2d=cov2d, cam_depths=cd)
+
+    def project_backward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
+                         v_xys, v_conics, glob_scale=1.0, clip=0.01):
+        N = len(means)
+        m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
+        vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
+        vx, vxp = _f(v_xys); vc, vcp = _f(v_conics)
+        vmn, vmnp = _fo((N, 3)); vs, vsp = _fo((N, 3)); vq, vqp = _fo((N, 4))
+        self._chk(self.lib.ref_project_backward(
+            C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp, C.c_float(fx), C.c_float(fy),
+            C.c_float(cx), C.c_float(cy), C.c_int(H), C.c_int(W), C.c_float(clip), vxp, vcp, vmnp,
+            vsp, vqp))
+        return dict(v_means=vmn, v_scales=vs, v_quats=vq)
+
+    def sh_forward(self, degrees_to_use, dirs, coeffs):
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        d, dp = _f(dirs); c, cp = _f(coeffs); out, op = _fo((N, 3))
+        self._chk(self.lib.ref_sh_forward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), dp, cp, op))
+        return out
+
+    def sh_backward(self, degrees_to_use, dirs, coeffs, v_colors):
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        d, dp = _f(dirs); c, cp = _f(coeffs); v, vp = _f(v_colors); out, op = _fo((N, K, 3))
+        self._chk(self.lib.ref_sh_backward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), dp, cp,
+                                           vp, op))
+        return out
+
+    def rasterize_forward(self, W, H, xys, conics, colors, opacities, background, cov2d,
+                          cam_depths, want_contributors=True):
+        N = len(xys)
+        x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
+        bg, bgp = _f(background); c2, c2p = _f(cov2d); cd, cdp = _f(cam_depths)
+        img, ip = _fo((H, W, 3)); fT, fp = _fo((H, W)); cnt, cntp = _io((H, W))
+        st = C.c_void_p()
+        self._chk(self.lib.ref_rasterize_forward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop,
+                                                 op, bgp, c2p, cdp, ip, fp, cntp, C.byref(st)))
+        ids = None
+        if want_contributors:
+            total = int(cnt.sum())
+            ids, idp = _io((max(total, 1),))
+            self.lib.ref_rasterize_contributors(st, idp)
+            ids = ids[:total]
+        return dict(img=img, final_Ts=fT, px_counts=cnt, contributors=ids, state=st)
+
+    def rasterize_backward(self, W, H, xys, conics, colors, opacities, background, cov2d,
+                           cam_depths, final_Ts, state, v_out, free=True):
+        N = len(xys)
+        x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
+        bg, bgp = _f(background); c2, c2p = _f(cov2d); cd, cdp = _f(cam_depths)
+        fT, fp = _f(final_Ts); vo, vop = _f(v_out)
+        vxy, vxyp = _fo((N, 2)); vcn, vcnp = _fo((N, 3)); vco, vcop = _fo((N, 3)); vop_, vopp = _fo((N,))
+        # NB the reference deletes px2gid itself only inside RasterizeGaussiansCPU::backward;
+        # through the raw *_tensor_cpu functions the shim owns it.
+        self._chk(self.lib.ref_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop,
+                                                  op, bgp, c2p, cdp, fp, state, vop, vxyp, vcnp,
+                                                  vcop, vopp))
+        if free:
+            self.lib.ref_rasterize_free(state)
+        return dict(v_xy=vxy, v_conic=vcn, v_colors=vco, v_opacity=vop_)
+
+    def rasterize_free(self, state):
+        self.lib.ref_rasterize_free(state)
+
+    def chain_fwd_bwd(self, means, scales, quats, dirs, coeffs, opacities, viewmat, projmat, fx,
+                      fy, cx, cy, H, W, background, v_out, degrees_to_use=0):
+        """Whole hot path through the reference's op wrappers; coeffs [N,K,3] or colours [N,3]."""
+        N = len(means)
+        K = coeffs.shape[1] if coeffs.ndim == 3 else 0
+        m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
+        if dirs is not None:
+            d, dp = _f(dirs)
+        else:
+            dp = None
+        c, cp = _f(coeffs); o, op = _f(opacities)
+        vm, vmp = _f(viewmat); pm, pmp = _f(projmat); bg, bgp = _f(background)
+        img, ip = _fo((H, W, 3))
+        vmn, vmnp = _fo((N, 3)); vs, vsp = _fo((N, 3)); vq, vqp = _fo((N, 4))
+        vc, vcp = _fo(coeffs.shape); vo_, vop_ = _fo((N,))
+        if v_out is not None:
+            vout, voutp = _f(v_out)
+        else:
+            voutp = None
+        times = (C.c_double * 2)()
+        self._chk(self.lib.ref_chain_fwd_bwd(
+            C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), mp, sp, qp, dp, cp, op, vmp, pmp,
+            C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(H), C.c_int(W),
+            bgp, voutp, ip, vmnp, vsp, vqp, vcp, vop_, times))
+        return dict(img=img, v_means=vmn, v_scales=vs, v_quats=vq, v_coeffs=vc, v_opacities=vo_,
+                    fwd_ms=times[0], bwd_ms=times[1])
+
+
+_restated = None
+_reference = None
+
+
+def restated() -> Restated:
+    global _restated
+    if _restated is None:
+        _restated = Restated()
+    return _restated
+
+
+def reference() -> Reference:
+    global _reference
+    if _reference is None:
+        _reference = Reference()
+    return _reference
+
+
+def have_reference() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libgsplat_ref.so"))

@@ -1,0 +1,105 @@
+"""-m gpu: HIP kernels (through the C ABI) against the CPU oracle on identical inputs.
+
+Stage tests feed the oracle the HIP stage's own inputs so that each kernel is checked in
+isolation; the compositing stages are required to be BIT-EXACT in the forward direction
+(image, final_Ts, contributor sets) and within fp32 summation-order tolerance in the backward.
+"""
+import numpy as np
+import pytest
+
+from opensplat_amd import scenes
+from tests.util import hip_pipeline, np_, oracle_raster, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _contributor_counts_from_hip(out, s):
+    """Per-pixel contributor count recomputed from final_idx is not available directly; compare
+    final_Ts / image / final_idx-derived last contributor instead."""
+    return None
+
+
+SCENES = {
+    "c1_small": lambda: scenes.simple_trainer_scene(3000, 128, 96, seed=0),
+    "camera_sh3": lambda: scenes.camera_scene(20000, 400, 240, K=16, seed=7, znear=1.0, zfar=100.0),
+    "camera_ragged": lambda: scenes.camera_scene(5000, 203, 117, K=4, seed=11, sigma_px=(1.0, 6.0),
+                                                 znear=1.0, zfar=100.0),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_projection_forward(name, restated):
+    s = SCENES[name]()
+    out = hip_pipeline(s, backward=False)
+    o = restated.project_forward(s.means, s.scales, s.quats, s.viewmat, s.projmat, s.fx, s.fy,
+                                 s.cx, s.cy, s.H, s.W)
+    assert rel_err(np_(out["xys"]), o["xys"]) < 2e-6
+    assert rel_err(np_(out["conics"]), o["conics"]) < 1e-4
+    c2 = o["cov2d"].reshape(-1, 4)[:, [0, 1, 3]]
+    assert rel_err(np_(out["cov2d"]), c2) < 1e-4
+    assert rel_err(np_(out["depths"]), o["depths"]) < 1e-6
+    assert rel_err(np_(out["cov3d"]), o["cov3d"]) < 1e-5
+    assert (np_(out["radii"]) != o["radii"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_rasterize_forward_bit_exact(name, restated):
+    s = SCENES[name]()
+    out = hip_pipeline(s, backward=False)
+    f, _ = oracle_raster(restated, s, np_(out["xys"]), np_(out["conics"]), np_(out["colors"]),
+                         np_(out["cov2d"]), np_(out["depths"]))
+    assert np.array_equal(np_(out["final_Ts"]), f["final_Ts"])
+    assert np.array_equal(np_(out["img"]), f["img"])
+    # last contributor per pixel: oracle lists are back-to-front, so the first id of each list
+    ids_sorted = np_(out["binned"].gaussian_ids_sorted)
+    fi = np_(out["final_idx"]).ravel()
+    counts = f["px_counts"].ravel()
+    offs = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    has = counts > 0
+    assert np.array_equal(fi >= 0, has)
+    assert np.array_equal(ids_sorted[fi[has]], f["contributors"][offs[has]])
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_rasterize_backward(name, restated):
+    s = SCENES[name]()
+    if s.v_out is None:
+        s.v_out = np.random.RandomState(3).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
+    out = hip_pipeline(s, backward=True)
+    f, g = oracle_raster(restated, s, np_(out["xys"]), np_(out["conics"]), np_(out["colors"]),
+                         np_(out["cov2d"]), np_(out["depths"]), s.v_out)
+    for k in ["v_xy", "v_conic", "v_colors", "v_opacity"]:
+        assert rel_err(np_(out[k]), g[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_projection_backward(name, restated):
+    s = SCENES[name]()
+    if s.v_out is None:
+        s.v_out = np.random.RandomState(3).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
+    out = hip_pipeline(s, backward=True)
+    o = restated.project_backward(s.means, s.scales, s.quats, s.viewmat, s.projmat, s.fx, s.fy,
+                                  s.cx, s.cy, s.H, s.W, np_(out["v_xy"]), np_(out["v_conic"]))
+    vis = np_(out["radii"]) > 0
+    for k in ["v_means", "v_scales", "v_quats"]:
+        assert rel_err(np_(out[k])[vis], o[k][vis]) < 5e-5, k
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh(deg, restated):
+    import torch
+
+    from opensplat_amd import cabi
+    from tests.util import to_dev
+
+    s = scenes.camera_scene(10007, 64, 64, K=16, seed=2)
+    dirs, coeffs = to_dev(s.dirs), to_dev(s.sh_coeffs)
+    c = cabi.sh_forward(deg, dirs, coeffs)
+    ref = restated.sh_forward(deg, s.dirs, s.sh_coeffs)
+    assert np.abs(np_(c) - ref).max() < 2e-6
+    v = np.random.RandomState(0).randn(s.N, 3).astype(np.float32)
+    g = cabi.sh_backward(deg, 16, dirs, to_dev(v))
+    gref = restated.sh_backward(deg, s.dirs, s.sh_coeffs, v)
+    assert np.abs(np_(g) - gref).max() < 1e-6
+    nb = (deg + 1) ** 2
+    assert np.all(np_(g)[:, nb:, :] == 0)
