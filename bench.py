@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""bench.py — full forward+backward rasterizations per second of the MI355X rasterizer.
+
+One "step" = one complete pass of the hot path over one camera (BASELINE.json metric):
+    project fwd -> SH fwd -> clamp_min(+0.5) -> pack/scan/sort/bin -> composite fwd
+    -> composite bwd -> clamp backward -> SH bwd -> project bwd   [-> RCCL all-reduce if N > 1]
+producing the image and all six parameter gradients.  Every stage goes through the C ABI of
+libgsplat_hip.so (include/gsplat_hip.h); torch only provides device memory, the stream and, for
+N > 1, torch.distributed (nccl == RCCL).
+
+Workload: N = 1 -> BASELINE configs[1] ("C2": 1 M Gaussians, 1920x1080, SH degree 3, 16x16
+tiles, seeded synthetic scene of SURVEY.md §8d).  N > 1 -> configs[3] ("C4"): the same number of
+shared Gaussians, one camera per rank, gradients all-reduced over xGMI; weak scaling (one camera
+per GPU), value = cameras rasterized per second by the whole job.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      dominant kernel: algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak
+  cpu_baseline  OpenSplat's own gsplat-cpu (oracle/_ref, compiled from /root/reference) timed on
+                this host's cores on the same scene — only here is anything under oracle/ used.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4"])
+    ap.add_argument("--fast-exp", action="store_true",
+                    help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-gaussians", type=int, default=0,
+                    help="Gaussians in the CPU-baseline sample (0 = the whole workload)")
+    return ap.parse_args()
+
+
+class Pipeline:
+    """The hot path on one GPU with every buffer preallocated."""
+
+    def __init__(self, scene, device, flags):
+        import torch
+
+        from opensplat_amd import cabi, dist
+
+        self.torch, self.cabi, self.dist = torch, cabi, dist
+        s = self.s = scene
+        self.flags = flags
+        dev = self.dev = device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.means, self.scales, self.quats = t(s.means), t(s.scales), t(s.quats)
+        self.opac = t(s.opacities.reshape(-1))
+        self.dirs, self.coeffs = t(s.dirs), t(s.sh_coeffs)
+        self.v_out = t(s.v_out)
+        self.vm_dev, self.pm_dev = t(s.viewmat), t(s.projmat)
+        self.cam = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H)
+        N, K, W, H = s.N, s.K, s.W, s.H
+        f = dict(device=dev, dtype=torch.float32)
+        i = dict(device=dev, dtype=torch.int32)
+        self.proj = dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
+                         radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
+                         num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
+                         cov2d=torch.empty((N, 3), **f))
+        self.sh_rgb = torch.empty((N, 3), **f)
+        self.ws = cabi.BinWorkspace()
+        self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
+                        final_idx=torch.empty((H, W), **i))
+        # 2-D gradients accumulated with atomics: one flat buffer, one memset per step
+        self.g2d = torch.zeros(N * 9, **f)
+        self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
+                           v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.g2d[8 * N:])
+        self.grads = dist.GradBuffer(N, K, dev)
+        self.pb_out = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
+                           v_quats=self.grads.v_quats)
+        self.num_isects = 0
+        self.stage_names = ["project_fwd", "sh_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
+                            "sh_bwd", "project_bwd", "allreduce"]
+
+    def step(self, events=None):
+        torch, cabi, s = self.torch, self.cabi, self.s
+
+        def mark():
+            if events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                events.append(e)
+
+        mark()
+        p = cabi.project_forward(self.cam, self.means, self.scales, self.quats, self.vm_dev,
+                                 self.pm_dev, out=self.proj)
+        mark()
+        rgb = cabi.sh_forward(s.degrees_to_use, self.dirs, self.coeffs, out=self.sh_rgb)
+        colors = torch.clamp_min(rgb + 0.5, 0.0)  # model.cpp:192
+        mark()
+        b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
+                              self.opac, p["cov2d"], self.ws, keep_unsorted=False)
+        self.num_isects = b.num_isects
+        mark()
+        f = cabi.rasterize_forward(s.W, s.H, b, s.background, self.flags, out=self.fwd)
+        mark()
+        self.g2d.zero_()
+        g = cabi.rasterize_backward(s.W, s.H, s.N, b, s.background, f["final_Ts"], f["final_idx"],
+                                    self.v_out, self.flags, out=self.rgrads)
+        mark()
+        v_rgb = g["v_colors"] * (rgb > -0.5)  # backward of clamp_min(rgb + 0.5, 0)
+        cabi.sh_backward(s.degrees_to_use, s.K, self.dirs, v_rgb, out=self.grads.v_sh)
+        w1 = self.dist.allreduce_sh_async(self.grads)  # overlaps the projection backward
+        mark()
+        # opacity gradient: the op surface returns d/d(sigmoid(opacity)); copy into the flat buffer
+        self.grads.v_opacity.copy_(g["v_opacity"])
+        cabi.project_backward(self.cam, self.means, self.scales, self.quats, p["radii"], g["v_xy"],
+                              g["v_conic"], None, self.vm_dev, self.pm_dev, out=self.pb_out)
+        mark()
+        w2 = self.dist.allreduce_rest_async(self.grads)
+        self.dist.wait_all(w1, w2)
+        mark()
+
+
+def algorithmic_bytes(N, K, M, P):
+    """compulsory HBM traffic of one fwd+bwd, and the per-kernel shares used for
+    roofline.achieved (stated in DESIGN.md §Measurement)."""
+    total = N * (244 + 24 * K) + 100 * M + 40 * P
+    per_stage = {
+        "project_fwd": N * (40 + 44),            # read means/scales/quats, write xy conic depth radii tiles (+cov)
+        "sh_fwd": N * (12 + 12 * K + 12),        # dirs + coeffs -> rgb
+        "bin_sort": 24 * M + N * 52,             # write + read (key,id) once; pack reads
+        "rasterize_fwd": 40 * M + 20 * P,        # id 4 + gather 36 per intersection; rgb/T/idx per pixel
+        "rasterize_bwd": 40 * M + 20 * P + 36 * N,  # + 9 accumulated floats per Gaussian
+        "sh_bwd": N * (24 + 12 * K),
+        "project_bwd": N * (40 + 36 + 40),
+    }
+    return total, per_stage
+
+
+def cpu_baseline(scene, n_sample):
+    """OpenSplat's gsplat-cpu (oracle/_ref) or, if that build is absent, the C restatement."""
+    import oracle
+
+    s = scene
+    n = s.N if n_sample <= 0 else min(n_sample, s.N)
+    sl = slice(0, n)
+    cores = os.cpu_count() or 1
+    if oracle.have_reference():
+        R = oracle.reference()
+        t0 = time.time()
+        r = R.chain_fwd_bwd(s.means[sl], s.scales[sl], s.quats[sl], s.dirs[sl], s.sh_coeffs[sl],
+                            s.opacities[sl], s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.H, s.W,
+                            s.background, s.v_out, degrees_to_use=s.degrees_to_use)
+        wall = time.time() - t0
+        sec = (r["fwd_ms"] + r["bwd_ms"]) / 1e3
+        return dict(value=1.0 / sec, unit="rasterizations/s", cores=cores,
+                    threads_torch=R.num_threads(), kind="reference",
+                    sample="1 fwd+bwd of %d of %d Gaussians at %dx%d, SH deg %d, same scene/camera"
+                           "/cotangent; compositing loops are single-threaded by construction "
+                           "(gsplat_cpu.cpp:188,313), projection/SH use torch intra-op threads"
+                           % (n, s.N, s.W, s.H, s.degrees_to_use),
+                    fwd_ms=r["fwd_ms"], bwd_ms=r["bwd_ms"], wall_s=wall)
+    O = oracle.restated()
+    t0 = time.time()
+    p = O.project_forward(s.means[sl], s.scales[sl], s.quats[sl], s.viewmat, s.projmat, s.fx, s.fy,
+                          s.cx, s.cy, s.H, s.W)
+    rgb = np.maximum(O.sh_forward(s.degrees_to_use, s.dirs[sl], s.sh_coeffs[sl]) + 0.5, 0.0)
+    f = O.rasterize_forward(s.W, s.H, p["xys"], p["conics"], rgb, s.opacities[sl], s.background,
+                            p["cov2d"], p["cam_depths"], want_contributors=False)
+    g = O.rasterize_backward(s.W, s.H, p["xys"], p["conics"], rgb, s.opacities[sl], s.background,
+                             p["cov2d"], p["cam_depths"], f["final_Ts"], f["state"], s.v_out)
+    O.sh_backward(s.degrees_to_use, s.dirs[sl], s.sh_coeffs[sl], g["v_colors"])
+    O.project_backward(s.means[sl], s.scales[sl], s.quats[sl], s.viewmat, s.projmat, s.fx, s.fy,
+                       s.cx, s.cy, s.H, s.W, g["v_xy"], g["v_conic"])
+    sec = time.time() - t0
+    return dict(value=1.0 / sec, unit="rasterizations/s", cores=1, kind="port",
+                sample="1 fwd+bwd of %d of %d Gaussians at %dx%d (plain-C restatement, 1 thread)"
+                       % (n, s.N, s.W, s.H))
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    from opensplat_amd import cabi, dist, scenes
+
+    rank, world, local = dist.init_from_env("nccl")
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cabi.lib()  # fail loudly if the HIP library is missing
+
+    cfg = args.config
+    if cfg == "auto":
+        cfg = "c2" if world == 1 else "c4"
+    if cfg == "c2":
+        scene = scenes.camera_scene(args.gaussians, args.width, args.height, K=16, seed=1,
+                                    sigma_px=(0.5, 4.0), name="C2")
+        workload = "C2: %d Gaussians, %dx%d, SH degree 3 (K=16), 16x16 tiles, seed 1" % (
+            args.gaussians, args.width, args.height)
+    elif cfg == "c3":
+        scene = scenes.camera_scene(5 * args.gaussians, 2 * args.width, 2 * args.height, K=16, seed=2,
+                                    sigma_px=(1.0, 8.0), name="C3")
+        workload = "C3: %d Gaussians, %dx%d, SH degree 3" % (scene.N, scene.W, scene.H)
+    else:
+        scene = scenes.config_c4(rank, args.gaussians)
+        workload = ("C4: %d shared Gaussians, %d cameras at 1920x1080 (one per rank, yaw offsets), "
+                    "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians, world))
+
+    flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
+    pipe = Pipeline(scene, dev, flags)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    all_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev = []
+        pipe.step(ev)
+        all_events.append(ev)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage durations from HIP events recorded on the launch stream inside the timed region
+    stage_ms = {n: 0.0 for n in pipe.stage_names}
+    for ev in all_events:
+        for k, name in enumerate(pipe.stage_names):
+            stage_ms[name] += ev[k].elapsed_time(ev[k + 1])
+    stage_ms = {k: v / max(args.steps, 1) for k, v in stage_ms.items()}
+
+    if rank == 0:
+        N, K, M, P = scene.N, scene.K, pipe.num_isects, scene.W * scene.H
+        total_bytes, per_stage = algorithmic_bytes(N, K, M, P)
+        kernels = {k: v for k, v in stage_ms.items() if k in per_stage}
+        dom = max(kernels, key=kernels.get)
+        dom_ms = kernels[dom]
+        achieved = per_stage[dom] / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "forward+backward rasterizations/sec at 1M Gaussians 1080p",
+            "value": world * args.steps / elapsed,
+            "unit": "rasterizations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "gaussians": N, "width": scene.W, "height": scene.H,
+                       "sh_bases": K, "tile": 16, "intersections_M": M,
+                       "exp": "hardware v_exp_f32" if args.fast_exp else "glibc-bit-exact expf (parity mode)",
+                       "parallelism": "camera-per-rank dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": dom_ms, "algorithmic_bytes": per_stage[dom],
+                         "note": "compositing kernels are VALU/LDS/atomic-bound, not HBM-bound "
+                                 "(SURVEY.md §8d); the HBM fraction is reported as required"},
+            "path_roofline": {"algorithmic_bytes": total_bytes,
+                              "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
+                              "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stage_ms": stage_ms,
+            "grad_bytes_allreduced": pipe.grads.nbytes if world > 1 else 0,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(scene, args.cpu_gaussians)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,11 +90,12 @@ def make_camera(viewmat, projmat, fx, fy, cx, cy, W, H, clip=0.01, glob_scale=1.
     return cam
 
 
-def project_forward(cam: GsCamera, means, scales, quats, viewmat_dev=None, projmat_dev=None):
+def project_forward(cam: GsCamera, means, scales, quats, viewmat_dev=None, projmat_dev=None,
+                    out=None):
     N = means.shape[0]
     f = dict(device=means.device, dtype=torch.float32)
     i = dict(device=means.device, dtype=torch.int32)
-    out = dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
+    out = out or dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
                radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
                num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
                cov2d=torch.empty((N, 3), **f))
@@ -107,11 +108,12 @@ def project_forward(cam: GsCamera, means, scales, quats, viewmat_dev=None, projm
 
 
 def project_backward(cam: GsCamera, means, scales, quats, radii, v_xy, v_conic, v_depth=None,
-                     viewmat_dev=None, projmat_dev=None):
+                     viewmat_dev=None, projmat_dev=None, out=None):
     N = means.shape[0]
     f = dict(device=means.device, dtype=torch.float32)
-    out = dict(v_means=torch.empty((N, 3), **f), v_scales=torch.empty((N, 3), **f),
-               v_quats=torch.empty((N, 4), **f))
+    if out is None:
+        out = dict(v_means=torch.empty((N, 3), **f), v_scales=torch.empty((N, 3), **f),
+                   v_quats=torch.empty((N, 4), **f))
     _check(lib().gs_project_backward(C.byref(cam), _p(viewmat_dev), _p(projmat_dev), C.c_int(N),
                                      _p(means), _p(scales), _p(quats), _p(radii), _p(v_xy),
                                      _p(v_depth), _p(v_conic), _p(out["v_means"]),
@@ -120,17 +122,19 @@ def project_backward(cam: GsCamera, means, scales, quats, radii, v_xy, v_conic, 
     return out
 
 
-def sh_forward(degrees_to_use, dirs, coeffs):
+def sh_forward(degrees_to_use, dirs, coeffs, out=None):
     N, K = coeffs.shape[0], coeffs.shape[1]
-    colors = torch.empty((N, 3), device=coeffs.device, dtype=torch.float32)
+    colors = out if out is not None else torch.empty((N, 3), device=coeffs.device,
+                                                     dtype=torch.float32)
     _check(lib().gs_sh_forward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(dirs),
                                _p(coeffs), _p(colors), _stream()), "gs_sh_forward")
     return colors
 
 
-def sh_backward(degrees_to_use, K, dirs, v_colors):
+def sh_backward(degrees_to_use, K, dirs, v_colors, out=None):
     N = dirs.shape[0]
-    v_coeffs = torch.empty((N, K, 3), device=dirs.device, dtype=torch.float32)
+    v_coeffs = out if out is not None else torch.empty((N, K, 3), device=dirs.device,
+                                                       dtype=torch.float32)
     _check(lib().gs_sh_backward(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(dirs),
                                 _p(v_colors), _p(v_coeffs), _stream()), "gs_sh_backward")
     return v_coeffs
