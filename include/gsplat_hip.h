@@ -131,8 +131,10 @@ int gs_bin_scan(int N, const int32_t *tiles_hit, int32_t *cum_tiles_hit,
                 int32_t *num_isects_host /*host, nullable*/, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
-/* Emits one (tile | depth-bits, gaussian id) pair per intersection, radix-sorts them on
- * 32 + ceil(log2(tiles)) bits, and writes per-tile [start,end) ranges.
+/* Emits one (tile | depth-key, gaussian id) pair per intersection (depth-key = order-preserving
+ * uint32 image of the packed record's depth float, so any finite key sorts correctly), sorts on
+ * 32 + ceil(log2(tiles)) bits (stable: ties keep Gaussian-index order), and writes per-tile
+ * [start,end) ranges.
  *   out: isect_ids[M] (int64, unsorted) gaussian_ids[M] isect_ids_sorted[M]
  *        gaussian_ids_sorted[M] tile_bins[tiles,2]  — the five tensors binAndSortGaussians
  *        returns (rasterize_gaussians.hpp:11-20).  Any of the first three may be NULL, in which

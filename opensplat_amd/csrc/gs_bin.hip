@@ -75,8 +75,13 @@ k_emit_isects(int N, int tiles_x, const float4 *__restrict__ packed,
     int x0 = rx & 0xFFFF, x1 = rx >> 16, y0 = ry & 0xFFFF, y1 = ry >> 16;
     int tx0 = x0 / GS_TILE, tx1 = (x1 + GS_TILE - 1) / GS_TILE;
     int ty0 = y0 / GS_TILE, ty1 = (y1 + GS_TILE - 1) / GS_TILE;
-    // depth > clip > 0, so the IEEE bit pattern orders like the value (forward.cu:132)
-    uint64_t depth_bits = (uint64_t)__float_as_uint(p2.w);
+    // Order-preserving float -> uint map (flip all bits of negatives, set the sign bit of
+    // non-negatives).  The reference uses the raw bit pattern, valid only for depth > 0
+    // (forward.cu:132); the map sorts identically there and stays correct for ANY key, which
+    // lets tests drive the sort with the CPU reference's as-read keys.
+    uint32_t db = __float_as_uint(p2.w);
+    db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
+    uint64_t depth_bits = (uint64_t)db;
     int o = start;
     for (int ty = ty0; ty < ty1; ty++)
         for (int tx = tx0; tx < tx1; tx++) {

@@ -85,12 +85,13 @@ class Restated(_Base):
         vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
         xys, xp = _fo((N, 2)); radii, rp = _io((N,)); con, cp = _fo((N, 3))
         cov2d, c2p = _fo((N, 2, 2)); cd, cdp = _fo((N,)); dv, dvp = _fo((N,)); c3, c3p = _fo((N, 6))
+        kr, krp = _fo((N,))
         self.lib.orc_project_forward(C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp,
                                      C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                      C.c_int(H), C.c_int(W), C.c_float(clip), xp, rp, cp, c2p, cdp,
-                                     dvp, c3p)
+                                     dvp, c3p, krp)
         return dict(xys=xys, radii=radii, conics=con, cov2d=cov2d, cam_depths=cd, depths=dv,
-                    cov3d=c3)
+                    cov3d=c3, depth_keys_as_read=kr)
 
     def project_backward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
                          v_xys, v_conics, glob_scale=1.0, clip=0.01, v_depth=None):
@@ -184,12 +185,13 @@ class Reference(_Base):
         m, mp = _f(means); s, sp = _f(scales); q, qp = _f(quats)
         vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
         xys, xp = _fo((N, 2)); radii, rp = _io((N,)); con, cp = _fo((N, 3))
-        cov2d, c2p = _fo((N, 2, 2)); cd, cdp = _fo((N,))
+        cov2d, c2p = _fo((N, 2, 2)); cd, cdp = _fo((N,)); kr, krp = _fo((N,))
         self._chk(self.lib.ref_project_forward(
             C.c_int(N), mp, sp, C.c_float(glob_scale), qp, vmp, pmp, C.c_float(fx), C.c_float(fy),
             C.c_float(cx), C.c_float(cy), C.c_int(H), C.c_int(W), C.c_float(clip), xp, rp, cp, c2p,
-            cdp))
-        return dict(xys=xys, radii=radii, conics=con, cov2d=cov2d, cam_depths=cd)
+            cdp, krp))
+        return dict(xys=xys, radii=radii, conics=con, cov2d=cov2d, cam_depths=cd,
+                    depth_keys_as_read=kr)
 
     def project_backward(self, means, scales, quats, viewmat, projmat, fx, fy, cx, cy, H, W,
                          v_xys, v_conics, glob_scale=1.0, clip=0.01):

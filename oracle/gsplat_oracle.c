@@ -126,8 +126,14 @@ int orc_project_forward(int N, const float *means, const float *scales, float gl
                         const float *quats, const float *viewmat, const float *projmat, float fx,
                         float fy, float cx, float cy, int H, int W, float clip, float *xys,
                         int32_t *radii, float *conics, float *cov2d, float *cam_depths,
-                        float *depths_view, float *cov3d6) {
+                        float *depths_view, float *cov3d6, float *depth_keys_as_read) {
     (void)cx; (void)cy; (void)clip; /* the CPU path ignores them, :58-62,:71,:123-124 */
+    /* REFERENCE QUIRK (documented in DESIGN.md, P11): camDepths is the strided view
+     * pProj[..., 2] (:128) but the CPU rasterizer indexes its data_ptr() with unit stride
+     * (:152,:157-158), so the key it actually sorts Gaussian a by is element a+2 of the
+     * flattened [N,3] pProj array, not Gaussian a's depth.  depth_keys_as_read (nullable)
+     * returns those keys so tests can reproduce the reference's end-to-end chain exactly. */
+    float *pproj_flat = depth_keys_as_read ? (float *)malloc(sizeof(float) * 3 * (size_t)(N + 1)) : 0;
     for (int n = 0; n < N; n++) {
         ProjTmp t;
         project_one(means + 3 * n, scales + 3 * n, glob_scale, quats + 4 * n, viewmat, projmat, fx,
@@ -148,6 +154,11 @@ int orc_project_forward(int N, const float *means, const float *scales, float gl
         cov2d[4 * n + 2] = t.b10;
         cov2d[4 * n + 3] = t.c;
         cam_depths[n] = pz;
+        if (pproj_flat) {
+            pproj_flat[3 * n + 0] = px;
+            pproj_flat[3 * n + 1] = py;
+            pproj_flat[3 * n + 2] = pz;
+        }
         if (depths_view) depths_view[n] = t.p[2];
         if (cov3d6) {
             cov3d6[6 * n + 0] = t.cov3d[0];
@@ -157,6 +168,10 @@ int orc_project_forward(int N, const float *means, const float *scales, float gl
             cov3d6[6 * n + 4] = t.cov3d[5];
             cov3d6[6 * n + 5] = t.cov3d[8];
         }
+    }
+    if (pproj_flat) {
+        for (int n = 0; n < N; n++) depth_keys_as_read[n] = pproj_flat[n + 2];
+        free(pproj_flat);
     }
     return 0;
 }

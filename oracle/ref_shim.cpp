@@ -76,11 +76,13 @@ const char *ref_last_error() { return g_err.c_str(); }
 
 int ref_num_threads() { return torch::get_num_threads(); }
 
-// gsplat_cpu.cpp:48-131.  cov2d is written as N x 2 x 2, cam_depths as N (NDC z).
+// gsplat_cpu.cpp:48-131.  cov2d is written as N x 2 x 2, cam_depths as N (NDC z, contiguous copy);
+// depth_keys_as_read (nullable): see below.
 int ref_project_forward(int N, const float *means, const float *scales, float glob_scale,
                         const float *quats, const float *viewmat, const float *projmat, float fx,
                         float fy, float cx, float cy, int H, int W, float clip, float *xys,
-                        int32_t *radii, float *conics, float *cov2d, float *cam_depths) {
+                        int32_t *radii, float *conics, float *cov2d, float *cam_depths,
+                        float *depth_keys_as_read) {
     REF_TRY
     torch::Tensor m = f32(means, {N, 3}), s = f32(scales, {N, 3}), q = f32(quats, {N, 4});
     torch::Tensor vm = f32(viewmat, {4, 4}), pm = f32(projmat, {4, 4});
@@ -91,6 +93,14 @@ int ref_project_forward(int N, const float *means, const float *scales, float gl
     put(std::get<2>(t), conics);
     put(std::get<3>(t), cov2d);
     put(std::get<4>(t), cam_depths);
+    if (depth_keys_as_read) {
+        // What rasterize_forward_tensor_cpu really sorts by: it takes camDepths.data_ptr()
+        // (gsplat_cpu.cpp:152) of the NON-contiguous view pProj[..., 2] (:128) and indexes it with
+        // unit stride (:157-158).  Reproduce that read verbatim (in bounds: a + 2 < 3N).
+        const torch::Tensor &cd = std::get<4>(t);
+        const float *p = static_cast<const float *>(cd.data_ptr());
+        for (int a = 0; a < N; a++) depth_keys_as_read[a] = p[a];
+    }
     REF_CATCH
 }
 
