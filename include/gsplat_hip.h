@@ -167,6 +167,10 @@ int gs_rasterize_backward(int W, int H, const int32_t *gaussian_ids_sorted,
                           const float *v_out_alpha /*nullable*/, float *v_xy, float *v_conic,
                           float *v_colors, float *v_opacity, uint32_t flags, gs_stream_t stream);
 
+/* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact
+ * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */
+int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags, gs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ GS_FLAG_FAST_EXP = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
-    "gs_bin_sort", "gs_rasterize_forward", "gs_rasterize_backward",
+    "gs_bin_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_debug_expf",
 ]
 
 
@@ -236,3 +236,10 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
                                        _p(out["v_conic"]), _p(out["v_colors"]), _p(out["v_opacity"]),
                                        C.c_uint32(flags), _stream()), "gs_rasterize_backward")
     return out
+
+
+def debug_expf(x, flags=0):
+    y = torch.empty_like(x)
+    _check(lib().gs_debug_expf(C.c_int64(x.numel()), _p(x), _p(y), C.c_uint32(flags), _stream()),
+           "gs_debug_expf")
+    return y

@@ -291,7 +291,35 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     }
 }
 
+// Test hook: the exponential exactly as the compositing kernels evaluate it.
+template <bool EXACT>
+__global__ void __launch_bounds__(256) k_debug_expf(int64_t n, const float *__restrict__ x,
+                                                    float *__restrict__ y) {
+    __shared__ uint64_t exp_tab[32];
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = gs_exp<EXACT>(x[i], exp_tab);
+}
+
 }  // namespace gs
+
+extern "C" int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags,
+                             gs_stream_t stream) {
+    if (n < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (n == 0) return GS_OK;
+    if (!x || !y) return GS_ERR_INVALID_ARGUMENT;
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (flags & GS_FLAG_FAST_EXP)
+        hipLaunchKernelGGL(gs::k_debug_expf<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           n, x, y);
+    else
+        hipLaunchKernelGGL(gs::k_debug_expf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           n, x, y);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
 
 extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                                     const int32_t *tile_bins, const float *packed,

@@ -1,0 +1,89 @@
+"""CPU: libgsplat_hip.so loads and exports every function include/gsplat_hip.h declares
+(no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from opensplat_amd import _build, cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "gsplat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_build.HIP_LIB), "run python -m opensplat_amd._build"
+    assert os.path.dirname(_build.HIP_LIB).startswith(ROOT)
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert len(names) >= 13
+    l = ctypes.CDLL(_build.HIP_LIB)
+    missing = [n for n in names if not hasattr(l, n)]
+    assert not missing, missing
+    assert sorted(cabi.SYMBOLS) == names, "cabi.SYMBOLS out of sync with the header"
+
+
+def test_status_strings_and_version():
+    l = cabi.lib()
+    assert l.gs_version() >= 100
+    assert l.gs_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4):
+        assert len(l.gs_strerror(code)) > 3
+    assert l.gs_strerror(-99) == b"unknown status"
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    l = cabi.lib()
+    cam = cabi.GsCamera()
+    cam.img_width, cam.img_height = 70000, 16
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
+    # negative N
+    assert l.gs_sh_forward(-1, 16, 3, null, null, null, null) == -1
+    # K not a valid number of SH bases / degree too high for K
+    assert l.gs_sh_forward(10, 5, 0, one, one, one, null) == -1
+    assert l.gs_sh_forward(10, 4, 2, one, one, one, null) == -1
+    # unaligned coefficient pointer
+    assert l.gs_sh_forward(10, 4, 1, one, ctypes.c_void_p(20), one, null) == -1
+    # null pointers
+    assert l.gs_project_forward(ctypes.byref(cam), null, null, 5, null, null, null, null, null,
+                                null, null, null, null, null, null) == -1
+    # image side > 65535 -> unsupported
+    assert l.gs_project_forward(ctypes.byref(cam), null, null, 5, one, one, one, one, one, one,
+                                one, one, one, one, null) == -2
+    assert l.gs_pack_splats(70000, 16, 5, one, one, one, one, one, one, null, one, one, null) == -2
+    # N == 0 is a no-op success
+    assert l.gs_sh_forward(0, 16, 3, null, null, null, null) == 0
+    assert l.gs_project_forward(ctypes.byref(cam), null, null, 0, null, null, null, null, null,
+                                null, null, null, null, null, null) == 0
+
+
+def test_torch_operator_library_registers():
+    import torch
+
+    from opensplat_amd import ops  # noqa: F401
+
+    for name in ["project_gaussians", "rasterize_gaussians", "spherical_harmonics", "set_fast_exp"]:
+        assert hasattr(torch.ops.opensplat_amd, name)
+
+
+def test_operators_refuse_cpu_tensors():
+    """No CPU fallback: the operators raise on host tensors (reference: CHECK_INPUT, bindings.h:14-19)."""
+    import pytest
+    import torch
+
+    from opensplat_amd import ops
+
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.spherical_harmonics(0, torch.zeros(4, 3), torch.zeros(4, 1, 3))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.project_gaussians(torch.zeros(4, 3), torch.ones(4, 3), 1.0, torch.ones(4, 4),
+                              torch.eye(4), torch.eye(4), 10.0, 10.0, 8.0, 8.0, 16, 16)
