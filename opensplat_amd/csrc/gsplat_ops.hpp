@@ -54,13 +54,14 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, int64_t> binAndSortGauss
 
 class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
 public:
-    // cov2d: the 7th output of ProjectGaussians; when undefined the pixel rectangle is derived
+    // cov2d: the 7th output of ProjectGaussians; when absent the pixel rectangle is derived
     // from the conics (call sites written against the reference's 10-argument signature).
     static torch::Tensor forward(torch::autograd::AutogradContext *ctx, torch::Tensor xys,
                                  torch::Tensor depths, torch::Tensor radii, torch::Tensor conics,
                                  torch::Tensor numTilesHit, torch::Tensor colors,
                                  torch::Tensor opacity, int64_t imgHeight, int64_t imgWidth,
-                                 torch::Tensor background, torch::Tensor cov2d = torch::Tensor());
+                                 torch::Tensor background,
+                                 c10::optional<torch::Tensor> cov2d = c10::nullopt);
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
                                                  torch::autograd::tensor_list grad_outputs);
 };

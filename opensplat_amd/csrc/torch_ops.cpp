@@ -210,7 +210,8 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
 Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor depths, Tensor radii,
                                    Tensor conics, Tensor numTilesHit, Tensor colors,
                                    Tensor opacity, int64_t imgHeight, int64_t imgWidth,
-                                   Tensor background, Tensor cov2d) {
+                                   Tensor background, c10::optional<Tensor> cov2dOpt) {
+    Tensor cov2d = (cov2dOpt.has_value() && cov2dOpt->defined()) ? *cov2dOpt : Tensor();
     (void)numTilesHit;  // recounted from the pixel rectangle inside binAndSortGaussians
     GS_CHECK_DEV(xys); GS_CHECK_DEV(depths); GS_CHECK_DEV(radii); GS_CHECK_DEV(conics);
     GS_CHECK_DEV(colors); GS_CHECK_DEV(opacity);
@@ -339,8 +340,7 @@ Tensor op_rasterize_gaussians(const Tensor &xys, const Tensor &depths, const Ten
                               const Tensor &opacity, int64_t imgHeight, int64_t imgWidth,
                               const Tensor &background, const c10::optional<Tensor> &cov2d) {
     return RasterizeGaussians::apply(xys, depths, radii, conics, numTilesHit, colors, opacity,
-                                     imgHeight, imgWidth, background,
-                                     cov2d.has_value() ? *cov2d : Tensor());
+                                     imgHeight, imgWidth, background, cov2d);
 }
 
 Tensor op_spherical_harmonics(int64_t degreesToUse, const Tensor &viewDirs, const Tensor &coeffs) {

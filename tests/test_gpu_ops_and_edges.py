@@ -243,8 +243,10 @@ def test_device_resident_matrices_equal_host_camera():
     s = scenes.camera_scene(2000, 96, 64, K=4, seed=23, yaw_deg=5.0, znear=1.0, zfar=100.0)
     a = hip_pipeline(s, device_matrices=False)
     b = hip_pipeline(s, device_matrices=True)
-    for k in ["xys", "conics", "img", "v_means", "v_quats"]:
+    for k in ["xys", "conics", "cov2d", "depths", "img", "final_Ts"]:
         assert np.array_equal(np_(a[k]), np_(b[k])), k
+    for k in ["v_means", "v_quats", "v_scales"]:  # atomics order differs run to run
+        assert rel_err(np_(a[k]), np_(b[k])) < 1e-5, k
 
 
 def test_binning_invariants():
