@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs that scripts/profile.sh leaves under gpurun_out/prof_<tag>/ into the
+small, tracked summaries under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats table (gs::* + sort kernels)
+  profiles/<tag>_pmc.json           per-kernel, per-launch means of every PMC counter collected
+  profiles/<tag>_summary.md         the table DESIGN.md / bench.py's roofline object refer to
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM [CDNA4]": FETCH_SIZE and
+WRITE_SIZE come from separate --pmc passes; rocprofv3 reports them in KiB; on gfx950 FETCH_SIZE
+tallies 128-B requests at 64 B for wide coalesced reads, so it is doubled ("corrected");
+WRITE_SIZE is reported as is (uncalibrated per the guide).
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def short(name: str) -> str:
+    name = name.strip('"')
+    m = re.search(r"gs::(k_\w+)(<[^>(]*>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    if "radix_sort_onesweep" in name:
+        if "onesweep_histograms" in name or "histogram" in name:
+            return "rocprim::radix_onesweep_histograms"
+        return "rocprim::radix_onesweep_" + str(abs(hash(name)) % 1000)
+    m = re.search(r"rocprim::\w+::detail::(\w+)", name)
+    if m:
+        return "rocprim::" + m.group(1)
+    return name[:60]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = ROOT / "gpurun_out" / f"prof_{tag}"
+    dst = ROOT / "profiles"
+    dst.mkdir(exist_ok=True)
+
+    # 1. kernel stats
+    stats = []
+    with open(src / "trace" / "trace_kernel_stats.csv") as f:
+        for row in csv.DictReader(f):
+            stats.append(row)
+    with open(dst / f"{tag}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in stats:
+            w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+    # 2. PMC passes
+    pmc = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [values]
+    for sub in ("fetch", "write", "sq", "sq2", "sq3", "tcc"):
+        p = src / sub / f"{sub}_counter_collection.csv"
+        if not p.exists():
+            continue
+        with open(p) as f:
+            for row in csv.DictReader(f):
+                pmc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, ctrs in pmc.items():
+        if "gs::" not in k and "rocprim" not in k:
+            continue
+        d = {c: sum(v) / len(v) for c, v in ctrs.items()}
+        d["launches_sampled"] = max(len(v) for v in ctrs.values())
+        if "FETCH_SIZE" in d:
+            d["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 1024 * 2
+        if "WRITE_SIZE" in d:
+            d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
+        out[k[:200]] = d
+    with open(dst / f"{tag}_pmc.json", "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+    # 3. markdown
+    avg = {r["Name"]: float(r["AverageNs"]) for r in stats}
+    calls = {r["Name"]: int(r["Calls"]) for r in stats}
+    lines = [f"# rocprofv3 summary, tag {tag}", "",
+             "Source: `scripts/profile.sh` on one MI355X (gpurun), summarised by "
+             "`scripts/summarize_profile.py`.", "",
+             "| kernel | calls | avg µs | % | HBM read MB (FETCH_SIZE×2) | HBM write MB | VALU insts/wave-avg | "
+             "VALU busy (ACTIVE_INST_VALU/BUSY_CYCLES) | LDS insts | wait_any/wave_cycles |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    pct = {r["Name"]: r["Percentage"] for r in stats}
+    for name in sorted(avg, key=lambda n: -avg[n] * calls[n]):
+        if "gs::" not in name and "rocprim" not in name:
+            continue
+        d = out.get(name[:200], {})
+        rd = d.get("hbm_read_bytes_corrected")
+        wr = d.get("hbm_write_bytes")
+        valu = d.get("SQ_INSTS_VALU")
+        busy = None
+        if d.get("SQ_BUSY_CYCLES"):
+            busy = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_BUSY_CYCLES"]
+        wait = None
+        if d.get("SQ_WAVE_CYCLES"):
+            wait = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
+        fmt = lambda v, s="%.1f": "–" if v is None else s % v
+        lines.append("| `%s` | %d | %.1f | %s | %s | %s | %s | %s | %s | %s |" % (
+            short(name), calls[name], avg[name] / 1e3, pct[name],
+            fmt(None if rd is None else rd / 1e6), fmt(None if wr is None else wr / 1e6),
+            fmt(valu, "%.3g"), fmt(busy, "%.3f"), fmt(d.get("SQ_INSTS_LDS"), "%.3g"),
+            fmt(wait, "%.3f")))
+    (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
