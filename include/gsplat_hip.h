@@ -114,7 +114,7 @@ int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const fl
  * (gsplat_cpu.cpp:167-168,201-204), and writes tiles_hit[N] = tiles overlapped by it.
  * cov2d may be NULL: the rectangle is then derived from the conic's inverse (legacy call sites
  * that only have the reference's six projection outputs).  radii <= 0 -> empty rectangle.   */
-int gs_pack_splats(int W, int H, int N, const float *xys, const float *depths,
+int gs_pack_splats(int W, int H, int N, const float *xys, const float *depths /*unused*/,
                    const int32_t *radii, const float *conics, const float *colors,
                    const float *opacities, const float *cov2d /*nullable*/, float *packed,
                    int32_t *tiles_hit, gs_stream_t stream);
@@ -141,7 +141,7 @@ int gs_bin_scan(int N, const int32_t *tiles_hit, int32_t *cum_tiles_hit,
  *        case workspace memory is used for them.
  * num_isects must equal cum_tiles_hit[N-1]. */
 int gs_bin_sort(int W, int H, int N, int32_t num_isects, const float *packed,
-                const int32_t *cum_tiles_hit, int64_t *isect_ids, int32_t *gaussian_ids,
+                const float *depths, const int32_t *cum_tiles_hit, int64_t *isect_ids, int32_t *gaussian_ids,
                 int64_t *isect_ids_sorted, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                 void *workspace, size_t workspace_bytes, gs_stream_t stream);
 
@@ -170,6 +170,10 @@ int gs_rasterize_backward(int W, int H, const int32_t *gaussian_ids_sorted,
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact
  * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */
 int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags, gs_stream_t stream);
+
+/* Test hook: the nine-value transposing wave reduction of the backward kernel.
+ *   in [blocks, 9, 64] (value i of lane l at in[b][i][l])  ->  out[blocks, 9] = sums over lanes. */
+int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_debug_expf",
+    "gs_debug_reduce9",
 ]
 
 
@@ -203,7 +204,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         keys_sorted = w.get("keys_sorted", (M,), torch.int64, dev)
     else:
         keys = ids = keys_sorted = None
-    _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(M), _p(packed), _p(cum),
+    _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(M), _p(packed), _p(depths), _p(cum),
                          _p(keys), _p(ids), _p(keys_sorted), _p(ids_sorted), _p(tile_bins), _p(ws),
                          C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
     return Binned(packed, tiles_hit, cum, M, keys, ids, keys_sorted, ids_sorted, tile_bins)
@@ -242,4 +243,12 @@ def debug_expf(x, flags=0):
     y = torch.empty_like(x)
     _check(lib().gs_debug_expf(C.c_int64(x.numel()), _p(x), _p(y), C.c_uint32(flags), _stream()),
            "gs_debug_expf")
+    return y
+
+
+def debug_reduce9(x):
+    """x [blocks, 9, 64] -> [blocks, 9]: the backward kernel's transposing wave reduction."""
+    blocks = x.shape[0]
+    y = torch.empty((blocks, 9), device=x.device, dtype=torch.float32)
+    _check(lib().gs_debug_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_reduce9")
     return y

@@ -3,42 +3,65 @@
 // Replaces rasterize_forward / rasterize_backward_kernel (reference
 // rasterizer/gsplat/forward.cu:256-378, backward.cu:161-355).  Per-pixel recurrence, thresholds
 // and clamp constants are the CPU oracle's (rasterizer/gsplat-cpu/gsplat_cpu.cpp:188-240 forward,
-// :313-373 backward), evaluated in the same operation order without FMA contraction and with a
-// glibc-bit-exact expf, so that contributor sets, final_Ts and the image equal gsplat-cpu's
-// bit for bit on identical inputs; the backward differs only in the order in which per-pixel
-// terms are summed into a Gaussian's gradient.
+// :313-373 backward).  The forward evaluates them in the same operation order without FMA
+// contraction and with a glibc-bit-exact expf, so that contributor sets, final_Ts and the image
+// equal gsplat-cpu's bit for bit on identical inputs.  The backward makes the same
+// contributor decisions (same alpha >= 1/255 outcome as the forward, exactly) but is free to
+// re-associate the gradient arithmetic (fp32 atomics make the sum order undefined anyway).
 //
-// CDNA4 mapping (this is not the reference's 16x16-threads-per-tile CUDA layout):
+// Both kernels are VALU-bound (rocprofv3: SQ_ACTIVE_INST_VALU ~ 85 % of busy cycles, LDS and HBM
+// far from their limits), so the design minimises wave-instructions per (tile, Gaussian) entry:
 //   * one 64-lane wavefront == one workgroup == one 16x16 tile; every lane owns FOUR pixels
-//     (column lane&15, rows (lane>>4) + 4k, k = 0..3).  The per-Gaussian record is read from LDS
-//     once per wave (broadcast ds_read_b128) and amortised over 4 pixels per lane, which keeps
-//     the LDS pipe far below the VALU pipe; 4 independent pixel chains per lane give the ILP
-//     that a 2-cycle-issue SIMD-32 needs.
-//   * no workgroup barriers between waves at all: the tile's sorted list is staged 64 entries
-//     at a time by the wave itself, and early termination is a 64-bit ballot.
-//   * the pixel-in-rectangle test of the CPU oracle costs 2 VALU ops: each staged entry carries
-//     a 16+16-bit column/row mask local to the tile, each pixel a constant 2-bit probe.
-//   * a 4-row strip that the rectangle does not touch is skipped with a scalar branch, and the
-//     fp64 exponential is only issued when some lane of the strip can pass alpha >= 1/255
-//     (sigma <= ln(255*opacity) + 1e-3, precomputed per entry).
-//   * backward: per-entry partial gradients are summed over the lane's 4 pixels in registers,
-//     then over the wave with DPP row reductions + v_readlane, and ONE lane issues the 9
-//     global_atomic_add_f32 per (tile, Gaussian) — 4-8x fewer atomics than the reference's
-//     per-32-lane-warp scheme.
+//     (column lane&15, rows (lane>>4) + 4k, k = 0..3), handled as TWO packed pairs so that the
+//     sigma quadratic form and the gradient body run on v_pk_{mul,add,fma}_f32 (2 pixels per
+//     instruction).  The per-Gaussian record is read from LDS once per wave (broadcast
+//     ds_read_b128) and amortised over 4 pixels per lane.
+//   * no workgroup barriers between waves: the tile's sorted list is staged 64 entries at a time
+//     by the wave itself (next chunk's gather prefetched into registers while the current chunk
+//     is consumed), early termination is a 64-bit ballot.
+//   * per-pixel "is this Gaussian relevant" is two float compares, 0 <= sigma <= sigma_max, with
+//     sigma_max = ln(255*opacity) precomputed per Gaussian: the CPU oracle's pixel-rectangle test
+//     is implied by it whenever the rectangle encloses the sigma_max ellipse box (flag bit set by
+//     gs_pack_splats); only for the rare Gaussians whose rectangle cuts the ellipse is the
+//     rectangle applied explicitly (scalar-branched slow path).  Finished / out-of-image pixels
+//     carry a NaN row coordinate in the forward, so they fail the same two compares for free.
+//   * an 8-row half of the tile that the (tightened) rectangle does not touch is skipped with a
+//     scalar branch; the fp64 exponential is only issued when some lane of the pair passes.
+//   * backward: the exponential is v_exp_f32, with the exact fp64 evaluation re-run only for
+//     lanes whose alpha lies within 2.5e-6 (relative) of the 1/255 threshold, so the decision
+//     equals the forward's; 1/(1-alpha) is v_rcp_f32 + one Newton step; the running colour
+//     buffer is tracked as its dot product with the pixel's cotangent (one register per pixel
+//     instead of three); sigma moments are accumulated per pixel and converted to the nine
+//     gradient components once per entry and lane.
+//   * the nine partial gradients x 64 lanes are reduced with a transposing network:
+//     v_permlane32_swap / v_permlane16_swap fold value PAIRS across the wave's halves / rows
+//     (2 instructions merge two registers into one), DPP row_mirror / half_mirror / quad_perm
+//     finish inside 8-lane groups, after which nine different lanes hold the nine totals and ONE
+//     global_atomic_add_f32 instruction (nine active lanes, per-lane addresses) scatters them —
+//     ~30 VALU + 1 VMEM per contributing (tile, Gaussian) instead of 9 x (11 VALU + 1 VMEM).
 //
-// Roofline: neither kernel is HBM-bound.  Work is ~256 pixel x Gaussian evaluations per sorted
-// tile entry (VALU + LDS broadcast); HBM traffic is one 48-byte gather per entry plus 20 B per
-// pixel.  DESIGN.md states the algorithmic bytes used for roofline.achieved.
+// Roofline: HBM traffic is one 48-byte gather per entry plus 20 B per pixel; DESIGN.md states the
+// algorithmic bytes used for roofline.achieved and the VALU accounting.
 #include "gs_device.h"
 
 namespace gs {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
 constexpr int kChunk = 64;  // entries staged per pass == wave width
 
 // LDS image of one staged entry (48 B, three ds_read_b128):
-//   a = {x, y, conic A, conic B}   b = {conic C, opacity, sigma_max, mask bits}   c = {r, g, b, id}
+//   a = {x, y, conic A, conic B}   b = {conic C, opacity, sigma_max|flag, mask bits}
+//   c = {r, g, b, id}
 struct __attribute__((aligned(16))) Staged {
     float4 a, b, c;
+};
+
+// One sorted-list entry as gathered from HBM (13 VGPRs): prefetched one chunk ahead.
+struct Rec {
+    float4 p0, p1, p2;
+    int g;
 };
 
 __device__ __forceinline__ uint32_t tile_mask(uint32_t rx, uint32_t ry, int tile_x0, int tile_y0) {
@@ -51,23 +74,22 @@ __device__ __forceinline__ uint32_t tile_mask(uint32_t rx, uint32_t ry, int tile
     return (cm && rm) ? (cm | (rm << 16)) : 0u;
 }
 
-// Load entry `idx` of the sorted list and convert it to its staged form for tile (tx, ty).
-__device__ __forceinline__ void stage_entry(Staged *dst, int idx, const int32_t *__restrict__ ids,
-                                            const float4 *__restrict__ packed, int tile_x0,
-                                            int tile_y0) {
-    int g = ids[idx];
-    float4 p0 = packed[3 * (size_t)g + 0];
-    float4 p1 = packed[3 * (size_t)g + 1];
-    float4 p2 = packed[3 * (size_t)g + 2];
-    float opac = p1.y;
-    // alpha = opac * exp(-sigma) >= 1/255 needs sigma <= ln(255 * opac); the margin makes the
-    // skip strictly conservative w.r.t. rounding of the log, the exp and the product.
-    float smax = (opac > 0.0f) ? (__logf(255.0f * opac) + 1.0e-3f) : -1.0f;
-    uint32_t m = tile_mask(__float_as_uint(p2.y), __float_as_uint(p2.z), tile_x0, tile_y0);
-    dst->a = p0;
-    dst->b = make_float4(p1.x, opac, smax, __uint_as_float(m));
-    dst->c = make_float4(p1.z, p1.w, p2.x, __int_as_float(g));
+__device__ __forceinline__ void fetch_entry(Rec &r, int idx, const int32_t *__restrict__ ids,
+                                            const float4 *__restrict__ packed) {
+    r.g = ids[idx];
+    r.p0 = packed[3 * (size_t)r.g + 0];
+    r.p1 = packed[3 * (size_t)r.g + 1];
+    r.p2 = packed[3 * (size_t)r.g + 2];
 }
+
+__device__ __forceinline__ void stage_entry(Staged *dst, const Rec &r, int tile_x0, int tile_y0) {
+    uint32_t m = tile_mask(__float_as_uint(r.p1.w), __float_as_uint(r.p2.w), tile_x0, tile_y0);
+    dst->a = r.p0;
+    dst->b = make_float4(r.p1.x, r.p1.y, r.p1.z, __uint_as_float(m));
+    dst->c = make_float4(r.p2.x, r.p2.y, r.p2.z, __int_as_float(r.g));
+}
+
+__device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
@@ -86,60 +108,84 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     const int lx = lane & 15, ly = lane >> 4;
     const int px = tile_x0 + lx;
     const float pxf = (float)px;
-    float pyf[4], T[4], acc[4][3];
+    // py2[h] = row coordinates of pixels k = 2h, 2h+1; NaN once the pixel is finished (or outside
+    // the image): a NaN row makes sigma NaN, which fails "0 <= sigma <= sigma_max".
+    f2 py2[2];
+    float T[4], acc[4][3];
     int last[4];
-    bool done[4];
-    uint32_t probe[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int py = tile_y0 + ly + 4 * k;
-        pyf[k] = (float)py;
+        const int py = tile_y0 + ly + 4 * k;
+        const float v = (px < W && py < H) ? (float)py : qnan();
+        if (k & 1) py2[k >> 1].y = v; else py2[k >> 1].x = v;
         T[k] = 1.0f;
         acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
         last[k] = -1;
-        done[k] = !(px < W && py < H);
-        probe[k] = (1u << lx) | (1u << (16 + ly + 4 * k));
     }
+    const uint32_t colbit = 1u << lx;
 
     const int2 range = bins[tile];
+    Rec nxt;
+    if (range.x + lane < range.y) fetch_entry(nxt, range.x + lane, ids, packed);
     for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
-        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        const bool alive = (py2[0].x == py2[0].x) || (py2[0].y == py2[0].y) ||
+                           (py2[1].x == py2[1].x) || (py2[1].y == py2[1].y);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
-        if (c0 + lane < range.y) stage_entry(&stage[lane], c0 + lane, ids, packed, tile_x0, tile_y0);
+        if (c0 + lane < range.y) stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
         __syncthreads();
+        if (c0 + kChunk + lane < range.y) fetch_entry(nxt, c0 + kChunk + lane, ids, packed);
         const int n = min(kChunk, range.y - c0);
         for (int t = 0; t < n; t++) {
             const float4 ea = stage[t].a;
             const float4 eb = stage[t].b;
             const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
-            if (mask == 0u) continue;
-            const float dx = ea.x - pxf;
-            const float Adx = ea.z * dx;       // A * xCam
-            const float Bdx = ea.w * dx;       // B * xCam
-            const float Adxdx = Adx * dx;      // A * xCam * xCam
+            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.z));
+            const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
+            float dx = ea.x - pxf;
+            if (rect_binds && (mask & colbit) == 0u) dx = qnan();  // column outside the rectangle
+            const float Adx = ea.z * dx;    // A * xCam
+            const float Bdx = ea.w * dx;    // B * xCam
+            const float Adxdx = Adx * dx;   // A * xCam * xCam
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (((mask >> (16 + 4 * k)) & 0xFu) == 0u) continue;  // scalar: strip untouched
-                const float dy = ea.y - pyf[k];
-                // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217
-                const float sigma = 0.5f * (Adxdx + eb.x * dy * dy) + Bdx * dy;
-                const bool need = !done[k] && ((mask & probe[k]) == probe[k]) && (sigma >= 0.0f) &&
-                                  (sigma <= eb.z);
-                if (__ballot(need) == 0ull) continue;
-                if (need) {
-                    const float alpha = fminf(0.999f, eb.y * gs_exp<EXACT>(-sigma, exp_tab));
-                    if (alpha >= (1.0f / 255.0f)) {
-                        const float nextT = T[k] * (1.0f - alpha);
-                        if (nextT <= 1e-4f) {
-                            done[k] = true;  // this pixel is done; the Gaussian is not rendered
-                        } else {
-                            const float4 ec = stage[t].c;
-                            const float vis = alpha * T[k];
-                            acc[k][0] += vis * ec.x;
-                            acc[k][1] += vis * ec.y;
-                            acc[k][2] += vis * ec.z;
-                            T[k] = nextT;
-                            last[k] = c0 + t;
+            for (int h = 0; h < 2; h++) {
+                if (((mask >> (16 + 8 * h)) & 0xFFu) == 0u) continue;  // scalar: half untouched
+                f2 py = py2[h];
+                if (rect_binds) {  // rows outside the rectangle
+                    if ((mask & (1u << (16 + ly + 8 * h))) == 0u) py.x = qnan();
+                    if ((mask & (1u << (16 + ly + 8 * h + 4))) == 0u) py.y = qnan();
+                }
+                const f2 dy = ea.y - py;
+                // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217 (same op order)
+                f2 sg = (eb.x * dy) * dy;
+                sg = Adxdx + sg;
+                sg = 0.5f * sg;
+                sg = sg + Bdx * dy;
+                const bool need0 = (sg.x >= 0.0f) && (sg.x <= eb.z);
+                const bool need1 = (sg.y >= 0.0f) && (sg.y <= eb.z);
+                if (__builtin_amdgcn_ballot_w64(need0 || need1) == 0ull) continue;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int k = 2 * h + j;
+                    const bool need = j ? need1 : need0;
+                    const float sigma = j ? sg.y : sg.x;
+                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+                    if (need) {
+                        const float alpha = fminf(0.999f, eb.y * gs_exp<EXACT>(-sigma, exp_tab));
+                        if (alpha >= (1.0f / 255.0f)) {
+                            const float nextT = T[k] * (1.0f - alpha);
+                            if (nextT <= 1e-4f) {
+                                // pixel done; the Gaussian is not rendered (gsplat_cpu.cpp:225-228)
+                                if (j) py2[h].y = qnan(); else py2[h].x = qnan();
+                            } else {
+                                const float4 ec = stage[t].c;
+                                const float vis = alpha * T[k];
+                                acc[k][0] += vis * ec.x;
+                                acc[k][1] += vis * ec.y;
+                                acc[k][2] += vis * ec.z;
+                                T[k] = nextT;
+                                last[k] = c0 + t;
+                            }
                         }
                     }
                 }
@@ -158,6 +204,62 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             final_idx[pix] = last[k];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposing wave reduction of nine per-lane values.  On return the totals sit in nine lanes:
+//   lane 0: v0   lane 32: v1   lane 16: v2   lane 48: v3   lane 8: v4   lane 40: v5
+//   lane 24: v6  lane 56: v7   lane 1: v8
+// (kReduceLane[i] below; checked on the device by tests via gs_debug_reduce9).
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    // a.hi <-> b.lo, then add: lanes 0-31 get a.lo+a.hi, lanes 32-63 get b.lo+b.hi
+    u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    // odd rows of a <-> even rows of b, then add: rows 0,2 get a's row pairs, rows 1,3 get b's
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4,
+                                         float v5, float v6, float v7, float v8, int lane) {
+    const float p01 = swap_add32(v0, v1), p23 = swap_add32(v2, v3);
+    const float p45 = swap_add32(v4, v5), p67 = swap_add32(v6, v7);
+    const float p8 = swap_add32(v8, v8);
+    const float qa = swap_add16(p01, p23);  // rows: v0, v2, v1, v3
+    const float qb = swap_add16(p45, p67);  // rows: v4, v6, v5, v7
+    float q8 = swap_add16(p8, p8);          // every row: 16 partials of v8
+    const float ra = qa + dpp_f<0x140>(qa);  // row_mirror: lanes 0-7 hold 8 partials
+    const float rb = qb + dpp_f<0x140>(qb);
+    q8 = q8 + dpp_f<0x140>(q8);
+    float r = (lane & 8) ? rb : ra;
+    r += dpp_f<0x141>(r);   // row_half_mirror
+    q8 += dpp_f<0x141>(q8);
+    r += dpp_f<0x4E>(r);    // quad_perm [2,3,0,1]
+    q8 += dpp_f<0x4E>(q8);
+    r += dpp_f<0xB1>(r);    // quad_perm [1,0,3,2]
+    q8 += dpp_f<0xB1>(q8);
+    return (lane == 1) ? q8 : r;
+}
+
+// role of a lane after reduce9: index of the value it holds, -1 if none.  Lanes 0,8,...,56 hold
+// value bitreverse3(lane >> 3) (the two swap stages deal values out by halves, then by rows).
+__device__ __forceinline__ int reduce9_role(int lane) {
+    if (lane == 1) return 8;
+    if (lane & 7) return -1;
+    return (int)((0x73516240u >> (4 * (lane >> 3))) & 0xFu);
+}
+
+__global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ in,
+                                                      float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const float *p = in + (size_t)blockIdx.x * 9 * 64;
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = p[i * 64 + lane];
+    const float r = reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lane);
+    const int role = reduce9_role(lane);
+    if (role >= 0) out[(size_t)blockIdx.x * 9 + role] = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -180,112 +282,157 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     const int lx = lane & 15, ly = lane >> 4;
     const int px = tile_x0 + lx;
     const float pxf = (float)px;
-    float pyf[4], T[4], Tfin[4], buf[4][3], vo[4][3], voa[4];
+    // per pixel pair h (pixels k = 2h, 2h+1): row coordinate, transmittance being unwound,
+    // T_final * (v_out_alpha - bg . v_out), running <colour buffer, v_out>, cotangent
+    f2 py2[2], T2[2], TW2[2], bv2[2], vo2[2][3];
     int last[4];
-    uint32_t probe[4];
     int my_last = -1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
-        pyf[k] = (float)py;
-        probe[k] = (1u << lx) | (1u << (16 + ly + 4 * k));
-        buf[k][0] = buf[k][1] = buf[k][2] = 0.0f;
+        float Tfin = 1.0f, o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, oa = 0.0f;
+        int l = -1;
         if (px < W && py < H) {
             const size_t pix = (size_t)py * W + px;
-            Tfin[k] = final_Ts[pix];
-            last[k] = final_idx[pix];
-            vo[k][0] = v_out[3 * pix + 0];
-            vo[k][1] = v_out[3 * pix + 1];
-            vo[k][2] = v_out[3 * pix + 2];
-            voa[k] = v_out_alpha ? v_out_alpha[pix] : 0.0f;
-        } else {
-            Tfin[k] = 1.0f;
-            last[k] = -1;
-            vo[k][0] = vo[k][1] = vo[k][2] = 0.0f;
-            voa[k] = 0.0f;
+            Tfin = final_Ts[pix];
+            l = final_idx[pix];
+            o0 = v_out[3 * pix + 0];
+            o1 = v_out[3 * pix + 1];
+            o2 = v_out[3 * pix + 2];
+            oa = v_out_alpha ? v_out_alpha[pix] : 0.0f;
         }
-        T[k] = Tfin[k];
-        my_last = max(my_last, last[k]);
+        const float tw = Tfin * (oa - (bg0 * o0 + bg1 * o1 + bg2 * o2));
+        const int h = k >> 1;
+        if (k & 1) {
+            py2[h].y = (float)py; T2[h].y = Tfin; TW2[h].y = tw;
+            vo2[h][0].y = o0; vo2[h][1].y = o1; vo2[h][2].y = o2;
+        } else {
+            py2[h].x = (float)py; T2[h].x = Tfin; TW2[h].x = tw;
+            vo2[h][0].x = o0; vo2[h][1].x = o1; vo2[h][2].x = o2;
+        }
+        last[k] = l;
+        my_last = max(my_last, l);
     }
+    bv2[0] = (f2)(0.0f);
+    bv2[1] = (f2)(0.0f);
+
+    // lanes that hold a reduced total scatter it: per-lane base pointer and element stride
+    const int role = reduce9_role(lane);
+    float *wbase = (role < 2) ? v_xy + role : (role < 5) ? v_conic + (role - 2)
+                   : (role < 8) ? v_colors + (role - 5) : v_opacity;
+    const int wstride = (role < 2) ? 2 : (role < 8) ? 3 : 1;
+    const uint32_t colbit = 1u << lx;
+
     const int2 range = bins[tile];
     const int wave_last = wave_max_i(my_last);  // last list entry any pixel of the tile used
     if (wave_last < range.x) return;            // (also covers empty tiles / no contributors)
 
     // walk the list back to front in chunks; slot 0 of a chunk is its furthest-back entry
+    Rec nxt;
+    if (wave_last - lane >= range.x) fetch_entry(nxt, wave_last - lane, ids, packed);
     for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
         __syncthreads();
-        if (hi - lane >= range.x) stage_entry(&stage[lane], hi - lane, ids, packed, tile_x0, tile_y0);
+        if (hi - lane >= range.x) stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
         __syncthreads();
+        if (hi - kChunk - lane >= range.x) fetch_entry(nxt, hi - kChunk - lane, ids, packed);
         const int n = min(kChunk, hi - range.x + 1);
         for (int t = 0; t < n; t++) {
             const float4 ea = stage[t].a;
             const float4 eb = stage[t].b;
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
-            if (mask == 0u) continue;
-            const int e = hi - t;  // index of this entry in the sorted list
             const float4 ec = stage[t].c;
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
+            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.z));
+            const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
+            const int e = hi - t;  // index of this entry in the sorted list
             const float dx = ea.x - pxf;
             const float Adx = ea.z * dx, Bdx = ea.w * dx, Adxdx = Adx * dx;
-            float g_x = 0.f, g_y = 0.f, g_A = 0.f, g_B = 0.f, g_C = 0.f;
-            float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
-            bool any = false;
+            const bool col_ok = !rect_binds || (mask & colbit) != 0u;
+            f2 s0 = (f2)(0.0f), s1 = (f2)(0.0f), s2 = (f2)(0.0f);
+            f2 gr = (f2)(0.0f), gg = (f2)(0.0f), gb = (f2)(0.0f);
+            bool any = false;  // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (((mask >> (16 + 4 * k)) & 0xFu) == 0u) continue;
-                const float dy = ea.y - pyf[k];
-                const float sigma = 0.5f * (Adxdx + eb.x * dy * dy) + Bdx * dy;
-                const bool need = (e <= last[k]) && ((mask & probe[k]) == probe[k]) &&
-                                  (sigma >= 0.0f) && (sigma <= eb.z);
-                if (__ballot(need) == 0ull) continue;
-                if (need) {
-                    // gsplat_cpu.cpp:337-370
-                    const float vis = gs_exp<EXACT>(-sigma, exp_tab);
-                    const float alpha = fminf(0.99f, eb.y * vis);
-                    if (alpha >= (1.0f / 255.0f)) {
-                        const float ra = 1.0f / (1.0f - alpha);
-                        T[k] *= ra;
-                        const float fac = alpha * T[k];
-                        g_r += fac * vo[k][0];
-                        g_g += fac * vo[k][1];
-                        g_b += fac * vo[k][2];
-                        const float Tr = Tfin[k] * ra;
-                        const float v_alpha =
-                            ((ec.x * T[k] - buf[k][0] * ra) * vo[k][0]) +
-                            ((ec.y * T[k] - buf[k][1] * ra) * vo[k][1]) +
-                            ((ec.z * T[k] - buf[k][2] * ra) * vo[k][2]) + (Tr * voa[k]) +
-                            (-Tfin[k] * ra * bg0 * vo[k][0]) + (-Tfin[k] * ra * bg1 * vo[k][1]) +
-                            (-Tfin[k] * ra * bg2 * vo[k][2]);
-                        buf[k][0] += ec.x * fac;
-                        buf[k][1] += ec.y * fac;
-                        buf[k][2] += ec.z * fac;
-                        const float v_sigma = -eb.y * vis * v_alpha;
-                        g_A += 0.5f * v_sigma * dx * dx;
-                        g_B += 0.5f * v_sigma * dx * dy;
-                        g_C += 0.5f * v_sigma * dy * dy;
-                        g_x += v_sigma * (Adx + ea.w * dy);
-                        g_y += v_sigma * (Bdx + eb.x * dy);
-                        g_o += vis * v_alpha;
-                        any = true;
+            for (int h = 0; h < 2; h++) {
+                if (((mask >> (16 + 8 * h)) & 0xFFu) == 0u) continue;  // scalar: half untouched
+                const f2 dy = ea.y - py2[h];
+                f2 sg = (eb.x * dy) * dy;
+                sg = Adxdx + sg;
+                sg = 0.5f * sg;
+                sg = sg + Bdx * dy;
+                bool need0 = (e <= last[2 * h]) && (sg.x >= 0.0f) && (sg.x <= eb.z) && col_ok;
+                bool need1 = (e <= last[2 * h + 1]) && (sg.y >= 0.0f) && (sg.y <= eb.z) && col_ok;
+                if (rect_binds) {
+                    need0 = need0 && (mask & (1u << (16 + ly + 8 * h))) != 0u;
+                    need1 = need1 && (mask & (1u << (16 + ly + 8 * h + 4))) != 0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(need0 || need1) == 0ull) continue;
+                any = true;
+                // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338;
+                // lanes that do not take part end up with vis = alpha = 0
+                f2 vis;
+                vis.x = need0 ? __expf(-sg.x) : 0.0f;
+                vis.y = need1 ? __expf(-sg.y) : 0.0f;
+                f2 alpha = eb.y * vis;
+                if (EXACT) {
+                    // same >= 1/255 decision as the forward: redo the exponential exactly where
+                    // the fast one cannot decide (|rel. distance to the threshold| < 2.5e-6)
+                    const float thr = 1.0f / 255.0f;
+                    const bool amb0 = need0 && fabsf(alpha.x - thr) < 1.0e-8f;
+                    const bool amb1 = need1 && fabsf(alpha.y - thr) < 1.0e-8f;
+                    if (__builtin_amdgcn_ballot_w64(amb0 || amb1) != 0ull) {
+                        if (amb0) { vis.x = expf_glibc(-sg.x, exp_tab); alpha.x = eb.y * vis.x; }
+                        if (amb1) { vis.y = expf_glibc(-sg.y, exp_tab); alpha.y = eb.y * vis.y; }
                     }
                 }
+                const bool ok0 = alpha.x >= (1.0f / 255.0f);
+                const bool ok1 = alpha.y >= (1.0f / 255.0f);
+                alpha.x = ok0 ? fminf(0.99f, alpha.x) : 0.0f;
+                alpha.y = ok1 ? fminf(0.99f, alpha.y) : 0.0f;
+                vis.x = ok0 ? vis.x : 0.0f;
+                vis.y = ok1 ? vis.y : 0.0f;
+                // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
+                const f2 om = 1.0f - alpha;
+                f2 ra;
+                ra.x = __builtin_amdgcn_rcpf(om.x);
+                ra.y = __builtin_amdgcn_rcpf(om.y);
+                const f2 er = __builtin_elementwise_fma(-om, ra, (f2)(1.0f));
+                ra = __builtin_elementwise_fma(ra, er, ra);
+                T2[h] = T2[h] * ra;               // transmittance in front of this Gaussian
+                const f2 fac = alpha * T2[h];
+                gr = __builtin_elementwise_fma(fac, vo2[h][0], gr);
+                gg = __builtin_elementwise_fma(fac, vo2[h][1], gg);
+                gb = __builtin_elementwise_fma(fac, vo2[h][2], gb);
+                // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
+                f2 cv = ec.x * vo2[h][0];
+                cv = __builtin_elementwise_fma((f2)(ec.y), vo2[h][1], cv);
+                cv = __builtin_elementwise_fma((f2)(ec.z), vo2[h][2], cv);
+                const f2 v_alpha = __builtin_elementwise_fma(T2[h], cv, ra * (TW2[h] - bv2[h]));
+                bv2[h] = __builtin_elementwise_fma(fac, cv, bv2[h]);
+                // u = vis * v_alpha; v_sigma = -opacity * u (applied once per entry below)
+                const f2 u = vis * v_alpha;
+                s0 = s0 + u;
+                const f2 ud = u * dy;
+                s1 = s1 + ud;
+                s2 = __builtin_elementwise_fma(ud, dy, s2);
             }
-            if (__ballot(any) == 0ull) continue;
-            // wave-wide sums (uniform results), then one lane scatters 9 atomics
-            const float s_x = wave_sum(g_x), s_y = wave_sum(g_y);
-            const float s_A = wave_sum(g_A), s_B = wave_sum(g_B), s_C = wave_sum(g_C);
-            const float s_r = wave_sum(g_r), s_g = wave_sum(g_g), s_b = wave_sum(g_b);
-            const float s_o = wave_sum(g_o);
-            if (lane == 0) {
+            if (!any) continue;
+            // per-lane conversion of the moments to the nine gradient components
+            const float S0 = s0.x + s0.y, S1 = s1.x + s1.y, S2 = s2.x + s2.y;
+            const float mo = -eb.y;
+            const float vs0 = mo * S0;         // sum v_sigma
+            const float vs1 = mo * S1;         // sum v_sigma * dy
+            const float vs2 = mo * S2;         // sum v_sigma * dy^2
+            const float mx = dx * vs0;         // sum v_sigma * dx
+            const float g_x = fmaf(ea.z, mx, ea.w * vs1);  // v_sigma * (A dx + B dy)
+            const float g_y = fmaf(ea.w, mx, eb.x * vs1);  // v_sigma * (B dx + C dy)
+            const float hdx = 0.5f * dx;
+            const float g_A = hdx * mx;        // 0.5 * v_sigma * dx^2
+            const float g_B = hdx * vs1;       // 0.5 * v_sigma * dx * dy   (gsplat_cpu.cpp:361-363)
+            const float g_C = 0.5f * vs2;      // 0.5 * v_sigma * dy^2
+            const float r = reduce9(g_x, g_y, g_A, g_B, g_C, gr.x + gr.y, gg.x + gg.y,
+                                    gb.x + gb.y, S0, lane);
+            if (role >= 0) {
                 const int g = __float_as_int(ec.w);
-                atomicAdd(&v_xy[2 * (size_t)g + 0], s_x);
-                atomicAdd(&v_xy[2 * (size_t)g + 1], s_y);
-                atomicAdd(&v_conic[3 * (size_t)g + 0], s_A);
-                atomicAdd(&v_conic[3 * (size_t)g + 1], s_B);
-                atomicAdd(&v_conic[3 * (size_t)g + 2], s_C);
-                atomicAdd(&v_colors[3 * (size_t)g + 0], s_r);
-                atomicAdd(&v_colors[3 * (size_t)g + 1], s_g);
-                atomicAdd(&v_colors[3 * (size_t)g + 2], s_b);
-                atomicAdd(&v_opacity[g], s_o);
+                atomicAdd(wbase + (size_t)g * wstride, r);
             }
         }
     }
@@ -317,6 +464,15 @@ extern "C" int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags
     else
         hipLaunchKernelGGL(gs::k_debug_expf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            n, x, y);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream) {
+    if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (blocks == 0) return GS_OK;
+    if (!in || !out) return GS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gs::k_debug_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

@@ -199,7 +199,7 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
     Tensor tileBins = torch::empty({tiles, 2}, i32);
     size_t wsBytes = gs_bin_workspace_bytes((int)N, M, W, H);
     Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
-    check_status(gs_bin_sort(W, H, (int)N, (int32_t)M, fptr(packed), cum.data_ptr<int32_t>(),
+    check_status(gs_bin_sort(W, H, (int)N, (int32_t)M, fptr(packed), fptr(depths), cum.data_ptr<int32_t>(),
                              nullptr, nullptr, nullptr, idsSorted.data_ptr<int32_t>(),
                              tileBins.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
                  "gs_bin_sort");
