@@ -81,7 +81,9 @@ class Pipeline:
         self.ws = cabi.BinWorkspace()
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i))
-        # 2-D gradients accumulated with atomics: one flat buffer, one memset per step
+        # 2-D gradients (fully written by gs_rasterize_backward) + its record workspace
+        self.bwd_ws = torch.empty((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
+                                  device=dev, dtype=torch.uint8)
         self.g2d = torch.zeros(N * 9, **f)
         self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
                            v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.g2d[8 * N:])
@@ -109,14 +111,13 @@ class Pipeline:
         colors = torch.clamp_min(rgb + 0.5, 0.0)  # model.cpp:192
         mark()
         b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
-                              self.opac, p["cov2d"], self.ws, keep_unsorted=False)
+                              self.opac, p["cov2d"], self.ws)
         self.num_isects = b.num_isects
         mark()
         f = cabi.rasterize_forward(s.W, s.H, b, s.background, self.flags, out=self.fwd)
         mark()
-        self.g2d.zero_()
         g = cabi.rasterize_backward(s.W, s.H, s.N, b, s.background, f["final_Ts"], f["final_idx"],
-                                    self.v_out, self.flags, out=self.rgrads)
+                                    self.v_out, self.flags, out=self.rgrads, workspace=self.bwd_ws)
         mark()
         v_rgb = g["v_colors"] * (rgb > -0.5)  # backward of clamp_min(rgb + 0.5, 0)
         cabi.sh_backward(s.degrees_to_use, s.K, self.dirs, v_rgb, out=self.grads.v_sh)

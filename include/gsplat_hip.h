@@ -41,7 +41,8 @@ typedef enum GsStatus {
     GS_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, K not in {1,4,9,16,25} ... */
     GS_ERR_UNSUPPORTED = -2,      /* image wider/taller than 65535 px */
     GS_ERR_WORKSPACE = -3,        /* workspace too small for (N, max_isects) */
-    GS_ERR_HIP = -4               /* a HIP runtime call failed; see gs_last_hip_error() */
+    GS_ERR_HIP = -4,              /* a HIP runtime call failed; see gs_last_hip_error() */
+    GS_ERR_CAPACITY = -5          /* more intersections than the caller's id buffer holds */
 } GsStatus;
 
 /* Camera + image description: the scalar arguments of ProjectGaussians::apply
@@ -109,41 +110,57 @@ int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const fl
  * rasterize_gaussians.cpp:6-37,62-63).
  *
  * gs_pack_splats: gathers the 2-D attributes of each Gaussian into one 48-byte record
- *   { x, y, conic A, B | C, opacity, r, g | b, (x0 | x1<<16), (y0 | y1<<16), depth }
- * where [x0,x1) x [y0,y1) is the CPU oracle's pixel rectangle clipped to the image
- * (gsplat_cpu.cpp:167-168,201-204), and writes tiles_hit[N] = tiles overlapped by it.
- * cov2d may be NULL: the rectangle is then derived from the conic's inverse (legacy call sites
- * that only have the reference's six projection outputs).  radii <= 0 -> empty rectangle.   */
-int gs_pack_splats(int W, int H, int N, const float *xys, const float *depths /*unused*/,
-                   const int32_t *radii, const float *conics, const float *colors,
-                   const float *opacities, const float *cov2d /*nullable*/, float *packed,
-                   int32_t *tiles_hit, gs_stream_t stream);
+ *   { x, y, conic A, B | C, opacity, sigma_max, (x0 | x1<<16) | r, g, b, (y0 | y1<<16) }
+ * sigma_max = ln(255*opacity) + margin is the largest exponent at which the Gaussian can still
+ * reach alpha >= 1/255 (gsplat_cpu.cpp:220-222); its lowest mantissa bit flags "the rectangle
+ * must be tested per pixel".  [x0,x1) x [y0,y1) is the CPU oracle's pixel rectangle clipped to
+ * the image (gsplat_cpu.cpp:167-168,201-204) intersected with the bounding box of the
+ * sigma <= sigma_max ellipse — pixels outside that box fail the alpha threshold in the reference
+ * as well, so contributor sets are unchanged while fewer tiles are touched.
+ * tiles_hit[N] = 16x16 tiles overlapped by the stored rectangle.
+ * cov2d may be NULL: the CPU rectangle is then derived from the conic's inverse (legacy call
+ * sites that only have the reference's six projection outputs).  radii <= 0 or
+ * opacity < 1/255 -> empty rectangle, zero tiles.                                            */
+int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
+                   const float *conics, const float *colors, const float *opacities,
+                   const float *cov2d /*nullable*/, float *packed, int32_t *tiles_hit,
+                   gs_stream_t stream);
 
-/* Workspace (bytes) needed by gs_bin_scan + gs_bin_sort for N Gaussians, num_isects
- * intersections and a W x H image. */
+/* Workspace (bytes, 256-byte aligned base) sufficient for gs_bin_scan (any num_isects) and for
+ * gs_bin_sort with capacity num_isects, for a W x H image.  Nothing in the workspace has to
+ * survive between the two calls. */
 size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
 
-/* Inclusive scan of tiles_hit -> cum_tiles_hit[N]; the total is also copied (async, on `stream`)
- * to *num_isects_host, which must be pinned host memory or NULL.  The caller synchronises the
- * stream before reading it (the reference syncs at the same place,
- * rasterize_gaussians.cpp:63). */
-int gs_bin_scan(int N, const int32_t *tiles_hit, int32_t *cum_tiles_hit,
+/* Counts the intersections of every 16x16 tile (rectangles of the packed records) and scans the
+ * counts:  tile_bins[tiles,2] = [start, end) of each tile's segment in the sorted id list.
+ * The total M is also copied (async, on `stream`) to *num_isects_host, which must be pinned host
+ * memory or NULL; the caller synchronises the stream before reading it (the reference syncs at
+ * the same place, rasterize_gaussians.cpp:63) — or does not read it at all and passes a
+ * sufficient capacity to gs_bin_sort. */
+int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
                 int32_t *num_isects_host /*host, nullable*/, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
-/* Emits one (tile | depth-key, gaussian id) pair per intersection (depth-key = order-preserving
- * uint32 image of the packed record's depth float, so any finite key sorts correctly), sorts on
- * 32 + ceil(log2(tiles)) bits (stable: ties keep Gaussian-index order), and writes per-tile
- * [start,end) ranges.
- *   out: isect_ids[M] (int64, unsorted) gaussian_ids[M] isect_ids_sorted[M]
- *        gaussian_ids_sorted[M] tile_bins[tiles,2]  — the five tensors binAndSortGaussians
- *        returns (rasterize_gaussians.hpp:11-20).  Any of the first three may be NULL, in which
- *        case workspace memory is used for them.
- * num_isects must equal cum_tiles_hit[N-1]. */
-int gs_bin_sort(int W, int H, int N, int32_t num_isects, const float *packed,
-                const float *depths, const int32_t *cum_tiles_hit, int64_t *isect_ids, int32_t *gaussian_ids,
-                int64_t *isect_ids_sorted, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                void *workspace, size_t workspace_bytes, gs_stream_t stream);
+/* Fills every tile's segment of gaussian_ids_sorted[capacity] with the ids of the Gaussians
+ * overlapping the tile, ordered by `depths` (any finite float key sorts correctly; ties in
+ * Gaussian-index order) — the result of the reference's global (tile | depth) sort + gather,
+ * built with a counting scatter and one on-chip sort per tile.  capacity must be >= M (the
+ * total of gs_bin_scan); slots beyond capacity are never written. */
+int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                const int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
+                size_t workspace_bytes, gs_stream_t stream);
+
+/* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
+ * rasterize_gaussians.cpp:6-37 together with its caller's cumsum/.item(), :62-63): for callers
+ * that keep a gaussian_ids_sorted buffer of `capacity` entries and a workspace of
+ * gs_bin_workspace_bytes(N, capacity, W, H) bytes across calls.  *num_isects_host (pinned host
+ * memory, required) receives M; returns GS_ERR_CAPACITY without sorting if M > capacity — grow
+ * the buffers to *num_isects_host and call again.  Blocks the calling thread once (where the
+ * reference blocks). */
+int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
+                    const float *depths, int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                    int32_t *num_isects_host /*host*/, void *workspace, size_t workspace_bytes,
+                    gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Compositing.  Replace rasterize_forward_tensor / rasterize_backward_tensor
@@ -151,21 +168,27 @@ int gs_bin_sort(int W, int H, int N, int32_t num_isects, const float *packed,
  * thresholds as the CPU oracle gsplat_cpu.cpp:188-240 (fwd) and :313-373 (bwd).
  *   fwd out: out_img[H,W,3] final_Ts[H,W] final_idx[H,W] (index into gaussian_ids_sorted of the
  *            last Gaussian composited into the pixel, -1 if none)
- *   bwd out: v_xy[N,2] v_conic[N,3] v_colors[N,3] v_opacity[N] — ACCUMULATED with atomics: the
- *            caller zero-fills them first (the reference allocates them with torch::zeros,
- *            bindings.cu:591-598).  v_out_alpha may be NULL (OpenSplat always passes zeros,
+ *   bwd out: v_xy[N,2] v_conic[N,3] v_colors[N,3] v_opacity[N] — fully written (no pre-zeroing
+ *            needed; the reference allocates them with torch::zeros, bindings.cu:591-598, and
+ *            accumulates into them).  Partial gradients are accumulated with fp32 atomics into
+ *            64-byte per-Gaussian records in `workspace` (gs_rasterize_backward_workspace_bytes(N)
+ *            bytes, 64-byte aligned) and split into the four tensors at the end.
+ *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background is a host float[3].               */
 int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          const int32_t *tile_bins, const float *packed,
                          const float *background /*host[3]*/, float *out_img, float *final_Ts,
                          int32_t *final_idx, uint32_t flags, gs_stream_t stream);
 
-int gs_rasterize_backward(int W, int H, const int32_t *gaussian_ids_sorted,
+size_t gs_rasterize_backward_workspace_bytes(int N);
+
+int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
                           const int32_t *tile_bins, const float *packed,
                           const float *background /*host[3]*/, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out,
                           const float *v_out_alpha /*nullable*/, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, uint32_t flags, gs_stream_t stream);
+                          float *v_colors, float *v_opacity, void *workspace,
+                          size_t workspace_bytes, uint32_t flags, gs_stream_t stream);
 
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact
  * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */

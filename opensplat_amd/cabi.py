@@ -23,7 +23,7 @@ GS_FLAG_FAST_EXP = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
-    "gs_bin_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_debug_expf",
+    "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
     "gs_debug_reduce9",
 ]
 
@@ -42,14 +42,17 @@ def lib() -> C.CDLL:
     """Load libgsplat_hip.so (after torch, so both share torch's HIP runtime)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_build.HIP_LIB):
+        path = os.environ.get("GSPLAT_HIP_LIB", _build.HIP_LIB)  # e.g. an instrumented build
+        if not os.path.exists(path):
             raise ImportError("libgsplat_hip.so is not built: run `python -m opensplat_amd._build` "
                               "(no CPU fallback exists)")
-        l = C.CDLL(_build.HIP_LIB)
+        l = C.CDLL(path)
         l.gs_strerror.restype = C.c_char_p
         l.gs_last_hip_error.restype = C.c_char_p
         l.gs_bin_workspace_bytes.restype = C.c_size_t
         l.gs_bin_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
+        l.gs_rasterize_backward_workspace_bytes.restype = C.c_size_t
+        l.gs_rasterize_backward_workspace_bytes.argtypes = [C.c_int]
         _lib = l
     return _lib
 
@@ -145,12 +148,8 @@ def sh_backward(degrees_to_use, K, dirs, v_colors, out=None):
 class Binned:
     packed: torch.Tensor          # [N, 12] f32
     tiles_hit: torch.Tensor       # [N] i32
-    cum_tiles_hit: torch.Tensor   # [N] i32
     num_isects: int
-    isect_ids: torch.Tensor       # [M] i64 (unsorted keys)
-    gaussian_ids: torch.Tensor    # [M] i32 (unsorted)
-    isect_ids_sorted: torch.Tensor
-    gaussian_ids_sorted: torch.Tensor
+    gaussian_ids_sorted: torch.Tensor   # [M] i32, per-tile depth-ordered lists
     tile_bins: torch.Tensor       # [tiles, 2] i32
 
 
@@ -159,6 +158,7 @@ class BinWorkspace:
 
     def __init__(self):
         self.ws = None
+        self.capacity = 0   # entries the id buffer / sort workspace currently hold
         self.m_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
         self.bufs = {}
 
@@ -173,41 +173,42 @@ class BinWorkspace:
         return t[:n].view(*shape)
 
 
+GS_ERR_CAPACITY = -5
+
+
 def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
-                 workspace: BinWorkspace | None = None, keep_unsorted=True) -> Binned:
-    """pack -> scan -> (one sync to read M) -> emit + sort + tile ranges."""
+                 workspace: BinWorkspace | None = None) -> Binned:
+    """pack -> gs_bin_and_sort (count + scan, one sync to read M, scatter + per-tile sort).
+
+    The id buffer and the workspace live in `workspace` and only grow: the first call (and any
+    call whose M exceeds the capacity) pays one retry."""
     l = lib()
     N = xys.shape[0]
     dev = xys.device
     w = workspace or BinWorkspace()
     packed = w.get("packed", (N, GS_SPLAT_DWORDS), torch.float32, dev)
     tiles_hit = w.get("tiles_hit", (N,), torch.int32, dev)
-    cum = w.get("cum", (N,), torch.int32, dev)
-    _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(depths), _p(radii),
-                            _p(conics), _p(colors), _p(opacities), _p(cov2d), _p(packed),
-                            _p(tiles_hit), _stream()), "gs_pack_splats")
-    scan_bytes = l.gs_bin_workspace_bytes(N, 0, W, H)
-    scan_ws = w.get("ws", (scan_bytes,), torch.uint8, dev)
-    m_host = w.m_host if w.m_host is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
-    _check(l.gs_bin_scan(C.c_int(N), _p(tiles_hit), _p(cum), C.c_void_p(m_host.data_ptr()),
-                         _p(scan_ws), C.c_size_t(scan_bytes), _stream()), "gs_bin_scan")
-    torch.cuda.current_stream().synchronize()
-    M = int(m_host[0]) if N > 0 else 0
     tiles = ((W + GS_TILE - 1) // GS_TILE) * ((H + GS_TILE - 1) // GS_TILE)
-    ws_bytes = l.gs_bin_workspace_bytes(N, M, W, H)
-    ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
-    ids_sorted = w.get("ids_sorted", (M,), torch.int32, dev)
     tile_bins = w.get("tile_bins", (tiles, 2), torch.int32, dev)
-    if keep_unsorted:
-        keys = w.get("keys", (M,), torch.int64, dev)
-        ids = w.get("ids", (M,), torch.int32, dev)
-        keys_sorted = w.get("keys_sorted", (M,), torch.int64, dev)
-    else:
-        keys = ids = keys_sorted = None
-    _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(M), _p(packed), _p(depths), _p(cum),
-                         _p(keys), _p(ids), _p(keys_sorted), _p(ids_sorted), _p(tile_bins), _p(ws),
-                         C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
-    return Binned(packed, tiles_hit, cum, M, keys, ids, keys_sorted, ids_sorted, tile_bins)
+    _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
+                            _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
+                            _stream()), "gs_pack_splats")
+    m_host = w.m_host if w.m_host is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+    while True:
+        cap = max(w.capacity, 1024)
+        ws_bytes = l.gs_bin_workspace_bytes(N, cap, W, H)
+        ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
+        ids = w.get("ids_sorted", (cap,), torch.int32, dev)
+        rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
+                               _p(depths), _p(tile_bins), _p(ids), C.c_void_p(m_host.data_ptr()),
+                               _p(ws), C.c_size_t(ws_bytes), _stream())
+        M = int(m_host[0])
+        if rc == GS_ERR_CAPACITY:
+            w.capacity = M + M // 8 + 1024
+            continue
+        _check(rc, "gs_bin_and_sort")
+        break
+    return Binned(packed, tiles_hit, M, ids[:M], tile_bins)
 
 
 def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
@@ -225,17 +226,22 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
 
 
 def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx, v_out, flags=0,
-                       v_out_alpha=None, out=None):
+                       v_out_alpha=None, out=None, workspace=None):
     dev = binned.packed.device
     if out is None:
-        out = dict(v_xy=torch.zeros((N, 2), device=dev), v_conic=torch.zeros((N, 3), device=dev),
-                   v_colors=torch.zeros((N, 3), device=dev), v_opacity=torch.zeros((N,), device=dev))
+        out = dict(v_xy=torch.empty((N, 2), device=dev), v_conic=torch.empty((N, 3), device=dev),
+                   v_colors=torch.empty((N, 3), device=dev), v_opacity=torch.empty((N,), device=dev))
+    ws_bytes = lib().gs_rasterize_backward_workspace_bytes(N)
+    if workspace is None or workspace.numel() < ws_bytes:
+        workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
     bg = (C.c_float * 3)(*[float(b) for b in background])
-    _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
-                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(final_Ts),
-                                       _p(final_idx), _p(v_out), _p(v_out_alpha), _p(out["v_xy"]),
-                                       _p(out["v_conic"]), _p(out["v_colors"]), _p(out["v_opacity"]),
-                                       C.c_uint32(flags), _stream()), "gs_rasterize_backward")
+    _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N),
+                                       _p(binned.gaussian_ids_sorted), _p(binned.tile_bins),
+                                       _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
+                                       _p(v_out_alpha), _p(out["v_xy"]), _p(out["v_conic"]),
+                                       _p(out["v_colors"]), _p(out["v_opacity"]), _p(workspace),
+                                       C.c_size_t(workspace.numel()), C.c_uint32(flags), _stream()),
+           "gs_rasterize_backward")
     return out
 
 

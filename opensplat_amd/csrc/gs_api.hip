@@ -17,6 +17,7 @@ extern "C" const char *gs_strerror(int status) {
     case GS_ERR_UNSUPPORTED: return "unsupported configuration (image side > 65535 px)";
     case GS_ERR_WORKSPACE: return "workspace too small";
     case GS_ERR_HIP: return "HIP runtime error (see gs_last_hip_error)";
+    case GS_ERR_CAPACITY: return "more tile intersections than the id buffer's capacity";
     default: return "unknown status";
     }
 }

@@ -1,24 +1,33 @@
-// gs_bin.hip — per-Gaussian 2-D record packing, tile counting, intersection emission, radix sort
-// and per-tile range extraction.
+// gs_bin.hip — per-Gaussian 2-D record packing, tile counting, intersection scatter and per-tile
+// depth sort.
 //
 // Replaces, on the reference side: torch::cumsum + .item() (rasterize_gaussians.cpp:62-63),
 // map_gaussian_to_intersects (forward.cu:107-143), torch::sort + torch::gather
 // (rasterize_gaussians.cpp:25-32) and get_tile_bin_edges (forward.cu:148-169).
 //
-// Differences that are deliberate:
-//   * which tiles a Gaussian lands in is decided by the CPU oracle's pixel rectangle
-//     (gsplat_cpu.cpp:167-168,201-204), not by the GPU reference's radius square — that is what
-//     makes the contributor sets equal to gsplat-cpu's;
-//   * the sort key uses only the bits that vary: 32 depth bits + ceil(log2(tiles)) tile bits, and
-//     the sort moves 4-byte Gaussian ids, not 8-byte argsort indices followed by a gather;
-//   * tile_bins is [tiles, 2] (the reference allocates [M, 2], bindings.cu:324-326).
+// The reference builds the per-tile depth-ordered lists with ONE global sort of M
+// (tile<<32 | depth) int64 keys plus int64 argsort indices (8 radix passes over 16-byte pairs and
+// a gather).  On MI355X a counting partition followed by many small on-chip sorts is far cheaper:
+//   1. k_count_tiles   — one lane per Gaussian adds 1 to the counter of every tile its rectangle
+//                        overlaps (fire-and-forget L2 atomics);
+//   2. k_scan_tiles    — one workgroup scans the (<= ~130 k) tile counters: tile_bins[t] =
+//                        [start, end), scatter cursors, total M;
+//   3. k_scatter       — one lane per Gaussian claims a slot in each of its tiles' segments
+//                        (returning atomics on the cursors) and writes the 64-bit key
+//                        (order-preserving depth bits << 32 | Gaussian id);
+//   4. k_sort_tiles    — one workgroup per tile sorts its segment by that key in LDS (bitonic
+//                        network on 64-bit keys) and writes the Gaussian ids; segments too long
+//                        for 64 KiB of LDS are sorted in place in global memory by the same
+//                        network.
+// The key is unique per (depth, id), so the result does not depend on the order in which step 3's
+// atomics land: lists are depth ordered with ties in Gaussian-index order —
+// deterministic, and identical to a stable sort by depth.  Traffic: 8 B written + read per
+// intersection plus 4 B of ids, against >= 128 B per intersection for the reference's scheme.
 //
-// All kernels are HBM/atomic-free streaming passes; the sort itself is rocPRIM's device radix
-// sort (a HIP-native header library compiled here for gfx950).
+// Which tiles a Gaussian lands in is decided by the CPU oracle's pixel rectangle tightened by the
+// alpha-threshold ellipse box (k_pack_splats), not by the GPU reference's radius square;
+// tile_bins is [tiles, 2] (the reference allocates [M, 2], bindings.cu:324-326).
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "gs_device.h"
 
@@ -92,90 +101,329 @@ k_pack_splats(int W, int H, int N, const float *__restrict__ xys,
     tiles_hit[n] = tiles;
 }
 
-// ---- emit ------------------------------------------------------------------------------------
-// One lane per Gaussian writes its (tile | depth) keys and ids at cum[n-1] .. cum[n].
-// TODO(perf): a lane-per-intersection mapping (binary search in cum) would coalesce the writes.
-__global__ void __launch_bounds__(256)
-k_emit_isects(int N, int tiles_x, const float4 *__restrict__ packed,
-              const float *__restrict__ depths, const int32_t *__restrict__ cum,
-              int64_t *__restrict__ keys, int32_t *__restrict__ ids) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    int start = (n == 0) ? 0 : cum[n - 1];
-    int end = cum[n];
-    if (end <= start) return;
-    uint32_t rx = __float_as_uint(packed[3 * n + 1].w), ry = __float_as_uint(packed[3 * n + 2].w);
+// ---- tile rectangle of a packed record --------------------------------------------------------
+struct TileRect {
+    int tx0, tx1, ty0, ty1;
+    __device__ __forceinline__ int count() const { return (tx1 - tx0) * (ty1 - ty0); }
+};
+__device__ __forceinline__ TileRect tile_rect(const float4 *__restrict__ packed, int n) {
+    uint32_t rx = __float_as_uint(packed[3 * (size_t)n + 1].w);
+    uint32_t ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
     int x0 = rx & 0xFFFF, x1 = rx >> 16, y0 = ry & 0xFFFF, y1 = ry >> 16;
-    int tx0 = x0 / GS_TILE, tx1 = (x1 + GS_TILE - 1) / GS_TILE;
-    int ty0 = y0 / GS_TILE, ty1 = (y1 + GS_TILE - 1) / GS_TILE;
-    // Order-preserving float -> uint map (flip all bits of negatives, set the sign bit of
-    // non-negatives).  The reference uses the raw bit pattern, valid only for depth > 0
-    // (forward.cu:132); the map sorts identically there and stays correct for ANY key, which
-    // lets tests drive the sort with the CPU reference's as-read keys.
-    uint32_t db = __float_as_uint(depths[n]);
-    db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
-    uint64_t depth_bits = (uint64_t)db;
-    int o = start;
-    for (int ty = ty0; ty < ty1; ty++)
-        for (int tx = tx0; tx < tx1; tx++) {
-            uint64_t tile = (uint64_t)(ty * tiles_x + tx);
-            keys[o] = (int64_t)((tile << 32) | depth_bits);
-            ids[o] = n;
-            o++;
-        }
+    TileRect r;
+    r.tx0 = x0 / GS_TILE; r.tx1 = (x1 + GS_TILE - 1) / GS_TILE;
+    r.ty0 = y0 / GS_TILE; r.ty1 = (y1 + GS_TILE - 1) / GS_TILE;
+    if (x1 <= x0 || y1 <= y0) r.tx1 = r.tx0, r.ty1 = r.ty0;
+    return r;
 }
 
-// ---- tile ranges -----------------------------------------------------------------------------
+// Visit every tile of every Gaussian of this wave's 64-lane slice.  Small rectangles are walked
+// by their own lane; a rectangle with more than kLaneTiles tiles is walked by the whole wave
+// (one lane looping over thousands of tiles would stall the other 63).
+constexpr int kLaneTiles = 16;
+// f(tile, pa, pb): (pa, pb) is the owning lane's payload (broadcast when the wave walks it).
+template <typename F>
+__device__ __forceinline__ void for_each_tile(const TileRect &r, bool valid, int tiles_x,
+                                              uint32_t pa, int pb, F f) {
+    const int cnt = valid ? r.count() : 0;
+    if (cnt > 0 && cnt <= kLaneTiles) {
+        for (int ty = r.ty0; ty < r.ty1; ty++)
+            for (int tx = r.tx0; tx < r.tx1; tx++) f(ty * tiles_x + tx, pa, pb);
+    }
+    uint64_t big = __builtin_amdgcn_ballot_w64(cnt > kLaneTiles);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int tx0 = __builtin_amdgcn_readlane(r.tx0, src);
+        const int tx1 = __builtin_amdgcn_readlane(r.tx1, src);
+        const int ty0 = __builtin_amdgcn_readlane(r.ty0, src);
+        const int ty1 = __builtin_amdgcn_readlane(r.ty1, src);
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)pa, src);
+        const int b = __builtin_amdgcn_readlane(pb, src);
+        const int w = tx1 - tx0, total = w * (ty1 - ty0);
+        for (int i = lane; i < total; i += 64) f((ty0 + i / w) * tiles_x + tx0 + i % w, a, b);
+    }
+}
+
+// ---- 1. count ----------------------------------------------------------------------------------
+// Global atomics run at ~27 G requests/s on MI355X whatever the layout (scripts/ubench/atomics.hip),
+// LDS atomics are an order of magnitude faster: a few persistent workgroups each keep a private
+// table of all tile counters in LDS (4 B x tiles: 32 KiB at 1080p, 127 KiB at 4K, of the CU's
+// 160 KiB) and flush the non-zero ones with coalesced global atomics at the end.
+// k_count_tiles_global is the fallback for images with more tiles than fit in LDS.
 __global__ void __launch_bounds__(256)
-k_tile_bin_edges(int M, const int64_t *__restrict__ keys_sorted, int2 *__restrict__ bins) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    int cur = (int)(keys_sorted[i] >> 32);
-    if (i == 0) bins[cur].x = 0;
-    else {
-        int prev = (int)(keys_sorted[i - 1] >> 32);
-        if (prev != cur) {
-            bins[prev].y = i;
-            bins[cur].x = i;
+k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
+                     int32_t *__restrict__ counts) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = n < N;
+    TileRect r = {0, 0, 0, 0};
+    if (valid) r = tile_rect(packed, n);
+    for_each_tile(r, valid, tiles_x, 0u, 0,
+                  [&](int tile, uint32_t, int) { atomicAdd(&counts[tile], 1); });
+}
+
+__global__ void __launch_bounds__(256)
+k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
+              int32_t *__restrict__ counts) {
+    extern __shared__ int32_t h[];
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
+    __syncthreads();
+    // every iteration is taken by whole waves (for_each_tile uses wave-wide operations)
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int n = base + threadIdx.x;
+        const bool valid = n < N;
+        TileRect r = {0, 0, 0, 0};
+        if (valid) r = tile_rect(packed, n);
+        for_each_tile(r, valid, tiles_x, 0u, 0,
+                      [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const int32_t c = h[t];
+        if (c) atomicAdd(&counts[t], c);
+    }
+}
+
+// ---- 2. scan -----------------------------------------------------------------------------------
+// One 1024-thread workgroup; tiles <= 2^17 or so (8K x 8K image = 262144 tiles still fits: each
+// thread owns a contiguous slice).
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(int tiles, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+             int32_t *__restrict__ total_dev) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (tiles + 1023) / 1024;
+    const int lo = min(t * per, tiles), hi = min(lo + per, tiles);
+    int32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += counts[i];
+    part[t] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (int d = 1; d < 1024; d <<= 1) {
+        int32_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = part[t] - sum;  // exclusive prefix of this thread's slice
+    for (int i = lo; i < hi; i++) {
+        const int32_t c = counts[i];
+        bins[i] = make_int2(run, run + c);
+        run += c;
+    }
+    if (t == 1023) *total_dev = part[1023];
+}
+
+// ---- 3. scatter --------------------------------------------------------------------------------
+// key = order-preserving uint32 image of the depth float (flip all bits of negatives, set the
+// sign bit of non-negatives) << 32 | Gaussian id.  The reference uses the raw bit pattern, valid
+// only for depth > 0 (forward.cu:132); the map sorts identically there and stays correct for ANY
+// key, which lets tests drive the sort with the CPU reference's as-read keys.
+__global__ void __launch_bounds__(256)
+k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
+                 const float *__restrict__ depths, const int2 *__restrict__ bins,
+                 int32_t *__restrict__ fill, uint64_t *__restrict__ keys) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = n < N;
+    TileRect r = {0, 0, 0, 0};
+    uint32_t db = 0;
+    if (valid) {
+        r = tile_rect(packed, n);
+        db = __float_as_uint(depths[n]);
+        db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
+    }
+    for_each_tile(r, valid, tiles_x, db, n, [&](int tile, uint32_t d, int g) {
+        const int pos = bins[tile].x + atomicAdd(&fill[tile], 1);
+        if (pos < capacity) keys[pos] = ((uint64_t)d << 32) | (uint32_t)g;
+    });
+}
+
+// LDS-privatised variant: pass A counts this workgroup's intersections per tile in LDS; the
+// flush reserves a contiguous range per (workgroup, tile) with ONE returning global atomic and
+// turns the LDS counter into the range's start; pass B walks the same Gaussians again and takes
+// slots from the LDS cursors.  Slot order inside a tile is arbitrary — k_sort_tiles fixes it.
+__global__ void __launch_bounds__(256)
+k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
+          const float *__restrict__ depths, const int2 *__restrict__ bins,
+          int32_t *__restrict__ fill, uint64_t *__restrict__ keys) {
+    extern __shared__ int32_t h[];
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
+    __syncthreads();
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int n = base + threadIdx.x;
+        const bool valid = n < N;
+        TileRect r = {0, 0, 0, 0};
+        if (valid) r = tile_rect(packed, n);
+        for_each_tile(r, valid, tiles_x, 0u, 0,
+                      [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const int32_t c = h[t];
+        if (c) h[t] = bins[t].x + atomicAdd(&fill[t], c);
+    }
+    __syncthreads();
+    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
+        const int n = base + threadIdx.x;
+        const bool valid = n < N;
+        TileRect r = {0, 0, 0, 0};
+        uint32_t db = 0;
+        if (valid) {
+            r = tile_rect(packed, n);
+            db = __float_as_uint(depths[n]);
+            db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
+        }
+        for_each_tile(r, valid, tiles_x, db, n, [&](int tile, uint32_t d, int g) {
+            const int pos = atomicAdd(&h[tile], 1);
+            if (pos < capacity) keys[pos] = ((uint64_t)d << 32) | (uint32_t)g;
+        });
+    }
+}
+
+// ---- 4. per-tile sort --------------------------------------------------------------------------
+// Bitonic network over P = next power of two >= n keys, in the all-ascending formulation: each
+// merge phase starts with a "flip" step (i <-> mirror position inside the 2k block) followed by
+// half-cleaners, and every compare-exchange moves the smaller key to the lower index.  Padding
+// keys (all-ones) at positions >= n therefore never move, so they can be virtual.
+template <typename Mem>
+__device__ __forceinline__ void bitonic_sort(Mem &m, int P, int tid, int nthreads) {
+    for (int k = 2; k <= P; k <<= 1) {
+        const int half = k >> 1;
+        for (int i = tid; i < (P >> 1); i += nthreads) {
+            const int lo = ((i & ~(half - 1)) << 1) | (i & (half - 1));
+            const int hi = lo ^ (k - 1);
+            const uint64_t a = m.get(lo), b = m.get(hi);
+            if (a > b) {
+                m.set(lo, b);
+                m.set(hi, a);
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = tid; i < (P >> 1); i += nthreads) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int hi = lo | j;
+                const uint64_t a = m.get(lo), b = m.get(hi);
+                if (a > b) {
+                    m.set(lo, b);
+                    m.set(hi, a);
+                }
+            }
+            __syncthreads();
         }
     }
-    if (i == M - 1) bins[cur].y = M;
+}
+
+struct LdsKeys {
+    uint64_t *p;
+    __device__ __forceinline__ uint64_t get(int i) const { return p[i]; }
+    __device__ __forceinline__ void set(int i, uint64_t v) { p[i] = v; }
+};
+// global-memory variant: indices >= n read as the padding key and are never written back
+struct GlobalKeys {
+    uint64_t *p;
+    int n;
+    __device__ __forceinline__ uint64_t get(int i) const { return i < n ? p[i] : ~0ull; }
+    __device__ __forceinline__ void set(int i, uint64_t v) {
+        if (i < n) p[i] = v;
+    }
+};
+
+// Sorts the tiles whose segment length n satisfies lo_n < n <= hi_n (other tiles return at once),
+// so that the same code is launched for three size classes with different LDS footprints.
+template <int CAP, int NT>  // CAP = LDS capacity in keys (0 -> sort in place in global memory)
+__global__ void __launch_bounds__(NT)
+k_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
+             uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
+    __shared__ uint64_t lds[CAP > 0 ? CAP : 1];
+    const int2 range = bins[blockIdx.x];
+    const int start = range.x;
+    const int n = min(range.y, capacity) - start;
+    if (n <= lo_n || n > hi_n) return;
+    const int tid = threadIdx.x;
+    if (n == 1) {
+        if (tid == 0) ids_sorted[start] = (int32_t)(uint32_t)keys[start];
+        return;
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    if (CAP > 0) {
+        for (int i = tid; i < P; i += NT) lds[i] = (i < n) ? keys[start + i] : ~0ull;
+        __syncthreads();
+        LdsKeys m{lds};
+        bitonic_sort(m, P, tid, NT);
+        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)lds[i];
+    } else {
+        GlobalKeys m{keys + start, n};
+        __syncthreads();
+        bitonic_sort(m, P, tid, NT);
+        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+    }
+}
+
+// All segments longer than 512 keys: up to 8192 in 64 KiB of LDS, longer ones in place in global
+// memory (one launch for both rare classes).
+__global__ void __launch_bounds__(256)
+k_sort_tiles_long(int32_t capacity, const int2 *__restrict__ bins, uint64_t *__restrict__ keys,
+                  int32_t *__restrict__ ids_sorted) {
+    __shared__ uint64_t lds[8192];
+    const int2 range = bins[blockIdx.x];
+    const int start = range.x;
+    const int n = min(range.y, capacity) - start;
+    if (n <= 512) return;
+    const int tid = threadIdx.x;
+    int P = 1024;
+    while (P < n) P <<= 1;
+    if (n <= 8192) {
+        for (int i = tid; i < P; i += 256) lds[i] = (i < n) ? keys[start + i] : ~0ull;
+        __syncthreads();
+        LdsKeys m{lds};
+        bitonic_sort(m, P, tid, 256);
+        for (int i = tid; i < n; i += 256) ids_sorted[start + i] = (int32_t)(uint32_t)lds[i];
+    } else {
+        GlobalKeys m{keys + start, n};
+        bitonic_sort(m, P, tid, 256);
+        for (int i = tid; i < n; i += 256) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+    }
 }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-static int tile_bits(int W, int H) {
-    int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    int b = 0;
-    while ((1 << b) < tiles) b++;
-    return b < 1 ? 1 : b;
+// LDS budget of the privatised count / scatter kernels (the CU has 160 KiB) and their grid: one
+// persistent workgroup per CU is enough to saturate the LDS atomic units; fewer for small N.
+constexpr size_t kMaxTileLds = 144 * 1024;
+static int persistent_blocks(int N) {
+    int b = (N + 255) / 256;
+    return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 
-static size_t scan_temp_bytes(int N) {
-    size_t bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
-                            (size_t)N, rocprim::plus<int32_t>(), (hipStream_t)0);
-    return bytes;
-}
-
-static size_t sort_temp_bytes(int64_t M, int end_bit) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                              (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)M, 0u,
-                              (unsigned)end_bit, (hipStream_t)0);
-    return bytes;
+// workspace layout: [ counters: tiles i32 | total: 1 i32 (+pad) | keys: capacity u64 ]
+// gs_bin_scan uses the counters as per-tile intersection counts, gs_bin_sort (which zeroes them
+// again) as per-tile fill cursors; nothing in the workspace has to survive between the two calls.
+struct BinLayout {
+    size_t counters, total_dev, keys, total;
+};
+static BinLayout bin_layout(int64_t capacity, int W, int H) {
+    const size_t tiles = (size_t)((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    BinLayout L;
+    L.counters = 0;
+    L.total_dev = L.counters + align_up(tiles * 4);
+    L.keys = L.total_dev + 256;
+    L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 8) + 256;
+    return L;
 }
 
 }  // namespace gs
 
-extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const float *depths,
-                              const int32_t *radii, const float *conics, const float *colors,
-                              const float *opacities, const float *cov2d, float *packed,
-                              int32_t *tiles_hit, gs_stream_t stream) {
+extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
+                              const float *conics, const float *colors, const float *opacities,
+                              const float *cov2d, float *packed, int32_t *tiles_hit,
+                              gs_stream_t stream) {
     if (N < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0) return GS_OK;
-    if (!xys || !depths || !radii || !conics || !colors || !opacities || !packed || !tiles_hit)
+    if (!xys || !radii || !conics || !colors || !opacities || !packed || !tiles_hit)
         return GS_ERR_INVALID_ARGUMENT;
     if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(gs::k_pack_splats, dim3((N + 255) / 256), dim3(256), 0,
@@ -187,74 +435,106 @@ extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const float
 
 extern "C" size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H) {
     if (N < 0 || num_isects < 0 || W <= 0 || H <= 0) return 0;
-    int64_t M = num_isects > 0 ? num_isects : 1;
-    size_t scan = gs::scan_temp_bytes(N > 0 ? N : 1);
-    size_t sort = gs::sort_temp_bytes(M, 32 + gs::tile_bits(W, H));
-    size_t tmp = gs::align_up(scan > sort ? scan : sort);
-    // three optional arrays (unsorted keys, unsorted ids, sorted keys) + library temp storage
-    return tmp + gs::align_up((size_t)M * 8) * 2 + gs::align_up((size_t)M * 4) + 256;
+    return gs::bin_layout(num_isects, W, H).total;
 }
 
-extern "C" int gs_bin_scan(int N, const int32_t *tiles_hit, int32_t *cum_tiles_hit,
+extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
                            int32_t *num_isects_host, void *workspace, size_t workspace_bytes,
                            gs_stream_t stream) {
-    if (N < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (N < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (!tile_bins || !workspace) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)workspace & 15u) return GS_ERR_INVALID_ARGUMENT;
+    if (N > 0 && !packed) return GS_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
-    if (N == 0) {
-        if (num_isects_host) *num_isects_host = 0;
-        return GS_OK;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    const int tiles = tiles_x * tiles_y;
+    const gs::BinLayout L = gs::bin_layout(0, W, H);
+    if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
+    char *base = static_cast<char *>(workspace);
+    int32_t *counts = reinterpret_cast<int32_t *>(base + L.counters);
+    int32_t *total_dev = reinterpret_cast<int32_t *>(base + L.total_dev);
+    GS_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)tiles, s));
+    if (N > 0) {
+        const size_t lds = sizeof(int32_t) * (size_t)tiles;
+        if (lds <= gs::kMaxTileLds) {
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_count_tiles),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)gs::kMaxTileLds));
+            const int blocks = gs::persistent_blocks(N);
+            hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(256), lds, s, N, tiles, tiles_x,
+                               reinterpret_cast<const float4 *>(packed), counts);
+        } else {
+            hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
+                               tiles_x, reinterpret_cast<const float4 *>(packed), counts);
+        }
+        GS_LAUNCH_CHECK();
     }
-    if (!tiles_hit || !cum_tiles_hit || !workspace) return GS_ERR_INVALID_ARGUMENT;
-    size_t need = gs::scan_temp_bytes(N);
-    if (workspace_bytes < need) return GS_ERR_WORKSPACE;
-    GS_HIP_CHECK(rocprim::inclusive_scan(workspace, need, tiles_hit, cum_tiles_hit, (size_t)N,
-                                         rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, counts,
+                       reinterpret_cast<int2 *>(tile_bins), total_dev);
+    GS_LAUNCH_CHECK();
     if (num_isects_host)
-        GS_HIP_CHECK(hipMemcpyAsync(num_isects_host, cum_tiles_hit + (N - 1), sizeof(int32_t),
+        GS_HIP_CHECK(hipMemcpyAsync(num_isects_host, total_dev, sizeof(int32_t),
                                     hipMemcpyDeviceToHost, s));
     return GS_OK;
 }
 
-extern "C" int gs_bin_sort(int W, int H, int N, int32_t num_isects, const float *packed,
-                           const float *depths, const int32_t *cum_tiles_hit, int64_t *isect_ids,
-                           int32_t *gaussian_ids, int64_t *isect_ids_sorted,
-                           int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
-                           size_t workspace_bytes, gs_stream_t stream) {
-    if (N < 0 || num_isects < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed,
+                           const float *depths, const int32_t *tile_bins,
+                           int32_t *gaussian_ids_sorted, void *workspace, size_t workspace_bytes,
+                           gs_stream_t stream) {
+    if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
-    if (!tile_bins) return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0 || capacity == 0) return GS_OK;
+    if (!packed || !depths || !tile_bins || !gaussian_ids_sorted || !workspace)
+        return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)workspace & 15u) return GS_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
-    GS_HIP_CHECK(hipMemsetAsync(tile_bins, 0, sizeof(int32_t) * 2 * (size_t)tiles, s));
-    const int64_t M = num_isects;
-    if (N == 0 || M == 0) return GS_OK;
-    if (!packed || !depths || !cum_tiles_hit || !gaussian_ids_sorted || !workspace)
-        return GS_ERR_INVALID_ARGUMENT;
-    if (workspace_bytes < gs_bin_workspace_bytes(N, M, W, H)) return GS_ERR_WORKSPACE;
-
-    const int end_bit = 32 + gs::tile_bits(W, H);
-    size_t sort_tmp = gs::sort_temp_bytes(M, end_bit);
-    size_t scan_tmp = gs::scan_temp_bytes(N > 0 ? N : 1);
-    size_t tmp = gs::align_up(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
+    const gs::BinLayout L = gs::bin_layout(capacity, W, H);
+    if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
     char *base = static_cast<char *>(workspace);
-    char *p = base + tmp;
-    if (!isect_ids) isect_ids = reinterpret_cast<int64_t *>(p);
-    p += gs::align_up((size_t)M * 8);
-    if (!isect_ids_sorted) isect_ids_sorted = reinterpret_cast<int64_t *>(p);
-    p += gs::align_up((size_t)M * 8);
-    if (!gaussian_ids) gaussian_ids = reinterpret_cast<int32_t *>(p);
+    int32_t *fill = reinterpret_cast<int32_t *>(base + L.counters);
+    uint64_t *keys = reinterpret_cast<uint64_t *>(base + L.keys);
+    const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
+    GS_HIP_CHECK(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)tiles, s));
 
-    hipLaunchKernelGGL(gs::k_emit_isects, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
-                       reinterpret_cast<const float4 *>(packed), depths, cum_tiles_hit, isect_ids,
-                       gaussian_ids);
+    const size_t lds = sizeof(int32_t) * (size_t)tiles;
+    if (lds <= gs::kMaxTileLds) {
+        GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scatter),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)gs::kMaxTileLds));
+        const int blocks = gs::persistent_blocks(N);
+        hipLaunchKernelGGL(gs::k_scatter, dim3(blocks), dim3(256), lds, s, N, tiles, tiles_x, capacity,
+                           reinterpret_cast<const float4 *>(packed), depths, bins, fill, keys);
+    } else {
+        hipLaunchKernelGGL(gs::k_scatter_global, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
+                           capacity, reinterpret_cast<const float4 *>(packed), depths, bins, fill,
+                           keys);
+    }
     GS_LAUNCH_CHECK();
-    GS_HIP_CHECK(rocprim::radix_sort_pairs(
-        base, sort_tmp, reinterpret_cast<const uint64_t *>(isect_ids),
-        reinterpret_cast<uint64_t *>(isect_ids_sorted), gaussian_ids, gaussian_ids_sorted,
-        (size_t)M, 0u, (unsigned)end_bit, s));
-    hipLaunchKernelGGL(gs::k_tile_bin_edges, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,
-                       (int)M, isect_ids_sorted, reinterpret_cast<int2 *>(tile_bins));
+    // <= 512 keys: one wave per tile (no cross-wave barriers); longer segments: 256 threads
+    hipLaunchKernelGGL((gs::k_sort_tiles<512, 64>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+                       bins, keys, gaussian_ids_sorted);
+    GS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gs::k_sort_tiles_long, dim3(tiles), dim3(256), 0, s, capacity, bins, keys,
+                       gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
     return GS_OK;
+}
+
+extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
+                               const float *depths, int32_t *tile_bins,
+                               int32_t *gaussian_ids_sorted, int32_t *num_isects_host,
+                               void *workspace, size_t workspace_bytes, gs_stream_t stream) {
+    if (!num_isects_host) return GS_ERR_INVALID_ARGUMENT;
+    int rc = gs_bin_scan(W, H, N, packed, tile_bins, num_isects_host, workspace, workspace_bytes,
+                         stream);
+    if (rc != GS_OK) return rc;
+    GS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const int32_t M = *num_isects_host;
+    if (M > capacity) return GS_ERR_CAPACITY;
+    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, workspace,
+                       workspace_bytes, stream);
 }

@@ -50,6 +50,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int kChunk = 64;  // entries staged per pass == wave width
+constexpr int kGradRec = 16;  // floats per Gaussian in the backward's gradient records (64 B)
+
+// Optional work counters (build with -DGS_STATS; never in the shipped library): per launch totals of
+// [0] entries visited  [1] 8-row halves evaluated  [2] halves with a needing lane  [3] exponential
+// passes  [4] needing (lane, pixel) pairs  — forward in slots 0-7, backward in slots 8-15.
+#ifdef GS_STATS
+__device__ unsigned long long g_stats[16];
+#define GS_STAT(slot, v)                                                          \
+    do {                                                                          \
+        if (threadIdx.x == 0) atomicAdd(&g_stats[slot], (unsigned long long)(v)); \
+    } while (0)
+#else
+#define GS_STAT(slot, v) \
+    do {                 \
+    } while (0)
+#endif
 
 // LDS image of one staged entry (48 B, three ds_read_b128):
 //   a = {x, y, conic A, conic B}   b = {conic C, opacity, sigma_max|flag, mask bits}
@@ -110,17 +126,19 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     const float pxf = (float)px;
     // py2[h] = row coordinates of pixels k = 2h, 2h+1; NaN once the pixel is finished (or outside
     // the image): a NaN row makes sigma NaN, which fails "0 <= sigma <= sigma_max".
-    f2 py2[2];
-    float T[4], acc[4][3];
+    f2 py2[2], T2[2], acc2[2][3];
     int last[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
         const float v = (px < W && py < H) ? (float)py : qnan();
         if (k & 1) py2[k >> 1].y = v; else py2[k >> 1].x = v;
-        T[k] = 1.0f;
-        acc[k][0] = acc[k][1] = acc[k][2] = 0.0f;
         last[k] = -1;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        T2[h] = (f2)(1.0f);
+        acc2[h][0] = acc2[h][1] = acc2[h][2] = (f2)(0.0f);
     }
     const uint32_t colbit = 1u << lx;
 
@@ -139,6 +157,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         for (int t = 0; t < n; t++) {
             const float4 ea = stage[t].a;
             const float4 eb = stage[t].b;
+            const float4 ec = stage[t].c;
             const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
             const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.z));
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
@@ -147,9 +166,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             const float Adx = ea.z * dx;    // A * xCam
             const float Bdx = ea.w * dx;    // B * xCam
             const float Adxdx = Adx * dx;   // A * xCam * xCam
+            GS_STAT(0, 1);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (((mask >> (16 + 8 * h)) & 0xFFu) == 0u) continue;  // scalar: half untouched
+                GS_STAT(1, 1);
                 f2 py = py2[h];
                 if (rect_binds) {  // rows outside the rectangle
                     if ((mask & (1u << (16 + ly + 8 * h))) == 0u) py.x = qnan();
@@ -163,32 +184,45 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 sg = sg + Bdx * dy;
                 const bool need0 = (sg.x >= 0.0f) && (sg.x <= eb.z);
                 const bool need1 = (sg.y >= 0.0f) && (sg.y <= eb.z);
-                if (__builtin_amdgcn_ballot_w64(need0 || need1) == 0ull) continue;
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int k = 2 * h + j;
-                    const bool need = j ? need1 : need0;
-                    const float sigma = j ? sg.y : sg.x;
-                    if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-                    if (need) {
-                        const float alpha = fminf(0.999f, eb.y * gs_exp<EXACT>(-sigma, exp_tab));
-                        if (alpha >= (1.0f / 255.0f)) {
-                            const float nextT = T[k] * (1.0f - alpha);
-                            if (nextT <= 1e-4f) {
-                                // pixel done; the Gaussian is not rendered (gsplat_cpu.cpp:225-228)
-                                if (j) py2[h].y = qnan(); else py2[h].x = qnan();
-                            } else {
-                                const float4 ec = stage[t].c;
-                                const float vis = alpha * T[k];
-                                acc[k][0] += vis * ec.x;
-                                acc[k][1] += vis * ec.y;
-                                acc[k][2] += vis * ec.z;
-                                T[k] = nextT;
-                                last[k] = c0 + t;
-                            }
-                        }
-                    }
+                // (ballots of the individual compares: they stay in SGPRs, no VALU round trip)
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(sg.x >= 0.0f) &
+                                    __builtin_amdgcn_ballot_w64(sg.x <= eb.z);
+                const uint64_t m1 = __builtin_amdgcn_ballot_w64(sg.y >= 0.0f) &
+                                    __builtin_amdgcn_ballot_w64(sg.y <= eb.z);
+                if ((m0 | m1) == 0ull) continue;
+                GS_STAT(2, 1);
+                GS_STAT(3, (m0 != 0ull) + (m1 != 0ull));
+                GS_STAT(4, __builtin_popcountll(m0) + __builtin_popcountll(m1));
+                // exp(-sigma) only where needed; other lanes keep 0 => alpha 0 => no contribution
+                f2 vis = (f2)(0.0f);
+                if (m0 != 0ull) {
+                    if (need0) vis.x = gs_exp<EXACT>(-sg.x, exp_tab);
                 }
+                if (m1 != 0ull) {
+                    if (need1) vis.y = gs_exp<EXACT>(-sg.y, exp_tab);
+                }
+                // gsplat_cpu.cpp:220-236 for both pixels of the pair, without branches:
+                //   alpha = min(0.999, opacity*vis); skip if alpha < 1/255; nextT = T*(1-alpha);
+                //   nextT <= 1e-4 -> pixel done (Gaussian not rendered); else composite.
+                f2 alpha = eb.y * vis;
+                alpha.x = __builtin_amdgcn_fmed3f(alpha.x, 0.0f, 0.999f);
+                alpha.y = __builtin_amdgcn_fmed3f(alpha.y, 0.0f, 0.999f);
+                const bool ok0 = alpha.x >= (1.0f / 255.0f), ok1 = alpha.y >= (1.0f / 255.0f);
+                const f2 nT = T2[h] * (1.0f - alpha);
+                const bool stop0 = nT.x <= 1e-4f, stop1 = nT.y <= 1e-4f;
+                const bool con0 = ok0 && !stop0, con1 = ok1 && !stop1;
+                f2 w = alpha * T2[h];
+                w.x = con0 ? w.x : 0.0f;
+                w.y = con1 ? w.y : 0.0f;
+                acc2[h][0] = acc2[h][0] + w * ec.x;
+                acc2[h][1] = acc2[h][1] + w * ec.y;
+                acc2[h][2] = acc2[h][2] + w * ec.z;
+                T2[h].x = con0 ? nT.x : T2[h].x;
+                T2[h].y = con1 ? nT.y : T2[h].y;
+                last[2 * h] = con0 ? (c0 + t) : last[2 * h];
+                last[2 * h + 1] = con1 ? (c0 + t) : last[2 * h + 1];
+                py2[h].x = (ok0 && stop0) ? qnan() : py2[h].x;
+                py2[h].y = (ok1 && stop1) ? qnan() : py2[h].y;
             }
         }
     }
@@ -197,10 +231,15 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         const int py = tile_y0 + ly + 4 * k;
         if (px < W && py < H) {
             const size_t pix = (size_t)py * W + px;
-            out_img[3 * pix + 0] = acc[k][0] + T[k] * bg0;
-            out_img[3 * pix + 1] = acc[k][1] + T[k] * bg1;
-            out_img[3 * pix + 2] = acc[k][2] + T[k] * bg2;
-            final_Ts[pix] = T[k];
+            const int h = k >> 1;
+            const float Tk = (k & 1) ? T2[h].y : T2[h].x;
+            const float a0 = (k & 1) ? acc2[h][0].y : acc2[h][0].x;
+            const float a1 = (k & 1) ? acc2[h][1].y : acc2[h][1].x;
+            const float a2 = (k & 1) ? acc2[h][2].y : acc2[h][2].x;
+            out_img[3 * pix + 0] = a0 + Tk * bg0;
+            out_img[3 * pix + 1] = a1 + Tk * bg1;
+            out_img[3 * pix + 2] = a2 + Tk * bg2;
+            final_Ts[pix] = Tk;
             final_idx[pix] = last[k];
         }
     }
@@ -269,9 +308,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                      float bg1, float bg2, const float *__restrict__ final_Ts,
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
-                     const float *__restrict__ v_out_alpha, float *__restrict__ v_xy,
-                     float *__restrict__ v_conic, float *__restrict__ v_colors,
-                     float *__restrict__ v_opacity) {
+                     const float *__restrict__ v_out_alpha, float *__restrict__ gacc) {
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[32];
     const int lane = threadIdx.x;
@@ -316,11 +353,12 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     bv2[0] = (f2)(0.0f);
     bv2[1] = (f2)(0.0f);
 
-    // lanes that hold a reduced total scatter it: per-lane base pointer and element stride
+    // lanes that hold a reduced total scatter it into the Gaussian's 64-byte gradient record
+    // gacc[g][0..8] = {v_x, v_y, v_A, v_B, v_C, v_r, v_g, v_b, v_opacity}: the nine lanes of the one
+    // atomic instruction hit ONE cache line, which the L2 serves ~4x faster than nine lines
+    // (measured, scripts/ubench/atomics.hip); k_unpack_grads splits the records afterwards.
     const int role = reduce9_role(lane);
-    float *wbase = (role < 2) ? v_xy + role : (role < 5) ? v_conic + (role - 2)
-                   : (role < 8) ? v_colors + (role - 5) : v_opacity;
-    const int wstride = (role < 2) ? 2 : (role < 8) ? 3 : 1;
+    float *wbase = gacc + (role >= 0 ? role : 0);
     const uint32_t colbit = 1u << lx;
 
     const int2 range = bins[tile];
@@ -345,27 +383,44 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
             const int e = hi - t;  // index of this entry in the sorted list
             const float dx = ea.x - pxf;
-            const float Adx = ea.z * dx, Bdx = ea.w * dx, Adxdx = Adx * dx;
-            const bool col_ok = !rect_binds || (mask & colbit) != 0u;
+            // sigma is evaluated from copies of dx / dy that are NaN outside the rectangle when
+            // the rectangle binds (a NaN sigma fails both compares); the moments use the real ones
+            float dxs = dx;
+            if (rect_binds && (mask & colbit) == 0u) dxs = qnan();
+            const float Adx = ea.z * dxs, Bdx = ea.w * dxs, Adxdx = Adx * dxs;
             f2 s0 = (f2)(0.0f), s1 = (f2)(0.0f), s2 = (f2)(0.0f);
             f2 gr = (f2)(0.0f), gg = (f2)(0.0f), gb = (f2)(0.0f);
             bool any = false;  // wave-uniform
+            GS_STAT(8, 1);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (((mask >> (16 + 8 * h)) & 0xFFu) == 0u) continue;  // scalar: half untouched
-                const f2 dy = ea.y - py2[h];
-                f2 sg = (eb.x * dy) * dy;
+                GS_STAT(9, 1);
+                f2 pys = py2[h];
+                if (rect_binds) {
+                    if ((mask & (1u << (16 + ly + 8 * h))) == 0u) pys.x = qnan();
+                    if ((mask & (1u << (16 + ly + 8 * h + 4))) == 0u) pys.y = qnan();
+                }
+                const f2 dys = ea.y - pys;
+                f2 dy = dys;
+                if (rect_binds) dy = ea.y - py2[h];
+                f2 sg = (eb.x * dys) * dys;
                 sg = Adxdx + sg;
                 sg = 0.5f * sg;
-                sg = sg + Bdx * dy;
-                bool need0 = (e <= last[2 * h]) && (sg.x >= 0.0f) && (sg.x <= eb.z) && col_ok;
-                bool need1 = (e <= last[2 * h + 1]) && (sg.y >= 0.0f) && (sg.y <= eb.z) && col_ok;
-                if (rect_binds) {
-                    need0 = need0 && (mask & (1u << (16 + ly + 8 * h))) != 0u;
-                    need1 = need1 && (mask & (1u << (16 + ly + 8 * h + 4))) != 0u;
-                }
-                if (__builtin_amdgcn_ballot_w64(need0 || need1) == 0ull) continue;
+                sg = sg + Bdx * dys;
+                const bool need0 = (e <= last[2 * h]) && (sg.x >= 0.0f) && (sg.x <= eb.z);
+                const bool need1 = (e <= last[2 * h + 1]) && (sg.y >= 0.0f) && (sg.y <= eb.z);
+                // (ballots of the individual compares: they stay in SGPRs, no VALU round trip)
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(e <= last[2 * h]) &
+                                    __builtin_amdgcn_ballot_w64(sg.x >= 0.0f) &
+                                    __builtin_amdgcn_ballot_w64(sg.x <= eb.z);
+                const uint64_t m1 = __builtin_amdgcn_ballot_w64(e <= last[2 * h + 1]) &
+                                    __builtin_amdgcn_ballot_w64(sg.y >= 0.0f) &
+                                    __builtin_amdgcn_ballot_w64(sg.y <= eb.z);
+                if ((m0 | m1) == 0ull) continue;
                 any = true;
+                GS_STAT(10, 1);
+                GS_STAT(12, __builtin_popcountll(m0) + __builtin_popcountll(m1));
                 // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338;
                 // lanes that do not take part end up with vis = alpha = 0
                 f2 vis;
@@ -378,15 +433,18 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                     const float thr = 1.0f / 255.0f;
                     const bool amb0 = need0 && fabsf(alpha.x - thr) < 1.0e-8f;
                     const bool amb1 = need1 && fabsf(alpha.y - thr) < 1.0e-8f;
-                    if (__builtin_amdgcn_ballot_w64(amb0 || amb1) != 0ull) {
+                    const uint64_t ma =
+                        (m0 & __builtin_amdgcn_ballot_w64(fabsf(alpha.x - thr) < 1.0e-8f)) |
+                        (m1 & __builtin_amdgcn_ballot_w64(fabsf(alpha.y - thr) < 1.0e-8f));
+                    if (ma != 0ull) {
                         if (amb0) { vis.x = expf_glibc(-sg.x, exp_tab); alpha.x = eb.y * vis.x; }
                         if (amb1) { vis.y = expf_glibc(-sg.y, exp_tab); alpha.y = eb.y * vis.y; }
                     }
                 }
                 const bool ok0 = alpha.x >= (1.0f / 255.0f);
                 const bool ok1 = alpha.y >= (1.0f / 255.0f);
-                alpha.x = ok0 ? fminf(0.99f, alpha.x) : 0.0f;
-                alpha.y = ok1 ? fminf(0.99f, alpha.y) : 0.0f;
+                alpha.x = ok0 ? __builtin_amdgcn_fmed3f(alpha.x, 0.0f, 0.99f) : 0.0f;
+                alpha.y = ok1 ? __builtin_amdgcn_fmed3f(alpha.y, 0.0f, 0.99f) : 0.0f;
                 vis.x = ok0 ? vis.x : 0.0f;
                 vis.y = ok1 ? vis.y : 0.0f;
                 // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
@@ -415,6 +473,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 s2 = __builtin_elementwise_fma(ud, dy, s2);
             }
             if (!any) continue;
+            GS_STAT(11, 1);
             // per-lane conversion of the moments to the nine gradient components
             const float S0 = s0.x + s0.y, S1 = s1.x + s1.y, S2 = s2.x + s2.y;
             const float mo = -eb.y;
@@ -432,10 +491,31 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                                     gb.x + gb.y, S0, lane);
             if (role >= 0) {
                 const int g = __float_as_int(ec.w);
-                atomicAdd(wbase + (size_t)g * wstride, r);
+                atomicAdd(wbase + (size_t)g * kGradRec, r);
             }
         }
     }
+}
+
+// Splits the 64-byte gradient records into the four tensors the operator surface returns
+// (rasterize_gaussians.cpp:113-124): v_xy[N,2] v_conic[N,3] v_colors[N,3] v_opacity[N].
+__global__ void __launch_bounds__(256)
+k_unpack_grads(int N, const float4 *__restrict__ gacc, float *__restrict__ v_xy,
+               float *__restrict__ v_conic, float *__restrict__ v_colors,
+               float *__restrict__ v_opacity) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = gacc[4 * (size_t)n + 0], b = gacc[4 * (size_t)n + 1];
+    const float o = reinterpret_cast<const float *>(gacc)[kGradRec * (size_t)n + 8];
+    v_xy[2 * (size_t)n + 0] = a.x;
+    v_xy[2 * (size_t)n + 1] = a.y;
+    v_conic[3 * (size_t)n + 0] = a.z;
+    v_conic[3 * (size_t)n + 1] = a.w;
+    v_conic[3 * (size_t)n + 2] = b.x;
+    v_colors[3 * (size_t)n + 0] = b.y;
+    v_colors[3 * (size_t)n + 1] = b.z;
+    v_colors[3 * (size_t)n + 2] = b.w;
+    v_opacity[n] = o;
 }
 
 // Test hook: the exponential exactly as the compositing kernels evaluate it.
@@ -467,6 +547,18 @@ extern "C" int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
+
+#ifdef GS_STATS
+extern "C" int gs_debug_stats(unsigned long long *host16, int reset) {
+    GS_HIP_CHECK(hipDeviceSynchronize());
+    if (host16) GS_HIP_CHECK(hipMemcpyFromSymbol(host16, HIP_SYMBOL(gs::g_stats), 16 * 8));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        GS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs::g_stats), z, 16 * 8));
+    }
+    return GS_OK;
+}
+#endif
 
 extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream) {
     if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
@@ -503,34 +595,45 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     return GS_OK;
 }
 
-extern "C" int gs_rasterize_backward(int W, int H, const int32_t *gaussian_ids_sorted,
+extern "C" size_t gs_rasterize_backward_workspace_bytes(int N) {
+    return N > 0 ? (size_t)N * gs::kGradRec * sizeof(float) : 0;
+}
+
+extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
                                      const int32_t *tile_bins, const float *packed,
                                      const float *background, const float *final_Ts,
                                      const int32_t *final_idx, const float *v_out,
                                      const float *v_out_alpha, float *v_xy, float *v_conic,
-                                     float *v_colors, float *v_opacity, uint32_t flags,
-                                     gs_stream_t stream) {
-    if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+                                     float *v_colors, float *v_opacity, void *workspace,
+                                     size_t workspace_bytes, uint32_t flags, gs_stream_t stream) {
+    if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (N == 0) return GS_OK;
     if (!tile_bins || !background || !final_Ts || !final_idx || !v_out || !v_xy || !v_conic ||
-        !v_colors || !v_opacity)
+        !v_colors || !v_opacity || !workspace)
         return GS_ERR_INVALID_ARGUMENT;
-    if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)packed & 15u) || ((uintptr_t)workspace & 63u)) return GS_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < gs_rasterize_backward_workspace_bytes(N)) return GS_ERR_WORKSPACE;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    float *gacc = static_cast<float *>(workspace);
+    GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
-                           v_xy, v_conic, v_colors, v_opacity);
+                           gacc);
     else
         hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
-                           v_xy, v_conic, v_colors, v_opacity);
+                           gacc);
+    GS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
+                       reinterpret_cast<const float4 *>(gacc), v_xy, v_conic, v_colors, v_opacity);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

@@ -176,33 +176,40 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
     gs_stream_t s = current_stream();
 
     Tensor packed = torch::empty({N, GS_SPLAT_DWORDS}, f32);
-    Tensor tilesHit = torch::empty({N}, i32), cum = torch::empty({N}, i32);
-    check_status(gs_pack_splats(W, H, (int)N, fptr(xys), fptr(depths), radii.data_ptr<int32_t>(),
-                                fptr(conics), fptr(colors), fptr(opacity),
+    Tensor tilesHit = torch::empty({N}, i32);
+    check_status(gs_pack_splats(W, H, (int)N, fptr(xys), radii.data_ptr<int32_t>(), fptr(conics),
+                                fptr(colors), fptr(opacity),
                                 cov2d.defined() ? fptr(cov2d) : nullptr, fptr_mut(packed),
                                 tilesHit.data_ptr<int32_t>(), s),
                  "gs_pack_splats");
 
-    // The intersection count sizes the sort: one pinned int, one stream sync — the same place the
-    // reference blocks (rasterize_gaussians.cpp:62-63).
-    Tensor mHost = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    size_t scanBytes = gs_bin_workspace_bytes((int)N, 0, W, H);
-    Tensor scanWs = torch::empty({(int64_t)scanBytes}, xys.options().dtype(torch::kUInt8));
-    check_status(gs_bin_scan((int)N, tilesHit.data_ptr<int32_t>(), cum.data_ptr<int32_t>(),
-                             mHost.data_ptr<int32_t>(), scanWs.data_ptr(), scanBytes, s),
-                 "gs_bin_scan");
-    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
-    const int64_t M = N > 0 ? mHost.data_ptr<int32_t>()[0] : 0;
-
+    // The intersection count sizes the id list: one pinned int, one stream sync inside
+    // gs_bin_and_sort — the same place the reference blocks (rasterize_gaussians.cpp:62-63).
+    // The capacity guess is the last count seen by this process (+12.5 %); a miss costs one retry.
+    static std::atomic<int64_t> capacityHint{0};
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    Tensor idsSorted = torch::empty({M}, i32);
     Tensor tileBins = torch::empty({tiles, 2}, i32);
-    size_t wsBytes = gs_bin_workspace_bytes((int)N, M, W, H);
-    Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
-    check_status(gs_bin_sort(W, H, (int)N, (int32_t)M, fptr(packed), fptr(depths), cum.data_ptr<int32_t>(),
-                             nullptr, nullptr, nullptr, idsSorted.data_ptr<int32_t>(),
-                             tileBins.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
-                 "gs_bin_sort");
+    Tensor mHost = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    Tensor idsSorted;
+    int64_t M = 0;
+    for (;;) {
+        int64_t cap = std::max<int64_t>(capacityHint.load(), 1024);
+        idsSorted = torch::empty({cap}, i32);
+        size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
+        Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
+        int rc = gs_bin_and_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
+                                 tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
+                                 mHost.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s);
+        M = mHost.data_ptr<int32_t>()[0];
+        if (rc == GS_ERR_CAPACITY) {
+            capacityHint.store(M + M / 8 + 1024);
+            continue;
+        }
+        check_status(rc, "gs_bin_and_sort");
+        capacityHint.store(M + M / 8 + 1024);
+        break;
+    }
+    idsSorted = idsSorted.narrow(0, 0, M);
     return std::make_tuple(packed, idsSorted, tileBins, M);
 }
 
@@ -273,15 +280,16 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
                          (float)ctx->saved_data["bg1"].toDouble(),
                          (float)ctx->saved_data["bg2"].toDouble()};
     auto f32 = packed.options();
-    // accumulated with atomics -> zero-filled (reference: bindings.cu:591-598)
-    Tensor v_xy = torch::zeros({N, 2}, f32), v_conic = torch::zeros({N, 3}, f32);
-    Tensor v_colors = torch::zeros({N, 3}, f32), v_opacity = torch::zeros({N, 1}, f32);
-    check_status(gs_rasterize_backward(W, H, idsSorted.data_ptr<int32_t>(),
+    Tensor v_xy = torch::empty({N, 2}, f32), v_conic = torch::empty({N, 3}, f32);
+    Tensor v_colors = torch::empty({N, 3}, f32), v_opacity = torch::empty({N, 1}, f32);
+    const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
+    Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
+    check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
                                        tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                        fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
                                        nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
                                        fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
-                                       fptr_mut(v_opacity),
+                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
                                        (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
                  "gs_rasterize_backward");
     Tensor none;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Work counters of the compositing kernels on the bench scene (instrumented -DGS_STATS build).
+
+  cd opensplat_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+      -ffp-contract=off -DGS_STATS gs_*.hip -o libgsplat_hip_stats.so
+  GSPLAT_HIP_LIB=opensplat_amd/csrc/libgsplat_hip_stats.so python scripts/work_stats.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from opensplat_amd import cabi, scenes  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+s = {"C1": scenes.config_c1, "C2": scenes.config_c2, "C3": scenes.config_c3}[cfg]()
+if s.v_out is None:
+    import numpy as np
+    s.v_out = np.random.RandomState(3).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
+pipe = bench.Pipeline(s, torch.device("cuda:0"), 0)
+l = cabi.lib()
+buf = (C.c_ulonglong * 16)()
+pipe.step()
+l.gs_debug_stats(buf, 1)
+pipe.step()
+l.gs_debug_stats(buf, 1)
+v = list(buf)
+names = ["entries", "halves", "halves_need", "exp_passes", "need_lane_pixels"]
+out = {"M": pipe.num_isects,
+       "forward": dict(zip(names, v[0:5])),
+       "backward": dict(zip(["entries", "halves", "halves_need", "entries_any", "need_lane_pixels"], v[8:13]))}
+print(json.dumps(out))
