@@ -67,12 +67,20 @@ __device__ unsigned long long g_stats[16];
     } while (0)
 #endif
 
-// LDS image of one staged entry (48 B, three ds_read_b128):
-//   a = {x, y, conic A, conic B}   b = {conic C, opacity, sigma_max|flag, mask bits}
-//   c = {r, g, b, id}
+// LDS image of one staged entry (96 B, six ds_read_b128).  Everything a packed (2-pixel) instruction
+// consumes is stored as a DUPLICATED pair, so that one 64-bit LDS read yields the broadcast
+// operand {v, v} directly (the compiler cannot express "same 32-bit register for both halves" on
+// v_pk_*_f32 and would spend a v_mov per use otherwise):
+//   q0 = {x, x, y, y}  q1 = {A, A, B, B}  q2 = {C, C, opacity, opacity}  q3 = {r, r, g, g}
+//   q4 = {b, b, sigma_max|flag, mask bits}  q5 = {id, -, -, -}
 struct __attribute__((aligned(16))) Staged {
-    float4 a, b, c;
+    f2 xx, yy, AA, BB, CC, oo, rr, gg, bb;
+    float smax;
+    uint32_t mask;
+    int id;
+    int pad[3];
 };
+static_assert(sizeof(Staged) == 96, "staged entry must be six 16-byte words");
 
 // One sorted-list entry as gathered from HBM (13 VGPRs): prefetched one chunk ahead.
 struct Rec {
@@ -99,31 +107,35 @@ __device__ __forceinline__ void fetch_entry(Rec &r, int idx, const int32_t *__re
 }
 
 __device__ __forceinline__ void stage_entry(Staged *dst, const Rec &r, int tile_x0, int tile_y0) {
-    uint32_t m = tile_mask(__float_as_uint(r.p1.w), __float_as_uint(r.p2.w), tile_x0, tile_y0);
-    dst->a = r.p0;
-    dst->b = make_float4(r.p1.x, r.p1.y, r.p1.z, __uint_as_float(m));
-    dst->c = make_float4(r.p2.x, r.p2.y, r.p2.z, __int_as_float(r.g));
+    const uint32_t m = tile_mask(__float_as_uint(r.p1.w), __float_as_uint(r.p2.w), tile_x0, tile_y0);
+    float4 *q = reinterpret_cast<float4 *>(dst);
+    q[0] = make_float4(r.p0.x, r.p0.x, r.p0.y, r.p0.y);
+    q[1] = make_float4(r.p0.z, r.p0.z, r.p0.w, r.p0.w);
+    q[2] = make_float4(r.p1.x, r.p1.x, r.p1.y, r.p1.y);
+    q[3] = make_float4(r.p2.x, r.p2.x, r.p2.y, r.p2.y);
+    q[4] = make_float4(r.p2.z, r.p2.z, r.p1.z, __uint_as_float(m));
+    q[5] = make_float4(__int_as_float(r.g), 0.0f, 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 
 // ---------------------------------------------------------------------------------------------
-template <bool EXACT>
+template <bool EXACT, bool PREFETCH>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                     float bg1, float bg2, float *__restrict__ out_img,
                     float *__restrict__ final_Ts, int32_t *__restrict__ final_idx) {
     __shared__ Staged stage[kChunk];
-    __shared__ uint64_t exp_tab[32];
+    __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
     const int tile = xcd_swizzle(blockIdx.x, num_tiles);
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
-    if (EXACT && lane < 32) exp_tab[lane] = kExp2fTab[lane];
+    if (EXACT) load_exp_table(exp_tab, lane, 64);
 
     const int lx = lane & 15, ly = lane >> 4;
     const int px = tile_x0 + lx;
-    const float pxf = (float)px;
+    const f2 pxf2 = (f2)((float)px);
     // py2[h] = row coordinates of pixels k = 2h, 2h+1; NaN once the pixel is finished (or outside
     // the image): a NaN row makes sigma NaN, which fails "0 <= sigma <= sigma_max".
     f2 py2[2], T2[2], acc2[2][3];
@@ -144,28 +156,33 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
 
     const int2 range = bins[tile];
     Rec nxt;
-    if (range.x + lane < range.y) fetch_entry(nxt, range.x + lane, ids, packed);
+    if (PREFETCH && range.x + lane < range.y) fetch_entry(nxt, range.x + lane, ids, packed);
     for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
         const bool alive = (py2[0].x == py2[0].x) || (py2[0].y == py2[0].y) ||
                            (py2[1].x == py2[1].x) || (py2[1].y == py2[1].y);
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
-        if (c0 + lane < range.y) stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
+        if (c0 + lane < range.y) {
+            if (!PREFETCH) fetch_entry(nxt, c0 + lane, ids, packed);
+            stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
+        }
         __syncthreads();
-        if (c0 + kChunk + lane < range.y) fetch_entry(nxt, c0 + kChunk + lane, ids, packed);
+        if (PREFETCH && c0 + kChunk + lane < range.y) fetch_entry(nxt, c0 + kChunk + lane, ids, packed);
         const int n = min(kChunk, range.y - c0);
         for (int t = 0; t < n; t++) {
-            const float4 ea = stage[t].a;
-            const float4 eb = stage[t].b;
-            const float4 ec = stage[t].c;
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
-            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.z));
+            const Staged &e = stage[t];
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(e.mask);
+            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(e.smax));
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
-            float dx = ea.x - pxf;
-            if (rect_binds && (mask & colbit) == 0u) dx = qnan();  // column outside the rectangle
-            const float Adx = ea.z * dx;    // A * xCam
-            const float Bdx = ea.w * dx;    // B * xCam
-            const float Adxdx = Adx * dx;   // A * xCam * xCam
+            f2 dx2 = e.xx - pxf2;  // {xCam, xCam}
+            if (rect_binds) {  // rare: keep it a scalar branch
+                asm volatile("; rectangle binds");
+                if ((mask & colbit) == 0u) dx2 = (f2)(qnan());  // column outside the rectangle
+            }
+            const f2 Adx = e.AA * dx2;     // A * xCam
+            const f2 Adxdx = Adx * dx2;    // A * xCam * xCam
+            const f2 Bdx = e.BB * dx2;     // B * xCam
+            const f2 yy = e.yy, CC = e.CC, oo = e.oo, rr = e.rr, gg = e.gg, bb = e.bb;
             GS_STAT(0, 1);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -173,22 +190,25 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 GS_STAT(1, 1);
                 f2 py = py2[h];
                 if (rect_binds) {  // rows outside the rectangle
+                    asm volatile("; rectangle binds");
                     if ((mask & (1u << (16 + ly + 8 * h))) == 0u) py.x = qnan();
                     if ((mask & (1u << (16 + ly + 8 * h + 4))) == 0u) py.y = qnan();
                 }
-                const f2 dy = ea.y - py;
+                const f2 dy = yy - py;
                 // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217 (same op order)
-                f2 sg = (eb.x * dy) * dy;
+                f2 sg = (CC * dy) * dy;
                 sg = Adxdx + sg;
                 sg = 0.5f * sg;
                 sg = sg + Bdx * dy;
-                const bool need0 = (sg.x >= 0.0f) && (sg.x <= eb.z);
-                const bool need1 = (sg.y >= 0.0f) && (sg.y <= eb.z);
-                // (ballots of the individual compares: they stay in SGPRs, no VALU round trip)
-                const uint64_t m0 = __builtin_amdgcn_ballot_w64(sg.x >= 0.0f) &
-                                    __builtin_amdgcn_ballot_w64(sg.x <= eb.z);
-                const uint64_t m1 = __builtin_amdgcn_ballot_w64(sg.y >= 0.0f) &
-                                    __builtin_amdgcn_ballot_w64(sg.y <= eb.z);
+                // 0 <= sigma <= sigma_max as ONE unsigned compare of the bit patterns: negative
+                // values and NaNs have larger patterns than any sigma_max (< 6).  Only -0.0 would be
+                // misjudged; it needs a negative conic entry, which gs_pack_splats routes to the
+                // flagged path, where adding +0.0 turns -0.0 into +0.0 first.
+                if (rect_binds) sg = sg + (f2)(0.0f);
+                const bool need0 = __float_as_uint(sg.x) <= sbits;
+                const bool need1 = __float_as_uint(sg.y) <= sbits;
+                const uint64_t m0 = __builtin_amdgcn_ballot_w64(__float_as_uint(sg.x) <= sbits);
+                const uint64_t m1 = __builtin_amdgcn_ballot_w64(__float_as_uint(sg.y) <= sbits);
                 if ((m0 | m1) == 0ull) continue;
                 GS_STAT(2, 1);
                 GS_STAT(3, (m0 != 0ull) + (m1 != 0ull));
@@ -201,28 +221,32 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 if (m1 != 0ull) {
                     if (need1) vis.y = gs_exp<EXACT>(-sg.y, exp_tab);
                 }
-                // gsplat_cpu.cpp:220-236 for both pixels of the pair, without branches:
+                // gsplat_cpu.cpp:220-236 for both pixels of the pair:
                 //   alpha = min(0.999, opacity*vis); skip if alpha < 1/255; nextT = T*(1-alpha);
                 //   nextT <= 1e-4 -> pixel done (Gaussian not rendered); else composite.
-                f2 alpha = eb.y * vis;
+                // A skipped pixel is given alpha = 0, which composites exactly nothing
+                // (T*(1-0) == T, acc + 0*c == acc), so no per-pixel branch is needed.
+                f2 alpha = oo * vis;
                 alpha.x = __builtin_amdgcn_fmed3f(alpha.x, 0.0f, 0.999f);
                 alpha.y = __builtin_amdgcn_fmed3f(alpha.y, 0.0f, 0.999f);
-                const bool ok0 = alpha.x >= (1.0f / 255.0f), ok1 = alpha.y >= (1.0f / 255.0f);
-                const f2 nT = T2[h] * (1.0f - alpha);
-                const bool stop0 = nT.x <= 1e-4f, stop1 = nT.y <= 1e-4f;
-                const bool con0 = ok0 && !stop0, con1 = ok1 && !stop1;
-                f2 w = alpha * T2[h];
-                w.x = con0 ? w.x : 0.0f;
-                w.y = con1 ? w.y : 0.0f;
-                acc2[h][0] = acc2[h][0] + w * ec.x;
-                acc2[h][1] = acc2[h][1] + w * ec.y;
-                acc2[h][2] = acc2[h][2] + w * ec.z;
-                T2[h].x = con0 ? nT.x : T2[h].x;
-                T2[h].y = con1 ? nT.y : T2[h].y;
-                last[2 * h] = con0 ? (c0 + t) : last[2 * h];
-                last[2 * h + 1] = con1 ? (c0 + t) : last[2 * h + 1];
-                py2[h].x = (ok0 && stop0) ? qnan() : py2[h].x;
-                py2[h].y = (ok1 && stop1) ? qnan() : py2[h].y;
+                bool ok0 = alpha.x >= (1.0f / 255.0f), ok1 = alpha.y >= (1.0f / 255.0f);
+                alpha.x = ok0 ? alpha.x : 0.0f;
+                alpha.y = ok1 ? alpha.y : 0.0f;
+                f2 nT = T2[h] * (1.0f - alpha);
+                // a pixel saturating (at most once per pixel and frame): rare, scalar-branched
+                if ((__builtin_amdgcn_ballot_w64(nT.x <= 1e-4f) |
+                     __builtin_amdgcn_ballot_w64(nT.y <= 1e-4f)) != 0ull) {
+                    asm volatile("; pixel saturates");
+                    if (nT.x <= 1e-4f) { py2[h].x = qnan(); alpha.x = 0.0f; nT.x = T2[h].x; ok0 = false; }
+                    if (nT.y <= 1e-4f) { py2[h].y = qnan(); alpha.y = 0.0f; nT.y = T2[h].y; ok1 = false; }
+                }
+                const f2 w = alpha * T2[h];
+                acc2[h][0] = acc2[h][0] + w * rr;
+                acc2[h][1] = acc2[h][1] + w * gg;
+                acc2[h][2] = acc2[h][2] + w * bb;
+                T2[h] = nT;
+                last[2 * h] = ok0 ? (c0 + t) : last[2 * h];
+                last[2 * h + 1] = ok1 ? (c0 + t) : last[2 * h + 1];
             }
         }
     }
@@ -310,15 +334,15 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                      const float *__restrict__ v_out_alpha, float *__restrict__ gacc) {
     __shared__ Staged stage[kChunk];
-    __shared__ uint64_t exp_tab[32];
+    __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
     const int tile = xcd_swizzle(blockIdx.x, num_tiles);
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
-    if (EXACT && lane < 32) exp_tab[lane] = kExp2fTab[lane];
+    if (EXACT) load_exp_table(exp_tab, lane, 64);
 
     const int lx = lane & 15, ly = lane >> 4;
     const int px = tile_x0 + lx;
-    const float pxf = (float)px;
+    const f2 pxf2 = (f2)((float)px);
     // per pixel pair h (pixels k = 2h, 2h+1): row coordinate, transmittance being unwound,
     // T_final * (v_out_alpha - bg . v_out), running <colour buffer, v_out>, cotangent
     f2 py2[2], T2[2], TW2[2], bv2[2], vo2[2][3];
@@ -375,19 +399,22 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         if (hi - kChunk - lane >= range.x) fetch_entry(nxt, hi - kChunk - lane, ids, packed);
         const int n = min(kChunk, hi - range.x + 1);
         for (int t = 0; t < n; t++) {
-            const float4 ea = stage[t].a;
-            const float4 eb = stage[t].b;
-            const float4 ec = stage[t].c;
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.w));
-            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(eb.z));
+            const Staged &en = stage[t];
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(en.mask);
+            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(en.smax));
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
             const int e = hi - t;  // index of this entry in the sorted list
-            const float dx = ea.x - pxf;
+            const f2 dx2 = en.xx - pxf2;
+            const float dx = dx2.x;
             // sigma is evaluated from copies of dx / dy that are NaN outside the rectangle when
             // the rectangle binds (a NaN sigma fails both compares); the moments use the real ones
-            float dxs = dx;
-            if (rect_binds && (mask & colbit) == 0u) dxs = qnan();
-            const float Adx = ea.z * dxs, Bdx = ea.w * dxs, Adxdx = Adx * dxs;
+            f2 dxs = dx2;
+            if (rect_binds) {  // rare: keep it a scalar branch
+                asm volatile("; rectangle binds");
+                if ((mask & colbit) == 0u) dxs = (f2)(qnan());
+            }
+            const f2 Adx = en.AA * dxs, Adxdx = Adx * dxs, Bdx = en.BB * dxs;
+            const f2 yy = en.yy, CC = en.CC, oo = en.oo, crr = en.rr, cgg = en.gg, cbb = en.bb;
             f2 s0 = (f2)(0.0f), s1 = (f2)(0.0f), s2 = (f2)(0.0f);
             f2 gr = (f2)(0.0f), gg = (f2)(0.0f), gb = (f2)(0.0f);
             bool any = false;  // wave-uniform
@@ -398,25 +425,26 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 GS_STAT(9, 1);
                 f2 pys = py2[h];
                 if (rect_binds) {
+                    asm volatile("; rectangle binds");
                     if ((mask & (1u << (16 + ly + 8 * h))) == 0u) pys.x = qnan();
                     if ((mask & (1u << (16 + ly + 8 * h + 4))) == 0u) pys.y = qnan();
                 }
-                const f2 dys = ea.y - pys;
+                const f2 dys = yy - pys;
                 f2 dy = dys;
-                if (rect_binds) dy = ea.y - py2[h];
-                f2 sg = (eb.x * dys) * dys;
+                if (rect_binds) dy = yy - py2[h];
+                f2 sg = (CC * dys) * dys;
                 sg = Adxdx + sg;
                 sg = 0.5f * sg;
                 sg = sg + Bdx * dys;
-                const bool need0 = (e <= last[2 * h]) && (sg.x >= 0.0f) && (sg.x <= eb.z);
-                const bool need1 = (e <= last[2 * h + 1]) && (sg.y >= 0.0f) && (sg.y <= eb.z);
+                // 0 <= sigma <= sigma_max as one unsigned compare (see the forward kernel)
+                if (rect_binds) sg = sg + (f2)(0.0f);
+                const bool need0 = (e <= last[2 * h]) && (__float_as_uint(sg.x) <= sbits);
+                const bool need1 = (e <= last[2 * h + 1]) && (__float_as_uint(sg.y) <= sbits);
                 // (ballots of the individual compares: they stay in SGPRs, no VALU round trip)
                 const uint64_t m0 = __builtin_amdgcn_ballot_w64(e <= last[2 * h]) &
-                                    __builtin_amdgcn_ballot_w64(sg.x >= 0.0f) &
-                                    __builtin_amdgcn_ballot_w64(sg.x <= eb.z);
+                                    __builtin_amdgcn_ballot_w64(__float_as_uint(sg.x) <= sbits);
                 const uint64_t m1 = __builtin_amdgcn_ballot_w64(e <= last[2 * h + 1]) &
-                                    __builtin_amdgcn_ballot_w64(sg.y >= 0.0f) &
-                                    __builtin_amdgcn_ballot_w64(sg.y <= eb.z);
+                                    __builtin_amdgcn_ballot_w64(__float_as_uint(sg.y) <= sbits);
                 if ((m0 | m1) == 0ull) continue;
                 any = true;
                 GS_STAT(10, 1);
@@ -426,7 +454,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 f2 vis;
                 vis.x = need0 ? __expf(-sg.x) : 0.0f;
                 vis.y = need1 ? __expf(-sg.y) : 0.0f;
-                f2 alpha = eb.y * vis;
+                f2 alpha = oo * vis;
                 if (EXACT) {
                     // same >= 1/255 decision as the forward: redo the exponential exactly where
                     // the fast one cannot decide (|rel. distance to the threshold| < 2.5e-6)
@@ -437,8 +465,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                         (m0 & __builtin_amdgcn_ballot_w64(fabsf(alpha.x - thr) < 1.0e-8f)) |
                         (m1 & __builtin_amdgcn_ballot_w64(fabsf(alpha.y - thr) < 1.0e-8f));
                     if (ma != 0ull) {
-                        if (amb0) { vis.x = expf_glibc(-sg.x, exp_tab); alpha.x = eb.y * vis.x; }
-                        if (amb1) { vis.y = expf_glibc(-sg.y, exp_tab); alpha.y = eb.y * vis.y; }
+                        if (amb0) { vis.x = expf_glibc(-sg.x, exp_tab); alpha.x = oo.x * vis.x; }
+                        if (amb1) { vis.y = expf_glibc(-sg.y, exp_tab); alpha.y = oo.x * vis.y; }
                     }
                 }
                 const bool ok0 = alpha.x >= (1.0f / 255.0f);
@@ -460,9 +488,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 gg = __builtin_elementwise_fma(fac, vo2[h][1], gg);
                 gb = __builtin_elementwise_fma(fac, vo2[h][2], gb);
                 // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
-                f2 cv = ec.x * vo2[h][0];
-                cv = __builtin_elementwise_fma((f2)(ec.y), vo2[h][1], cv);
-                cv = __builtin_elementwise_fma((f2)(ec.z), vo2[h][2], cv);
+                f2 cv = crr * vo2[h][0];
+                cv = __builtin_elementwise_fma(cgg, vo2[h][1], cv);
+                cv = __builtin_elementwise_fma(cbb, vo2[h][2], cv);
                 const f2 v_alpha = __builtin_elementwise_fma(T2[h], cv, ra * (TW2[h] - bv2[h]));
                 bv2[h] = __builtin_elementwise_fma(fac, cv, bv2[h]);
                 // u = vis * v_alpha; v_sigma = -opacity * u (applied once per entry below)
@@ -476,13 +504,13 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             GS_STAT(11, 1);
             // per-lane conversion of the moments to the nine gradient components
             const float S0 = s0.x + s0.y, S1 = s1.x + s1.y, S2 = s2.x + s2.y;
-            const float mo = -eb.y;
+            const float mo = -oo.x;
             const float vs0 = mo * S0;         // sum v_sigma
             const float vs1 = mo * S1;         // sum v_sigma * dy
             const float vs2 = mo * S2;         // sum v_sigma * dy^2
             const float mx = dx * vs0;         // sum v_sigma * dx
-            const float g_x = fmaf(ea.z, mx, ea.w * vs1);  // v_sigma * (A dx + B dy)
-            const float g_y = fmaf(ea.w, mx, eb.x * vs1);  // v_sigma * (B dx + C dy)
+            const float g_x = fmaf(en.AA.x, mx, en.BB.x * vs1);  // v_sigma * (A dx + B dy)
+            const float g_y = fmaf(en.BB.x, mx, CC.x * vs1);     // v_sigma * (B dx + C dy)
             const float hdx = 0.5f * dx;
             const float g_A = hdx * mx;        // 0.5 * v_sigma * dx^2
             const float g_B = hdx * vs1;       // 0.5 * v_sigma * dx * dy   (gsplat_cpu.cpp:361-363)
@@ -490,8 +518,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             const float r = reduce9(g_x, g_y, g_A, g_B, g_C, gr.x + gr.y, gg.x + gg.y,
                                     gb.x + gb.y, S0, lane);
             if (role >= 0) {
-                const int g = __float_as_int(ec.w);
-                atomicAdd(wbase + (size_t)g * kGradRec, r);
+                atomicAdd(wbase + (size_t)en.id * kGradRec, r);
             }
         }
     }
@@ -522,8 +549,8 @@ k_unpack_grads(int N, const float4 *__restrict__ gacc, float *__restrict__ v_xy,
 template <bool EXACT>
 __global__ void __launch_bounds__(256) k_debug_expf(int64_t n, const float *__restrict__ x,
                                                     float *__restrict__ y) {
-    __shared__ uint64_t exp_tab[32];
-    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2fTab[threadIdx.x];
+    __shared__ uint64_t exp_tab[kExpTabLds];
+    load_exp_table(exp_tab, threadIdx.x, 256);
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -584,11 +611,11 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL(gs::k_rasterize_forward<false>, dim3(tiles), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], out_img, final_Ts, final_idx);
     else
-        hipLaunchKernelGGL(gs::k_rasterize_forward<true>, dim3(tiles), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], out_img, final_Ts, final_idx);
     GS_LAUNCH_CHECK();
