@@ -194,6 +194,11 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
  * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */
 int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags, gs_stream_t stream);
 
+/* Measurement hook: records the two hipEvent_t (passed as void*) on the kernel's stream right
+ * before and right after the NEXT k_rasterize_forward / k_rasterize_backward launch made by the
+ * calling thread (the compositing kernel alone), then disarms itself. */
+int gs_debug_time_next_kernel(void *event_start, void *event_stop);
+
 /* Test hook: the nine-value transposing wave reduction of the backward kernel.
  *   in [blocks, 9, 64] (value i of lane l at in[b][i][l])  ->  out[blocks, 9] = sums over lanes. */
 int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
-    "gs_debug_reduce9",
+    "gs_debug_reduce9", "gs_debug_time_next_kernel",
 ]
 
 
@@ -258,3 +258,11 @@ def debug_reduce9(x):
     y = torch.empty((blocks, 9), device=x.device, dtype=torch.float32)
     _check(lib().gs_debug_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_reduce9")
     return y
+
+
+def time_next_kernel(ev_start, ev_stop):
+    """Arm the measurement hook with two torch.cuda.Event(enable_timing=True) objects that have been
+    recorded at least once (so that their HIP handles exist)."""
+    _check(lib().gs_debug_time_next_kernel(C.c_void_p(ev_start.cuda_event),
+                                           C.c_void_p(ev_stop.cuda_event)),
+           "gs_debug_time_next_kernel")

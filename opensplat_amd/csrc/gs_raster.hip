@@ -587,6 +587,26 @@ extern "C" int gs_debug_stats(unsigned long long *host16, int reset) {
 }
 #endif
 
+// Test/measurement hook: HIP events recorded immediately before and after the NEXT compositing
+// kernel launched by this thread (k_rasterize_forward or k_rasterize_backward alone, without the
+// memset / record-splitting kernels around it) — bench.py's roofline.achieved uses it.
+namespace gs {
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static inline void ev_before(hipStream_t s) {
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
+}
+static inline void ev_after(hipStream_t s) {
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
+    g_ev_start = g_ev_stop = nullptr;
+}
+}  // namespace gs
+
+extern "C" int gs_debug_time_next_kernel(void *event_start, void *event_stop) {
+    gs::g_ev_start = (hipEvent_t)event_start;
+    gs::g_ev_stop = (hipEvent_t)event_stop;
+    return GS_OK;
+}
+
 extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream) {
     if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
     if (blocks == 0) return GS_OK;
@@ -610,6 +630,7 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
@@ -618,6 +639,7 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
         hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], out_img, final_Ts, final_idx);
+    gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
@@ -648,6 +670,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     float *gacc = static_cast<float *>(workspace);
     GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
+    gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
@@ -658,6 +681,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
                            gacc);
+    gs::ev_after(s);
     GS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
                        reinterpret_cast<const float4 *>(gacc), v_xy, v_conic, v_colors, v_opacity);

@@ -107,6 +107,14 @@ def main():
             fmt(valu, "%.3g"), fmt(busy, "%.3f"), fmt(d.get("SQ_INSTS_LDS"), "%.3g"),
             fmt(wait, "%.3f")))
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+    # per-launch HBM traffic (bytes) of the gs:: kernels, for bench.py's roofline.traffic
+    traffic = {}
+    for name, d in out.items():
+        m = re.search(r"gs::(k_\w+)", name)
+        if m and "hbm_read_bytes_corrected" in d and "hbm_write_bytes" in d:
+            traffic[m.group(1)] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+    traffic["_source"] = f"profiles/{tag}_pmc.json (FETCH_SIZE x 2 KiB-units corrected + WRITE_SIZE)"
+    (dst / "traffic.json").write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
     print("\n".join(lines))
 
 
