@@ -15,10 +15,11 @@
 //   3. k_scatter       — one lane per Gaussian claims a slot in each of its tiles' segments
 //                        (returning atomics on the cursors) and writes the 64-bit key
 //                        (order-preserving depth bits << 32 | Gaussian id);
-//   4. k_sort_tiles    — one workgroup per tile sorts its segment by that key in LDS (bitonic
-//                        network on 64-bit keys) and writes the Gaussian ids; segments too long
-//                        for 64 KiB of LDS are sorted in place in global memory by the same
-//                        network.
+//   4. k_bucket_sort_* — one wave (or workgroup) per tile orders its segment by that key on chip:
+//                        a counting sort on the leading bits of (depth - nearest depth of the
+//                        tile) puts almost every key in its own bucket, a lane finishes the few
+//                        buckets with several keys; heavily tied depths fall back to a bitonic
+//                        network, segments too long for LDS are sorted in place in global memory.
 // The key is unique per (depth, id), so the result does not depend on the order in which step 3's
 // atomics land: lists are depth ordered with ties in Gaussian-index order —
 // deterministic, and identical to a stable sort by depth.  Traffic: 8 B written + read per
@@ -121,6 +122,10 @@ __device__ __forceinline__ TileRect tile_rect(const float4 *__restrict__ packed,
 // by their own lane; a rectangle with more than kLaneTiles tiles is walked by the whole wave
 // (one lane looping over thousands of tiles would stall the other 63).
 constexpr int kLaneTiles = 16;
+// threads per workgroup of the LDS-privatised count / scatter kernels: one workgroup per CU (its
+// LDS table may take most of the CU's 160 KiB), so the workgroup must bring enough waves by itself
+// to cover the latency of the record loads (with 256 threads the kernels were latency-bound)
+constexpr int kPersistentThreads = 1024;
 // f(tile, pa, pb): (pa, pb) is the owning lane's payload (broadcast when the wave walks it).
 template <typename F>
 __device__ __forceinline__ void for_each_tile(const TileRect &r, bool valid, int tiles_x,
@@ -163,7 +168,7 @@ k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
                   [&](int tile, uint32_t, int) { atomicAdd(&counts[tile], 1); });
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
               int32_t *__restrict__ counts) {
     extern __shared__ int32_t h[];
@@ -186,17 +191,28 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
 }
 
 // ---- 2. scan -----------------------------------------------------------------------------------
-// One 1024-thread workgroup; tiles <= 2^17 or so (8K x 8K image = 262144 tiles still fits: each
-// thread owns a contiguous slice).
+// One 1024-thread workgroup.  The counters are first copied to LDS with coalesced loads (up to
+// 36 864 tiles = 144 KiB), each thread then scans a contiguous slice there and the [start, end)
+// pairs are written back coalesced; larger images scan straight from global memory.
+// LDS index skew: one pad word per 32 so that threads walking contiguous 32-word-aligned slices hit
+// different banks
+__device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
+
 __global__ void __launch_bounds__(1024)
-k_scan_tiles(int tiles, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
              int32_t *__restrict__ total_dev) {
+    extern __shared__ int32_t c_lds[];
     __shared__ int32_t part[1024];
     const int t = threadIdx.x;
     const int per = (tiles + 1023) / 1024;
     const int lo = min(t * per, tiles), hi = min(lo + per, tiles);
+    if (use_lds) {
+        for (int i = t; i < tiles; i += 1024) c_lds[skew(i)] = counts[i];
+        __syncthreads();
+    }
     int32_t sum = 0;
-    for (int i = lo; i < hi; i++) sum += counts[i];
+    if (use_lds) for (int i = lo; i < hi; i++) sum += c_lds[skew(i)];
+    else for (int i = lo; i < hi; i++) sum += counts[i];
     part[t] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partials
@@ -207,10 +223,25 @@ k_scan_tiles(int tiles, const int32_t *__restrict__ counts, int2 *__restrict__ b
         __syncthreads();
     }
     int32_t run = part[t] - sum;  // exclusive prefix of this thread's slice
-    for (int i = lo; i < hi; i++) {
-        const int32_t c = counts[i];
-        bins[i] = make_int2(run, run + c);
-        run += c;
+    if (use_lds) {
+        for (int i = lo; i < hi; i++) {  // counts -> exclusive starts, in place
+            const int32_t c = c_lds[skew(i)];
+            c_lds[skew(i)] = run;
+            run += c;
+        }
+        __syncthreads();
+        const int32_t total = part[1023];
+        for (int i = t; i < tiles; i += 1024) {
+            const int32_t st = c_lds[skew(i)];
+            const int32_t en = (i + 1 < tiles) ? c_lds[skew(i + 1)] : total;
+            bins[i] = make_int2(st, en);
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            const int32_t c = counts[i];
+            bins[i] = make_int2(run, run + c);
+            run += c;
+        }
     }
     if (t == 1023) *total_dev = part[1023];
 }
@@ -243,7 +274,7 @@ k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict_
 // flush reserves a contiguous range per (workgroup, tile) with ONE returning global atomic and
 // turns the LDS counter into the range's start; pass B walks the same Gaussians again and takes
 // slots from the LDS cursors.  Slot order inside a tile is arbitrary — k_sort_tiles fixes it.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kPersistentThreads)
 k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
           const float *__restrict__ depths, const int2 *__restrict__ bins,
           int32_t *__restrict__ fill, uint64_t *__restrict__ keys) {
@@ -330,61 +361,258 @@ struct GlobalKeys {
     }
 };
 
-// Sorts the tiles whose segment length n satisfies lo_n < n <= hi_n (other tiles return at once),
-// so that the same code is launched for three size classes with different LDS footprints.
-template <int CAP, int NT>  // CAP = LDS capacity in keys (0 -> sort in place in global memory)
+// ---- 4b. bucket sort ---------------------------------------------------------------------------
+// The keys of one tile are (nearly) uniformly spread between the tile's nearest and farthest
+// Gaussian, so a counting sort on the leading bits of (depth key - min) puts almost every key in
+// its own bucket: O(n) LDS work instead of the bitonic network's O(n log^2 n).
+//   1. min / max of the 32-bit depth keys (wave reductions, combined through LDS);
+//   2. bucket = (depth key - min) >> shift  (shift chosen so that bucket < B; monotone in the key);
+//      LDS histogram, exclusive scan, scatter of the 64-bit keys through LDS cursors;
+//   3. every bucket holding more than one key is put in order by a single lane (insertion sort on
+//      the full (depth, id) key).  If some bucket is longer than kMaxBucket keys (many equal
+//      depths — pathological) the whole segment is re-sorted with the bitonic network instead.
+// CAP: segment capacity in keys; B: buckets; NT: threads.  LDS: 8*CAP + 4*B (+ a few words).
+constexpr int kMaxBucket = 24;
+
+template <int NT>
+__device__ __forceinline__ void block_minmax(uint32_t &mn, uint32_t &mx, uint32_t *scratch) {
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+    }
+    if (NT > 64) {
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { scratch[2 * w] = mn; scratch[2 * w + 1] = mx; }
+        __syncthreads();
+        for (int i = 0; i < NT / 64; i++) { mn = min(mn, scratch[2 * i]); mx = max(mx, scratch[2 * i + 1]); }
+        __syncthreads();
+    }
+}
+
+template <int CAP, int B, int NT>
 __global__ void __launch_bounds__(NT)
-k_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
-             uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
-    __shared__ uint64_t lds[CAP > 0 ? CAP : 1];
+k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
+                    uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *out = reinterpret_cast<uint64_t *>(smem);           // CAP keys
+    int32_t *cnt = reinterpret_cast<int32_t *>(out + CAP);         // B counters / cursors
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words
+    const int2 range = bins[blockIdx.x];
+    const int start = range.x;
+    const int n = min(range.y, capacity) - start;
+    if (n <= lo_n) return;
+    const int tid = threadIdx.x;
+    if (n > hi_n) {  // longer than the LDS capacity: bitonic network in place in global memory
+        int P = 2;
+        while (P < n) P <<= 1;
+        GlobalKeys m{keys + start, n};
+        bitonic_sort(m, P, tid, NT);
+        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+        return;
+    }
+    const uint64_t *src = keys + start;
+    // 1. range of the depth keys
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (int i = tid; i < n; i += NT) {
+        const uint32_t d = (uint32_t)(src[i] >> 32);
+        mn = min(mn, d);
+        mx = max(mx, d);
+    }
+    block_minmax<NT>(mn, mx, scratch);
+    const uint32_t span = mx - mn;
+    int shift = 0;
+    while ((span >> shift) >= (uint32_t)B) shift++;
+    // 2. histogram
+    for (int i = tid; i < B; i += NT) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const uint32_t d = (uint32_t)(src[i] >> 32);
+        atomicAdd(&cnt[(d - mn) >> shift], 1);
+    }
+    __syncthreads();
+    //    exclusive scan of the B counters: each thread owns B/NT consecutive ones
+    constexpr int PER = B / NT;
+    int32_t local[PER];
+    int32_t sum = 0, longest = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        local[j] = cnt[tid * PER + j];
+        longest = max(longest, local[j]);
+        sum += local[j];
+    }
+    int32_t incl = sum;  // inclusive scan across the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t v = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += v;
+    }
+    int32_t wave_base = 0;
+    if (NT > 64) {
+        int32_t *wsum = reinterpret_cast<int32_t *>(scratch + 2 * (NT / 64));
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        for (int w = 0; w < (tid >> 6); w++) wave_base += wsum[w];
+    }
+    int32_t run = wave_base + incl - sum;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        cnt[tid * PER + j] = run;  // becomes the bucket's cursor
+        run += local[j];
+    }
+    // pathological segment?  (wave-level OR, then across waves through LDS)
+    uint32_t *flag = scratch + 3 * (NT / 64);
+    if (tid == 0) *flag = 0u;
+    __syncthreads();
+    if (longest > kMaxBucket) atomicOr(flag, 1u);
+    // 3. scatter into bucket order
+    for (int i = tid; i < n; i += NT) {
+        const uint64_t k = src[i];
+        const uint32_t d = (uint32_t)(k >> 32);
+        const int pos = atomicAdd(&cnt[(d - mn) >> shift], 1);
+        out[pos] = k;
+    }
+    __syncthreads();
+    if (*flag) {
+        // many equal / clustered depths: bitonic network on the LDS copy (padding keys sort last)
+        int P = 2;
+        while (P < n) P <<= 1;
+        for (int i = n + tid; i < P && i < CAP; i += NT) out[i] = ~0ull;
+        __syncthreads();
+        if (P <= CAP) {
+            LdsKeys m{out};
+            bitonic_sort(m, P, tid, NT);
+        } else {  // n > CAP/2 and not a power of two: virtual padding beyond CAP is never touched
+            struct Padded {
+                uint64_t *p; int n;
+                __device__ __forceinline__ uint64_t get(int i) const { return i < n ? p[i] : ~0ull; }
+                __device__ __forceinline__ void set(int i, uint64_t v) { if (i < n) p[i] = v; }
+            } m{out, n};
+            bitonic_sort(m, P, tid, NT);
+        }
+    } else {
+        // order inside buckets: cursor[b] is now the END of bucket b, the end of b-1 its start
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int b = tid * PER + j;
+            const int e = cnt[b];
+            const int s0 = e - local[j];
+            for (int i = s0 + 1; i < e; i++) {  // insertion sort (local[j] <= kMaxBucket)
+                const uint64_t k = out[i];
+                int q = i - 1;
+                while (q >= s0 && out[q] > k) {
+                    out[q + 1] = out[q];
+                    q--;
+                }
+                out[q + 1] = k;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
+}
+
+// Single-wave variant for the common short segments (n <= 64*PL keys): the keys are loaded ONCE
+// into registers (PL per lane), bucket b is owned by lane b % 64 (conflict-free LDS access), the
+// exclusive scan is B/64 DPP wave scans.  LDS: 8*64*PL + 4*B bytes (6 KiB for PL = 8, B = 512),
+// so that many tiles are resident per CU and their global-memory round trips overlap.
+__device__ __forceinline__ int wave_inclusive_scan_i(int v) {
+    // Hillis-Steele inside each 16-lane row (row_shr with zero fill), then the two row carries
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+template <int PL, int B>
+__global__ void __launch_bounds__(64)
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
+                   const uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
+    constexpr int CAP = 64 * PL, PER = B / 64;
+    __shared__ uint64_t out[CAP];
+    __shared__ int32_t cnt[B];
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
     if (n <= lo_n || n > hi_n) return;
-    const int tid = threadIdx.x;
-    if (n == 1) {
-        if (tid == 0) ids_sorted[start] = (int32_t)(uint32_t)keys[start];
-        return;
+    const int lane = threadIdx.x;
+    const uint64_t *src = keys + start;
+    uint64_t kk[PL];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        const int i = j * 64 + lane;
+        kk[j] = (i < n) ? src[i] : ~0ull;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(kk[j] >> 32);
+            mn = min(mn, d);
+            mx = max(mx, d);
+        }
     }
-    int P = 2;
-    while (P < n) P <<= 1;
-    if (CAP > 0) {
-        for (int i = tid; i < P; i += NT) lds[i] = (i < n) ? keys[start + i] : ~0ull;
-        __syncthreads();
-        LdsKeys m{lds};
-        bitonic_sort(m, P, tid, NT);
-        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)lds[i];
-    } else {
-        GlobalKeys m{keys + start, n};
-        __syncthreads();
-        bitonic_sort(m, P, tid, NT);
-        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     }
-}
-
-// All segments longer than 512 keys: up to 8192 in 64 KiB of LDS, longer ones in place in global
-// memory (one launch for both rare classes).
-__global__ void __launch_bounds__(256)
-k_sort_tiles_long(int32_t capacity, const int2 *__restrict__ bins, uint64_t *__restrict__ keys,
-                  int32_t *__restrict__ ids_sorted) {
-    __shared__ uint64_t lds[8192];
-    const int2 range = bins[blockIdx.x];
-    const int start = range.x;
-    const int n = min(range.y, capacity) - start;
-    if (n <= 512) return;
-    const int tid = threadIdx.x;
-    int P = 1024;
-    while (P < n) P <<= 1;
-    if (n <= 8192) {
-        for (int i = tid; i < P; i += 256) lds[i] = (i < n) ? keys[start + i] : ~0ull;
+    const uint32_t span = mx - mn;
+    int shift = 0;
+    while ((span >> shift) >= (uint32_t)B) shift++;
+#pragma unroll
+    for (int j = 0; j < PER; j++) cnt[j * 64 + lane] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PL; j++)
+        if (j * 64 + lane < n) atomicAdd(&cnt[((uint32_t)(kk[j] >> 32) - mn) >> shift], 1);
+    __syncthreads();
+    // exclusive scan, bucket b = j*64 + lane
+    int32_t local[PER];
+    int32_t base = 0, longest = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        local[j] = cnt[j * 64 + lane];
+        longest = max(longest, local[j]);
+        const int32_t incl = wave_inclusive_scan_i(local[j]);
+        cnt[j * 64 + lane] = base + incl - local[j];
+        base += __builtin_amdgcn_readlane(incl, 63);
+    }
+    const bool pathological = __builtin_amdgcn_ballot_w64(longest > kMaxBucket) != 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PL; j++)
+        if (j * 64 + lane < n) {
+            const int pos = atomicAdd(&cnt[((uint32_t)(kk[j] >> 32) - mn) >> shift], 1);
+            out[pos] = kk[j];
+        }
+    __syncthreads();
+    if (pathological) {
+        int P = 2;
+        while (P < n) P <<= 1;  // P <= CAP because n <= CAP and CAP is a power of two
+        for (int i = n + lane; i < P; i += 64) out[i] = ~0ull;
         __syncthreads();
-        LdsKeys m{lds};
-        bitonic_sort(m, P, tid, 256);
-        for (int i = tid; i < n; i += 256) ids_sorted[start + i] = (int32_t)(uint32_t)lds[i];
+        LdsKeys m{out};
+        bitonic_sort(m, P, lane, 64);
     } else {
-        GlobalKeys m{keys + start, n};
-        bitonic_sort(m, P, tid, 256);
-        for (int i = tid; i < n; i += 256) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (local[j] < 2) continue;
+            const int e = cnt[j * 64 + lane];  // cursor == end of the bucket
+            const int s0 = e - local[j];
+            for (int i = s0 + 1; i < e; i++) {  // insertion sort (local[j] <= kMaxBucket)
+                const uint64_t k = out[i];
+                int q = i - 1;
+                while (q >= s0 && out[q] > k) {
+                    out[q + 1] = out[q];
+                    q--;
+                }
+                out[q + 1] = k;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        const int i = j * 64 + lane;
+        if (i < n) ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
     }
 }
 
@@ -394,7 +622,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // persistent workgroup per CU is enough to saturate the LDS atomic units; fewer for small N.
 constexpr size_t kMaxTileLds = 144 * 1024;
 static int persistent_blocks(int N) {
-    int b = (N + 255) / 256;
+    int b = (N + kPersistentThreads - 1) / kPersistentThreads;
     return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 
@@ -462,7 +690,7 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
             const int blocks = gs::persistent_blocks(N);
-            hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(256), lds, s, N, tiles, tiles_x,
+            hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
                                reinterpret_cast<const float4 *>(packed), counts);
         } else {
             hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
@@ -470,8 +698,16 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
         }
         GS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, counts,
-                       reinterpret_cast<int2 *>(tile_bins), total_dev);
+    {
+        const size_t lds = sizeof(int32_t) * ((size_t)tiles + tiles / 32 + 1);
+        const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
+        if (use_lds)
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scan_tiles),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)gs::kMaxTileLds));
+        hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
+                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev);
+    }
     GS_LAUNCH_CHECK();
     if (num_isects_host)
         GS_HIP_CHECK(hipMemcpyAsync(num_isects_host, total_dev, sizeof(int32_t),
@@ -506,7 +742,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)gs::kMaxTileLds));
         const int blocks = gs::persistent_blocks(N);
-        hipLaunchKernelGGL(gs::k_scatter, dim3(blocks), dim3(256), lds, s, N, tiles, tiles_x, capacity,
+        hipLaunchKernelGGL(gs::k_scatter, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x, capacity,
                            reinterpret_cast<const float4 *>(packed), depths, bins, fill, keys);
     } else {
         hipLaunchKernelGGL(gs::k_scatter_global, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
@@ -514,13 +750,25 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                            keys);
     }
     GS_LAUNCH_CHECK();
-    // <= 512 keys: one wave per tile (no cross-wave barriers); longer segments: 256 threads
-    hipLaunchKernelGGL((gs::k_sort_tiles<512, 64>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+    // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
+    // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
+    // longer: in place in global memory
+    hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
                        bins, keys, gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gs::k_sort_tiles_long, dim3(tiles), dim3(256), 0, s, capacity, bins, keys,
-                       gaussian_ids_sorted);
+    hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+                       capacity, bins, keys, gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
+    {
+        constexpr int CAP = 8192, B = 4096, NT = 256;
+        const size_t lds = 8 * CAP + 4 * B + 64;
+        GS_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
+                           CAP, capacity, bins, keys, gaussian_ids_sorted);
+        GS_LAUNCH_CHECK();
+    }
     return GS_OK;
 }
 

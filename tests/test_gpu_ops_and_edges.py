@@ -406,3 +406,25 @@ def test_large_images_bin_through_lds_and_global_counters(W, H, restated):
                          np_(out["cov2d"]), np_(out["depths"]))
     assert np.array_equal(np_(out["img"]), f["img"])
     assert np.array_equal(np_(out["final_Ts"]), f["final_Ts"])
+
+
+@pytest.mark.parametrize("N", [900, 6000])
+def test_equal_depths_fall_back_to_the_network_sort(N):
+    """Heavily tied depths defeat the per-tile bucket sort (one bucket holds most keys): the
+    fallback must still give (depth, Gaussian index) order — what a stable sort by depth gives."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(N, 40, 24, K=0, seed=41, znear=1.0, zfar=100.0, sigma_px=(3.0, 6.0))
+    out = hip_pipeline(s, backward=False)
+    d = np.round(np_(out["depths"]), 0).astype(np.float32)          # ~9 distinct values
+    b = cabi.bin_and_sort(s.W, s.H, out["xys"], to_dev(d), out["radii"], out["conics"],
+                          out["colors"], to_dev(s.opacities.reshape(-1)), out["cov2d"])
+    torch.cuda.synchronize()
+    bins, ids = np_(b.tile_bins), np_(b.gaussian_ids_sorted)
+    assert (bins[:, 1] - bins[:, 0]).max() > 24
+    for a, e in bins:
+        seg = ids[a:e]
+        want = np.array(sorted(seg.tolist(), key=lambda g: (d[g], g)), dtype=seg.dtype)
+        assert np.array_equal(seg, want)
