@@ -203,8 +203,11 @@ def main():
 
     from opensplat_amd import cabi, dist, scenes
 
-    rank, world, local = dist.init_from_env("nccl")
+    # one rank per GPU over RCCL ("nccl"); GSPLAT_DIST_BACKEND=gloo lets the multi-rank code path be
+    # exercised on a box with fewer GPUs than ranks (ranks then share devices round-robin)
+    rank, world, local = dist.init_from_env(os.environ.get("GSPLAT_DIST_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cabi.lib()  # fail loudly if the HIP library is missing

@@ -150,6 +150,37 @@ k_sh_backward(int N, int nb, const float *__restrict__ dirs, const float *__rest
     }
 }
 
+// K = 16 (degree 3, the configuration OpenSplat trains at): FOUR lanes per Gaussian, each loads its
+// 48 contiguous bytes (bases 4q..4q+3 x rgb) as three float4 — a wave covers 16 Gaussians = 3 KiB of
+// contiguous coefficients, every fetched byte is used, no LDS staging — and the four partial dot
+// products are combined with two DPP quad permutes.
+__global__ void __launch_bounds__(256)
+k_sh_forward16_quad(int N, int nb, const float *__restrict__ dirs,
+                    const float *__restrict__ coeffs, float *__restrict__ colors) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = t >> 2;
+    const int q = (int)(t & 3);
+    if (g >= N) return;  // whole quads drop out together
+    float r[25];
+    sh_basis(nb, dirs[3 * g], dirs[3 * g + 1], dirs[3 * g + 2], r);
+    const float4 *p = reinterpret_cast<const float4 *>(coeffs + g * 48 + q * 12);
+    const float4 a = p[0], b = p[1], c = p[2];
+    const float r0 = q == 0 ? r[0] : q == 1 ? r[4] : q == 2 ? r[8] : r[12];
+    const float r1 = q == 0 ? r[1] : q == 1 ? r[5] : q == 2 ? r[9] : r[13];
+    const float r2 = q == 0 ? r[2] : q == 1 ? r[6] : q == 2 ? r[10] : r[14];
+    const float r3 = q == 0 ? r[3] : q == 1 ? r[7] : q == 2 ? r[11] : r[15];
+    float c0 = r0 * a.x + r1 * a.w + r2 * b.z + r3 * c.y;
+    float c1 = r0 * a.y + r1 * b.x + r2 * b.w + r3 * c.z;
+    float c2 = r0 * a.z + r1 * b.y + r2 * c.x + r3 * c.w;
+    c0 += dpp_f<0xB1>(c0); c1 += dpp_f<0xB1>(c1); c2 += dpp_f<0xB1>(c2);  // quad_perm [1,0,3,2]
+    c0 += dpp_f<0x4E>(c0); c1 += dpp_f<0x4E>(c1); c2 += dpp_f<0x4E>(c2);  // quad_perm [2,3,0,1]
+    if (q == 0) {
+        colors[3 * g + 0] = c0;
+        colors[3 * g + 1] = c1;
+        colors[3 * g + 2] = c2;
+    }
+}
+
 template <int K>
 static int launch_fwd(int N, int nb, const float *dirs, const float *coeffs, float *colors,
                       hipStream_t s) {
@@ -202,7 +233,13 @@ extern "C" int gs_sh_forward(int N, int K, int degrees_to_use, const float *dirs
     case 1: return gs::launch_fwd<1>(N, nb, dirs, coeffs, colors, s);
     case 4: return gs::launch_fwd<4>(N, nb, dirs, coeffs, colors, s);
     case 9: return gs::launch_fwd<9>(N, nb, dirs, coeffs, colors, s);
-    case 16: return gs::launch_fwd<16>(N, nb, dirs, coeffs, colors, s);
+    case 16: {
+        const int64_t threads = (int64_t)N * 4;
+        hipLaunchKernelGGL(gs::k_sh_forward16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+                           0, s, N, nb, dirs, coeffs, colors);
+        GS_LAUNCH_CHECK();
+        return GS_OK;
+    }
     default: return gs::launch_fwd<25>(N, nb, dirs, coeffs, colors, s);
     }
 }

@@ -65,7 +65,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         be = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         if be == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=be, rank=rank, world_size=world)
     return rank, world, local
 
