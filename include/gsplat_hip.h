@@ -54,11 +54,23 @@ typedef struct GsCamera {
     int32_t img_width, img_height;
     float clip_thresh; /* near-plane cull, default 0.01 (project_gaussians.hpp:28) */
     float glob_scale;  /* 1.0 everywhere in OpenSplat                        */
+    uint32_t flags;    /* GS_CAM_* ; 0 = the reference operator's semantics    */
 } GsCamera;
+
+/* GsCamera.flags.  "Fused glue" (SURVEY.md §8 row f1): lets the kernels absorb the element-wise
+ * torch ops Model::forward wraps around the three operators (model.cpp:114-225). */
+#define GS_CAM_LOG_SCALES 1u /* `scales` holds log-scales: exp() applied inside, v_scales is the  \
+                                gradient w.r.t. the log-scales (model.cpp:125,148 torch::exp)    */
 
 /* Flags for the compositing kernels. */
 #define GS_FLAG_FAST_EXP 1u /* use the hardware v_exp_f32 path instead of the glibc-bit-exact expf; \
                                contributor sets may then differ from the CPU oracle at thresholds */
+/* fused glue (row f1), all optional: */
+#define GS_FLAG_LOGIT_OPACITY 2u /* gs_pack_splats: `opacities` are logits, sigmoid applied inside   \
+                                    (model.cpp:200,215); gs_rasterize_backward: v_opacity is then  \
+                                    the gradient w.r.t. the logit                                  */
+#define GS_FLAG_CLAMP_IMAGE 4u   /* gs_rasterize_forward also writes min(image, 1) (model.cpp:222);  \
+                                    gs_rasterize_backward masks v_out where the raw image > 1     */
 
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
@@ -104,6 +116,21 @@ int gs_sh_forward(int N, int K, int degrees_to_use, const float *dirs, const flo
 int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const float *v_colors,
                    float *v_coeffs, gs_stream_t stream);
 
+/* Fused-glue variants (row f1) of the two calls above, replacing torch::cat (model.cpp:114), the
+ * view-direction computation (model.cpp:176-177) and clamp_min(rgb + 0.5, 0) (model.cpp:192):
+ *   fwd: means[N,3], cam_pos (host float[3]: camera centre in world space), features_dc[N,3],
+ *        features_rest[N,K-1,3] (NULL iff K == 1) -> colors[N,3] = max(SH(dir) + 0.5, 0) and
+ *        rgb_raw[N,3] = SH(dir), dir = normalize(means - cam_pos)
+ *   bwd: v_colors[N,3] (gradient w.r.t. the clamped colours) + rgb_raw -> v_dc[N,3],
+ *        v_rest[N,K-1,3]; no gradient to the means (the reference detaches them, model.cpp:176). */
+int gs_sh_forward_fused(int N, int K, int degrees_to_use, const float *means,
+                        const float *cam_pos /*host[3]*/, const float *features_dc,
+                        const float *features_rest, float *colors, float *rgb_raw,
+                        gs_stream_t stream);
+int gs_sh_backward_fused(int N, int K, int degrees_to_use, const float *means,
+                         const float *cam_pos /*host[3]*/, const float *rgb_raw,
+                         const float *v_colors, float *v_dc, float *v_rest, gs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Tile binning + sort.  Together these replace cumsum + map_gaussian_to_intersects_tensor +
  * torch::sort/gather + get_tile_bin_edges_tensor (bindings.h:96-109,
@@ -124,7 +151,7 @@ int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const fl
 int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
                    const float *conics, const float *colors, const float *opacities,
                    const float *cov2d /*nullable*/, float *packed, int32_t *tiles_hit,
-                   gs_stream_t stream);
+                   uint32_t flags /* GS_FLAG_LOGIT_OPACITY */, gs_stream_t stream);
 
 /* Workspace (bytes, 256-byte aligned base) sufficient for gs_bin_scan (any num_isects) and for
  * gs_bin_sort with capacity num_isects, for a W x H image.  Nothing in the workspace has to
@@ -178,7 +205,9 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
 int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          const int32_t *tile_bins, const float *packed,
                          const float *background /*host[3]*/, float *out_img, float *final_Ts,
-                         int32_t *final_idx, uint32_t flags, gs_stream_t stream);
+                         int32_t *final_idx,
+                         float *out_img_clamped /*[H,W,3], required with GS_FLAG_CLAMP_IMAGE*/,
+                         uint32_t flags, gs_stream_t stream);
 
 size_t gs_rasterize_backward_workspace_bytes(int N);
 
@@ -186,9 +215,11 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const int32_t *tile_bins, const float *packed,
                           const float *background /*host[3]*/, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out,
-                          const float *v_out_alpha /*nullable*/, float *v_xy, float *v_conic,
-                          float *v_colors, float *v_opacity, void *workspace,
-                          size_t workspace_bytes, uint32_t flags, gs_stream_t stream);
+                          const float *v_out_alpha /*nullable*/,
+                          const float *out_img /*raw image, required with GS_FLAG_CLAMP_IMAGE*/,
+                          float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                          void *workspace, size_t workspace_bytes, uint32_t flags,
+                          gs_stream_t stream);
 
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact
  * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */

@@ -18,11 +18,14 @@ from . import _build
 GS_TILE = 16
 GS_SPLAT_DWORDS = 12
 GS_FLAG_FAST_EXP = 1
+GS_FLAG_LOGIT_OPACITY = 2
+GS_FLAG_CLAMP_IMAGE = 4
+GS_CAM_LOG_SCALES = 1
 
 # every symbol include/gsplat_hip.h declares (tests check they are all exported)
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
-    "gs_sh_forward", "gs_sh_backward", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
+    "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
     "gs_debug_reduce9", "gs_debug_time_next_kernel",
 ]
@@ -32,7 +35,7 @@ class GsCamera(C.Structure):
     _fields_ = [("viewmat", C.c_float * 16), ("projmat", C.c_float * 16), ("fx", C.c_float),
                 ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("img_width", C.c_int32), ("img_height", C.c_int32), ("clip_thresh", C.c_float),
-                ("glob_scale", C.c_float)]
+                ("glob_scale", C.c_float), ("flags", C.c_uint32)]
 
 
 _lib = None
@@ -81,8 +84,10 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_camera(viewmat, projmat, fx, fy, cx, cy, W, H, clip=0.01, glob_scale=1.0) -> GsCamera:
+def make_camera(viewmat, projmat, fx, fy, cx, cy, W, H, clip=0.01, glob_scale=1.0,
+                flags=0) -> GsCamera:
     cam = GsCamera()
+    cam.flags = int(flags)
     vm = torch.as_tensor(viewmat, dtype=torch.float32).cpu().reshape(-1).tolist()
     pm = torch.as_tensor(projmat, dtype=torch.float32).cpu().reshape(-1).tolist()
     for i in range(16):
@@ -177,7 +182,7 @@ GS_ERR_CAPACITY = -5
 
 
 def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
-                 workspace: BinWorkspace | None = None) -> Binned:
+                 workspace: BinWorkspace | None = None, flags=0) -> Binned:
     """pack -> gs_bin_and_sort (count + scan, one sync to read M, scatter + per-tile sort).
 
     The id buffer and the workspace live in `workspace` and only grow: the first call (and any
@@ -192,7 +197,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
     tile_bins = w.get("tile_bins", (tiles, 2), torch.int32, dev)
     _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
                             _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
-                            _stream()), "gs_pack_splats")
+                            C.c_uint32(flags), _stream()), "gs_pack_splats")
     m_host = w.m_host if w.m_host is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
     while True:
         cap = max(w.capacity, 1024)
@@ -220,13 +225,14 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
     bg = (C.c_float * 3)(*[float(b) for b in background])
     _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
-                                      _p(out["final_Ts"]), _p(out["final_idx"]), C.c_uint32(flags),
+                                      _p(out["final_Ts"]), _p(out["final_idx"]),
+                                      _p(out.get("img_clamped")), C.c_uint32(flags),
                                       _stream()), "gs_rasterize_forward")
     return out
 
 
 def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx, v_out, flags=0,
-                       v_out_alpha=None, out=None, workspace=None):
+                       v_out_alpha=None, out=None, workspace=None, img_raw=None):
     dev = binned.packed.device
     if out is None:
         out = dict(v_xy=torch.empty((N, 2), device=dev), v_conic=torch.empty((N, 3), device=dev),
@@ -238,7 +244,7 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
     _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N),
                                        _p(binned.gaussian_ids_sorted), _p(binned.tile_bins),
                                        _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
-                                       _p(v_out_alpha), _p(out["v_xy"]), _p(out["v_conic"]),
+                                       _p(v_out_alpha), _p(img_raw), _p(out["v_xy"]), _p(out["v_conic"]),
                                        _p(out["v_colors"]), _p(out["v_opacity"]), _p(workspace),
                                        C.c_size_t(workspace.numel()), C.c_uint32(flags), _stream()),
            "gs_rasterize_backward")
@@ -266,3 +272,27 @@ def time_next_kernel(ev_start, ev_stop):
     _check(lib().gs_debug_time_next_kernel(C.c_void_p(ev_start.cuda_event),
                                            C.c_void_p(ev_stop.cuda_event)),
            "gs_debug_time_next_kernel")
+
+
+def sh_forward_fused(degrees_to_use, means, cam_pos, features_dc, features_rest):
+    """-> (colors = max(SH + 0.5, 0), rgb_raw); features_rest [N, K-1, 3] or None for K = 1."""
+    N = means.shape[0]
+    K = 1 + (features_rest.shape[1] if features_rest is not None else 0)
+    colors = torch.empty((N, 3), device=means.device, dtype=torch.float32)
+    raw = torch.empty((N, 3), device=means.device, dtype=torch.float32)
+    cp = (C.c_float * 3)(*[float(v) for v in cam_pos])
+    _check(lib().gs_sh_forward_fused(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(means), cp,
+                                     _p(features_dc), _p(features_rest), _p(colors), _p(raw),
+                                     _stream()), "gs_sh_forward_fused")
+    return colors, raw
+
+
+def sh_backward_fused(degrees_to_use, K, means, cam_pos, rgb_raw, v_colors):
+    N = means.shape[0]
+    v_dc = torch.empty((N, 3), device=means.device, dtype=torch.float32)
+    v_rest = torch.empty((N, K - 1, 3), device=means.device, dtype=torch.float32) if K > 1 else None
+    cp = (C.c_float * 3)(*[float(v) for v in cam_pos])
+    _check(lib().gs_sh_backward_fused(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(means), cp,
+                                      _p(rgb_raw), _p(v_colors), _p(v_dc), _p(v_rest), _stream()),
+           "gs_sh_backward_fused")
+    return v_dc, v_rest

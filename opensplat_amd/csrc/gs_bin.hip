@@ -54,7 +54,7 @@ k_pack_splats(int W, int H, int N, const float *__restrict__ xys,
               const int32_t *__restrict__ radii, const float *__restrict__ conics,
               const float *__restrict__ colors, const float *__restrict__ opacities,
               const float *__restrict__ cov2d, float4 *__restrict__ packed,
-              int32_t *__restrict__ tiles_hit) {
+              int32_t *__restrict__ tiles_hit, uint32_t flags) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float x = xys[2 * n], y = xys[2 * n + 1];
@@ -70,7 +70,8 @@ k_pack_splats(int W, int H, int N, const float *__restrict__ xys,
         cyy = A / det;
     }
     PixRect r = pixel_rect(x, y, cxx, cyy, W, H);
-    const float opac = opacities[n];
+    float opac = opacities[n];
+    if (flags & GS_FLAG_LOGIT_OPACITY) opac = 1.0f / (1.0f + expf(-opac));  // torch::sigmoid, model.cpp:215
     // conservative w.r.t. rounding of the log, the exp and the product opacity*exp(-sigma)
     float smax = (opac > 0.0f) ? (logf(255.0f * opac) + 2.0e-3f) : -1.0f;
     uint32_t binding = 1u;
@@ -647,7 +648,7 @@ static BinLayout bin_layout(int64_t capacity, int W, int H) {
 extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
                               const float *conics, const float *colors, const float *opacities,
                               const float *cov2d, float *packed, int32_t *tiles_hit,
-                              gs_stream_t stream) {
+                              uint32_t flags, gs_stream_t stream) {
     if (N < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0) return GS_OK;
@@ -656,7 +657,7 @@ extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const int32
     if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(gs::k_pack_splats, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, W, H, N, xys, radii, conics, colors, opacities,
-                       cov2d, reinterpret_cast<float4 *>(packed), tiles_hit);
+                       cov2d, reinterpret_cast<float4 *>(packed), tiles_hit, flags);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

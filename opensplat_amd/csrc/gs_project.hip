@@ -20,6 +20,7 @@ struct CamArgs {
     float fx, fy, cx, cy;
     int W, H;
     float clip, glob;
+    uint32_t flags;
 };
 
 static CamArgs make_cam(const GsCamera *c) {
@@ -29,6 +30,7 @@ static CamArgs make_cam(const GsCamera *c) {
     a.fx = c->fx; a.fy = c->fy; a.cx = c->cx; a.cy = c->cy;
     a.W = c->img_width; a.H = c->img_height;
     a.clip = c->clip_thresh; a.glob = c->glob_scale;
+    a.flags = c->flags;
     return a;
 }
 
@@ -146,6 +148,10 @@ k_project_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *__
     load_device_matrices(cam, vm_dev, pm_dev);
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float scale[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    if (cam.flags & GS_CAM_LOG_SCALES) {  // fused torch::exp(scales), model.cpp:148
+#pragma unroll
+        for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
+    }
     const float4 q4 = reinterpret_cast<const float4 *>(quats)[n];
     float quat[4] = {q4.x, q4.y, q4.z, q4.w};
     Proj o;
@@ -209,6 +215,10 @@ k_project_backward(CamArgs cam, const float *__restrict__ vm_dev,
     }
     float mean[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
     float scale[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    if (cam.flags & GS_CAM_LOG_SCALES) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
+    }
     const float4 q4 = reinterpret_cast<const float4 *>(quats)[n];
     float quat[4] = {q4.x, q4.y, q4.z, q4.w};
     Proj o;
@@ -274,7 +284,8 @@ k_project_backward(CamArgs cam, const float *__restrict__ vm_dev,
             acc += o.Rq[3 * i + j] * vM[3 * i + j];
             vR[3 * i + j] = vM[3 * i + j] * cam.glob * scale[j];
         }
-        v_scales[3 * n + j] = cam.glob * acc;
+        // d exp(ls) / d ls = exp(ls) when the input was a log-scale
+        v_scales[3 * n + j] = cam.glob * acc * ((cam.flags & GS_CAM_LOG_SCALES) ? scale[j] : 1.0f);
     }
     float w = o.u[0], x = o.u[1], y = o.u[2], z = o.u[3];
     float vu0 = 2.0f * (-z * vR[1] + y * vR[2] + z * vR[3] - x * vR[5] - y * vR[6] + x * vR[7]);

@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                     float bg1, float bg2, float *__restrict__ out_img,
-                    float *__restrict__ final_Ts, int32_t *__restrict__ final_idx) {
+                    float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
+                    float *__restrict__ out_clamped) {
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
@@ -260,9 +261,15 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             const float a0 = (k & 1) ? acc2[h][0].y : acc2[h][0].x;
             const float a1 = (k & 1) ? acc2[h][1].y : acc2[h][1].x;
             const float a2 = (k & 1) ? acc2[h][2].y : acc2[h][2].x;
-            out_img[3 * pix + 0] = a0 + Tk * bg0;
-            out_img[3 * pix + 1] = a1 + Tk * bg1;
-            out_img[3 * pix + 2] = a2 + Tk * bg2;
+            const float o0 = a0 + Tk * bg0, o1 = a1 + Tk * bg1, o2 = a2 + Tk * bg2;
+            out_img[3 * pix + 0] = o0;
+            out_img[3 * pix + 1] = o1;
+            out_img[3 * pix + 2] = o2;
+            if (out_clamped) {  // fused torch::clamp_max(rgb, 1), model.cpp:222
+                out_clamped[3 * pix + 0] = fminf(o0, 1.0f);
+                out_clamped[3 * pix + 1] = fminf(o1, 1.0f);
+                out_clamped[3 * pix + 2] = fminf(o2, 1.0f);
+            }
             final_Ts[pix] = Tk;
             final_idx[pix] = last[k];
         }
@@ -332,7 +339,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                      float bg1, float bg2, const float *__restrict__ final_Ts,
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
-                     const float *__restrict__ v_out_alpha, float *__restrict__ gacc) {
+                     const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                     float *__restrict__ gacc) {
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
@@ -360,6 +368,11 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             o0 = v_out[3 * pix + 0];
             o1 = v_out[3 * pix + 1];
             o2 = v_out[3 * pix + 2];
+            if (img_raw) {  // backward of the fused clamp_max(rgb, 1): torch passes where rgb <= 1
+                if (!(img_raw[3 * pix + 0] <= 1.0f)) o0 = 0.0f;
+                if (!(img_raw[3 * pix + 1] <= 1.0f)) o1 = 0.0f;
+                if (!(img_raw[3 * pix + 2] <= 1.0f)) o2 = 0.0f;
+            }
             oa = v_out_alpha ? v_out_alpha[pix] : 0.0f;
         }
         const float tw = Tfin * (oa - (bg0 * o0 + bg1 * o1 + bg2 * o2));
@@ -527,13 +540,17 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
 // Splits the 64-byte gradient records into the four tensors the operator surface returns
 // (rasterize_gaussians.cpp:113-124): v_xy[N,2] v_conic[N,3] v_colors[N,3] v_opacity[N].
 __global__ void __launch_bounds__(256)
-k_unpack_grads(int N, const float4 *__restrict__ gacc, float *__restrict__ v_xy,
-               float *__restrict__ v_conic, float *__restrict__ v_colors,
+k_unpack_grads(int N, const float4 *__restrict__ gacc, const float4 *__restrict__ packed_logit,
+               float *__restrict__ v_xy, float *__restrict__ v_conic, float *__restrict__ v_colors,
                float *__restrict__ v_opacity) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float4 a = gacc[4 * (size_t)n + 0], b = gacc[4 * (size_t)n + 1];
-    const float o = reinterpret_cast<const float *>(gacc)[kGradRec * (size_t)n + 8];
+    float o = reinterpret_cast<const float *>(gacc)[kGradRec * (size_t)n + 8];
+    if (packed_logit) {  // opacity = sigmoid(logit): d/dlogit = s (1 - s), model.cpp:215
+        const float sg = packed_logit[3 * (size_t)n + 1].y;
+        o *= sg * (1.0f - sg);
+    }
     v_xy[2 * (size_t)n + 0] = a.x;
     v_xy[2 * (size_t)n + 1] = a.y;
     v_conic[3 * (size_t)n + 0] = a.z;
@@ -619,8 +636,11 @@ extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stre
 extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                                     const int32_t *tile_bins, const float *packed,
                                     const float *background, float *out_img, float *final_Ts,
-                                    int32_t *final_idx, uint32_t flags, gs_stream_t stream) {
+                                    int32_t *final_idx, float *out_img_clamped, uint32_t flags,
+                                    gs_stream_t stream) {
     if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
+    float *clamped = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img_clamped : nullptr;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (!tile_bins || !background || !out_img || !final_Ts || !final_idx)
         return GS_ERR_INVALID_ARGUMENT;
@@ -634,11 +654,11 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], out_img, final_Ts, final_idx);
+                           background[1], background[2], out_img, final_Ts, final_idx, clamped);
     else
         hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], out_img, final_Ts, final_idx);
+                           background[1], background[2], out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -652,10 +672,13 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                                      const int32_t *tile_bins, const float *packed,
                                      const float *background, const float *final_Ts,
                                      const int32_t *final_idx, const float *v_out,
-                                     const float *v_out_alpha, float *v_xy, float *v_conic,
-                                     float *v_colors, float *v_opacity, void *workspace,
-                                     size_t workspace_bytes, uint32_t flags, gs_stream_t stream) {
+                                     const float *v_out_alpha, const float *out_img, float *v_xy,
+                                     float *v_conic, float *v_colors, float *v_opacity,
+                                     void *workspace, size_t workspace_bytes, uint32_t flags,
+                                     gs_stream_t stream) {
     if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
+    if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
+    const float *img_raw = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img : nullptr;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0) return GS_OK;
     if (!tile_bins || !background || !final_Ts || !final_idx || !v_out || !v_xy || !v_conic ||
@@ -675,16 +698,18 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
-                           gacc);
+                           img_raw, gacc);
     else
         hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(tiles), dim3(64), 0, s, W, H,
                            tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
-                           gacc);
+                           img_raw, gacc);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
-                       reinterpret_cast<const float4 *>(gacc), v_xy, v_conic, v_colors, v_opacity);
+                       reinterpret_cast<const float4 *>(gacc),
+                       (flags & GS_FLAG_LOGIT_OPACITY) ? pk : nullptr, v_xy, v_conic, v_colors,
+                       v_opacity);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

@@ -207,6 +207,155 @@ static int launch_bwd(int N, int nb, const float *dirs, const float *v_colors, f
     return GS_OK;
 }
 
+// ---- fused-glue variants ---------------------------------------------------
+// Coefficients arrive as OpenSplat stores them — features_dc[N,3] and features_rest[N,K-1,3]
+// (model.hpp) — so the per-step torch::cat copy (model.cpp:114, 192 MB at C2) disappears; the view
+// direction normalize(mean - cam_pos) (model.cpp:176-177) is computed in registers; the output is
+// clamp_min(rgb + 0.5, 0) (model.cpp:192) plus the raw rgb the backward needs for the clamp mask.
+// Layout trick as in k_sh_forward: a wave moves the 64 * 12(K-1)-byte slab of its 64 Gaussians'
+// higher-band coefficients with coalesced 16-byte loads through LDS rows of odd stride.
+template <int K>
+struct ShSplit {
+    static constexpr int ROW = 3 * (K - 1);
+    static constexpr int ROWP = (ROW == 0) ? 1 : (ROW | 1);
+    static constexpr int kBlock = (K > 16) ? 128 : 256;
+};
+
+__device__ __forceinline__ void view_dir(const float *__restrict__ means, int64_t g, float cx,
+                                         float cy, float cz, float &x, float &y, float &z) {
+    // (means - T) / ||means - T||, model.cpp:176-177 (torch::norm, no epsilon)
+    x = means[3 * g] - cx;
+    y = means[3 * g + 1] - cy;
+    z = means[3 * g + 2] - cz;
+    const float n = sqrtf(x * x + y * y + z * z);
+    x /= n; y /= n; z /= n;
+}
+
+template <int K>
+__global__ void __launch_bounds__(ShSplit<K>::kBlock)
+k_sh_forward_fused(int N, int nb, const float *__restrict__ means, float cx, float cy, float cz,
+                   const float *__restrict__ dc, const float *__restrict__ rest,
+                   float *__restrict__ colors, float *__restrict__ rgb_raw) {
+    constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if constexpr (ROW > 0) {
+        const float *src = rest + g0 * ROW;  // 16-B aligned: 64 * ROW * 4 bytes per wave
+        const int total = cnt * ROW;
+        for (int i = lane * 4; i < total; i += 64 * 4) {
+            if (i + 3 < total) {
+                float4 v = *reinterpret_cast<const float4 *>(src + i);
+                float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int idx = i + k;
+                    slab[(idx / ROW) * ROWP + (idx % ROW)] = e[k];
+                }
+            } else {
+                for (int idx = i; idx < total; idx++) slab[(idx / ROW) * ROWP + (idx % ROW)] = src[idx];
+            }
+        }
+    }
+    __syncthreads();
+    if (lane >= cnt) return;
+    const int64_t g = g0 + lane;
+    float x, y, z;
+    view_dir(means, g, cx, cy, cz, x, y, z);
+    float r[25];
+    sh_basis(nb, x, y, z, r);
+    float c0 = r[0] * dc[3 * g], c1 = r[0] * dc[3 * g + 1], c2 = r[0] * dc[3 * g + 2];
+    const float *row = slab + lane * ROWP;
+#pragma unroll
+    for (int b = 1; b < K; b++) {
+        c0 += r[b] * row[3 * (b - 1) + 0];
+        c1 += r[b] * row[3 * (b - 1) + 1];
+        c2 += r[b] * row[3 * (b - 1) + 2];
+    }
+    rgb_raw[3 * g + 0] = c0;
+    rgb_raw[3 * g + 1] = c1;
+    rgb_raw[3 * g + 2] = c2;
+    colors[3 * g + 0] = fmaxf(c0 + 0.5f, 0.0f);
+    colors[3 * g + 1] = fmaxf(c1 + 0.5f, 0.0f);
+    colors[3 * g + 2] = fmaxf(c2 + 0.5f, 0.0f);
+}
+
+template <int K>
+__global__ void __launch_bounds__(ShSplit<K>::kBlock)
+k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, float cy, float cz,
+                    const float *__restrict__ rgb_raw, const float *__restrict__ v_colors,
+                    float *__restrict__ v_dc, float *__restrict__ v_rest) {
+    constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if (lane < cnt) {
+        const int64_t g = g0 + lane;
+        float x, y, z;
+        view_dir(means, g, cx, cy, cz, x, y, z);
+        float r[25];
+        sh_basis(nb, x, y, z, r);
+        // clamp_min(rgb + 0.5, 0) backward: gradient passes where rgb + 0.5 >= 0 (torch's mask)
+        const float v0 = (rgb_raw[3 * g + 0] + 0.5f >= 0.0f) ? v_colors[3 * g + 0] : 0.0f;
+        const float v1 = (rgb_raw[3 * g + 1] + 0.5f >= 0.0f) ? v_colors[3 * g + 1] : 0.0f;
+        const float v2 = (rgb_raw[3 * g + 2] + 0.5f >= 0.0f) ? v_colors[3 * g + 2] : 0.0f;
+        v_dc[3 * g + 0] = r[0] * v0;
+        v_dc[3 * g + 1] = r[0] * v1;
+        v_dc[3 * g + 2] = r[0] * v2;
+        float *row = slab + lane * ROWP;
+#pragma unroll
+        for (int b = 1; b < K; b++) {
+            row[3 * (b - 1) + 0] = r[b] * v0;
+            row[3 * (b - 1) + 1] = r[b] * v1;
+            row[3 * (b - 1) + 2] = r[b] * v2;
+        }
+    }
+    __syncthreads();
+    if constexpr (ROW > 0) {
+        float *dst = v_rest + g0 * ROW;
+        const int total = cnt * ROW;
+        for (int i = lane * 4; i < total; i += 64 * 4) {
+            if (i + 3 < total) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int idx = i + k;
+                    e[k] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+                }
+                *reinterpret_cast<float4 *>(dst + i) = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+                for (int idx = i; idx < total; idx++) dst[idx] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_fwd_fused(int N, int nb, const float *means, const float *cp, const float *dc,
+                            const float *rest, float *colors, float *rgb_raw, hipStream_t s) {
+    constexpr int BLK = ShSplit<K>::kBlock;
+    size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    hipLaunchKernelGGL(k_sh_forward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+                       means, cp[0], cp[1], cp[2], dc, rest, colors, rgb_raw);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+template <int K>
+static int launch_bwd_fused(int N, int nb, const float *means, const float *cp, const float *rgb_raw,
+                            const float *v_colors, float *v_dc, float *v_rest, hipStream_t s) {
+    constexpr int BLK = ShSplit<K>::kBlock;
+    size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    hipLaunchKernelGGL(k_sh_backward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+                       means, cp[0], cp[1], cp[2], rgb_raw, v_colors, v_dc, v_rest);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
 static int deg_from_bases(int K) {  // spherical_harmonics.cpp:3-16, but strict
     switch (K) {
     case 1: return 0;
@@ -259,5 +408,47 @@ extern "C" int gs_sh_backward(int N, int K, int degrees_to_use, const float *dir
     case 9: return gs::launch_bwd<9>(N, nb, dirs, v_colors, v_coeffs, s);
     case 16: return gs::launch_bwd<16>(N, nb, dirs, v_colors, v_coeffs, s);
     default: return gs::launch_bwd<25>(N, nb, dirs, v_colors, v_coeffs, s);
+    }
+}
+
+extern "C" int gs_sh_forward_fused(int N, int K, int degrees_to_use, const float *means,
+                                   const float *cam_pos, const float *features_dc,
+                                   const float *features_rest, float *colors, float *rgb_raw,
+                                   gs_stream_t stream) {
+    int deg = gs::deg_from_bases(K);
+    if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg) return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!means || !cam_pos || !features_dc || !colors || !rgb_raw || (K > 1 && !features_rest))
+        return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)features_rest & 15u) return GS_ERR_INVALID_ARGUMENT;  // 16-byte vector loads
+    int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+    case 1: return gs::launch_fwd_fused<1>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    case 4: return gs::launch_fwd_fused<4>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    case 9: return gs::launch_fwd_fused<9>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    case 16: return gs::launch_fwd_fused<16>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    default: return gs::launch_fwd_fused<25>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    }
+}
+
+extern "C" int gs_sh_backward_fused(int N, int K, int degrees_to_use, const float *means,
+                                    const float *cam_pos, const float *rgb_raw,
+                                    const float *v_colors, float *v_dc, float *v_rest,
+                                    gs_stream_t stream) {
+    int deg = gs::deg_from_bases(K);
+    if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg) return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!means || !cam_pos || !rgb_raw || !v_colors || !v_dc || (K > 1 && !v_rest))
+        return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)v_rest & 15u) return GS_ERR_INVALID_ARGUMENT;  // 16-byte vector stores
+    int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+    case 1: return gs::launch_bwd_fused<1>(N, nb, means, cam_pos, rgb_raw, v_colors, v_dc, v_rest, s);
+    case 4: return gs::launch_bwd_fused<4>(N, nb, means, cam_pos, rgb_raw, v_colors, v_dc, v_rest, s);
+    case 9: return gs::launch_bwd_fused<9>(N, nb, means, cam_pos, rgb_raw, v_colors, v_dc, v_rest, s);
+    case 16: return gs::launch_bwd_fused<16>(N, nb, means, cam_pos, rgb_raw, v_colors, v_dc, v_rest, s);
+    default: return gs::launch_bwd_fused<25>(N, nb, means, cam_pos, rgb_raw, v_colors, v_dc, v_rest, s);
     }
 }

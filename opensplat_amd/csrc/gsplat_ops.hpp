@@ -50,7 +50,7 @@ public:
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, int64_t> binAndSortGaussians(
     const torch::Tensor &xys, const torch::Tensor &depths, const torch::Tensor &radii,
     const torch::Tensor &conics, const torch::Tensor &colors, const torch::Tensor &opacity,
-    const torch::Tensor &cov2d, int imgHeight, int imgWidth);
+    const torch::Tensor &cov2d, int imgHeight, int imgWidth, bool opacityIsLogit = false);
 
 class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
 public:
@@ -70,6 +70,25 @@ class SphericalHarmonics : public torch::autograd::Function<SphericalHarmonics> 
 public:
     static torch::Tensor forward(torch::autograd::AutogradContext *ctx, int64_t degreesToUse,
                                  torch::Tensor viewDirs, torch::Tensor coeffs);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+
+// SURVEY.md §8 row f1 — Model::forward's whole render chain (model.cpp:114-222) as one autograd
+// node with the element-wise glue fused into the kernels.  Inputs are the RAW parameters OpenSplat
+// optimises (log-scales, unnormalised quats, opacity logits, featuresDc / featuresRest), viewMat,
+// projMat (= proj @ view), camPos = camera centre in world space (T of camToWorld, model.cpp:95).
+// Returns { rgb[H,W,3] (clamp_max 1 applied), xys[N,2] (detached), radii[N] }.  The gradient of the
+// loss w.r.t. xys (Model::afterTrain reads xys.grad(), model.cpp:318) is written to xysGradOut.
+class SplatRender : public torch::autograd::Function<SplatRender> {
+public:
+    static torch::autograd::variable_list forward(
+        torch::autograd::AutogradContext *ctx, torch::Tensor means, torch::Tensor logScales,
+        torch::Tensor quats, torch::Tensor opacityLogits, torch::Tensor featuresDc,
+        torch::Tensor featuresRest, torch::Tensor viewMat, torch::Tensor projMat,
+        torch::Tensor camPos, double fx, double fy, double cx, double cy, int64_t imgHeight,
+        int64_t imgWidth, int64_t degreesToUse, torch::Tensor background,
+        c10::optional<torch::Tensor> xysGradOut = c10::nullopt);
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
                                                  torch::autograd::tensor_list grad_outputs);
 };

@@ -45,9 +45,10 @@ const float *fptr(const Tensor &t) { return t.data_ptr<float>(); }
 float *fptr_mut(Tensor &t) { return t.data_ptr<float>(); }
 
 GsCamera make_camera(double fx, double fy, double cx, double cy, int64_t H, int64_t W, double clip,
-                     double glob) {
+                     double glob, uint32_t flags = 0) {
     GsCamera c;
     std::memset(&c, 0, sizeof(c));
+    c.flags = flags;
     c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
     c.img_width = (int32_t)W; c.img_height = (int32_t)H;
     c.clip_thresh = (float)clip; c.glob_scale = (float)glob;
@@ -168,7 +169,8 @@ tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_ou
 // ---- binning ------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
     const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
-    const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth) {
+    const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth,
+    bool opacityIsLogit) {
     const int64_t N = xys.size(0);
     const int W = imgWidth, H = imgHeight;
     auto f32 = xys.options().dtype(torch::kFloat32);
@@ -180,7 +182,8 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
     check_status(gs_pack_splats(W, H, (int)N, fptr(xys), radii.data_ptr<int32_t>(), fptr(conics),
                                 fptr(colors), fptr(opacity),
                                 cov2d.defined() ? fptr(cov2d) : nullptr, fptr_mut(packed),
-                                tilesHit.data_ptr<int32_t>(), s),
+                                tilesHit.data_ptr<int32_t>(),
+                                opacityIsLogit ? GS_FLAG_LOGIT_OPACITY : 0u, s),
                  "gs_pack_splats");
 
     // The intersection count sizes the id list: one pinned int, one stream sync inside
@@ -241,7 +244,7 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     conics = conics.contiguous(); colors = colors.contiguous(); opacity = opacity.contiguous();
     const int W = (int)imgWidth, H = (int)imgHeight;
 
-    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W);
+    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
     Tensor packed = std::get<0>(b), idsSorted = std::get<1>(b), tileBins = std::get<2>(b);
 
     Tensor bgHost = background.detach().to(torch::kCPU, torch::kFloat32).contiguous();
@@ -253,7 +256,7 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
                                       tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                       fptr_mut(outImg), fptr_mut(finalTs),
-                                      finalIdx.data_ptr<int32_t>(), flags, current_stream()),
+                                      finalIdx.data_ptr<int32_t>(), nullptr, flags, current_stream()),
                  "gs_rasterize_forward");
 
     ctx->saved_data["imgWidth"] = imgWidth;
@@ -288,7 +291,7 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
                                        tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                        fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
                                        nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
-                                       fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
+                                       nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
                                        fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
                                        (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
                  "gs_rasterize_backward");
@@ -329,6 +332,159 @@ tensor_list SphericalHarmonics::backward(AutogradContext *ctx, tensor_list grad_
     return {none, none, v_coeffs};
 }
 
+
+// ---- SplatRender: Model::forward's render chain as ONE autograd node --------
+// Replaces, with identical semantics, model.cpp:114 (cat), :147-159 (exp, normalise, project),
+// :176-192 (view dirs, SH, +0.5, clamp_min), :208-218 (sigmoid, rasterize) and :222 (clamp_max):
+// the element-wise glue runs inside the kernels (GS_CAM_LOG_SCALES, gs_sh_*_fused,
+// GS_FLAG_LOGIT_OPACITY, GS_FLAG_CLAMP_IMAGE), no concatenated / exponentiated / normalised copies
+// of the parameters are materialised.  xys is returned (detached) together with radii for
+// Model::afterTrain (model.cpp:318-336); since xys is no longer a graph leaf whose .grad could be
+// retained (model.cpp:171), its gradient is written into `xysGradOut` when that tensor is given.
+variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor logScales,
+                                   Tensor quats, Tensor opacityLogits, Tensor featuresDc,
+                                   Tensor featuresRest, Tensor viewMat, Tensor projMat,
+                                   Tensor camPos, double fx, double fy, double cx, double cy,
+                                   int64_t imgHeight, int64_t imgWidth, int64_t degreesToUse,
+                                   Tensor background, c10::optional<Tensor> xysGradOut) {
+    GS_CHECK_DEV(means); GS_CHECK_DEV(logScales); GS_CHECK_DEV(quats); GS_CHECK_DEV(opacityLogits);
+    GS_CHECK_DEV(featuresDc);
+    GS_CHECK_F32(means); GS_CHECK_F32(logScales); GS_CHECK_F32(quats); GS_CHECK_F32(opacityLogits);
+    GS_CHECK_F32(featuresDc);
+    const int64_t N = means.size(0);
+    TORCH_CHECK(means.dim() == 2 && means.size(1) == 3, "means must be [N,3]");
+    TORCH_CHECK(logScales.sizes() == means.sizes(), "scales must be [N,3]");
+    TORCH_CHECK(quats.dim() == 2 && quats.size(0) == N && quats.size(1) == 4, "quats must be [N,4]");
+    TORCH_CHECK(opacityLogits.numel() == N, "opacities must have N elements");
+    TORCH_CHECK(featuresDc.dim() == 2 && featuresDc.size(0) == N && featuresDc.size(1) == 3,
+                "featuresDc must be [N,3]");
+    const bool hasRest = featuresRest.defined() && featuresRest.numel() > 0;
+    if (hasRest) {
+        GS_CHECK_DEV(featuresRest); GS_CHECK_F32(featuresRest);
+        TORCH_CHECK(featuresRest.dim() == 3 && featuresRest.size(0) == N && featuresRest.size(2) == 3,
+                    "featuresRest must be [N,K-1,3]");
+    }
+    const int64_t K = 1 + (hasRest ? featuresRest.size(1) : 0);
+    TORCH_CHECK(background.numel() == 3, "background must have 3 elements");
+    TORCH_CHECK(camPos.numel() == 3, "camPos must have 3 elements");
+    c10::DeviceGuard guard(means.device());
+    means = means.contiguous(); logScales = logScales.contiguous(); quats = quats.contiguous();
+    opacityLogits = opacityLogits.contiguous(); featuresDc = featuresDc.contiguous();
+    if (hasRest) featuresRest = featuresRest.contiguous();
+    const int W = (int)imgWidth, H = (int)imgHeight;
+    gs_stream_t s = current_stream();
+
+    GsCamera cam = make_camera(fx, fy, cx, cy, imgHeight, imgWidth, 0.01, 1.0, GS_CAM_LOG_SCALES);
+    Tensor vmHold, pmHold;
+    const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
+    const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
+    Tensor cpHost = camPos.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+    Tensor bgHost = background.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+    const float *cp = cpHost.data_ptr<float>(), *bg = bgHost.data_ptr<float>();
+
+    auto f32 = means.options();
+    auto i32 = means.options().dtype(torch::kInt32);
+    Tensor xys = torch::empty({N, 2}, f32), depths = torch::empty({N}, f32);
+    Tensor radii = torch::empty({N}, i32), conics = torch::empty({N, 3}, f32);
+    Tensor numTilesHit = torch::empty({N}, i32), cov3d = torch::empty({N, 6}, f32);
+    Tensor cov2d = torch::empty({N, 3}, f32);
+    check_status(gs_project_forward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(logScales),
+                                    fptr(quats), fptr_mut(xys), fptr_mut(depths),
+                                    radii.data_ptr<int32_t>(), fptr_mut(conics),
+                                    numTilesHit.data_ptr<int32_t>(), fptr_mut(cov3d),
+                                    fptr_mut(cov2d), s),
+                 "gs_project_forward");
+    Tensor colors = torch::empty({N, 3}, f32), rgbRaw = torch::empty({N, 3}, f32);
+    check_status(gs_sh_forward_fused((int)N, (int)K, (int)degreesToUse, fptr(means), cp,
+                                     fptr(featuresDc), hasRest ? fptr(featuresRest) : nullptr,
+                                     fptr_mut(colors), fptr_mut(rgbRaw), s),
+                 "gs_sh_forward_fused");
+    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacityLogits, cov2d, H, W, true);
+    Tensor packed = std::get<0>(b), idsSorted = std::get<1>(b), tileBins = std::get<2>(b);
+    Tensor imgRaw = torch::empty({H, W, 3}, f32), img = torch::empty({H, W, 3}, f32);
+    Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
+    const uint32_t flags = (g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u) | GS_FLAG_CLAMP_IMAGE |
+                           GS_FLAG_LOGIT_OPACITY;
+    check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
+                                      tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                      fptr_mut(imgRaw), fptr_mut(finalTs),
+                                      finalIdx.data_ptr<int32_t>(), fptr_mut(img), flags, s),
+                 "gs_rasterize_forward");
+
+    ctx->saved_data["imgWidth"] = imgWidth; ctx->saved_data["imgHeight"] = imgHeight;
+    ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
+    ctx->saved_data["cx"] = cx; ctx->saved_data["cy"] = cy;
+    ctx->saved_data["bg0"] = (double)bg[0]; ctx->saved_data["bg1"] = (double)bg[1];
+    ctx->saved_data["bg2"] = (double)bg[2];
+    ctx->saved_data["cp0"] = (double)cp[0]; ctx->saved_data["cp1"] = (double)cp[1];
+    ctx->saved_data["cp2"] = (double)cp[2];
+    ctx->saved_data["flags"] = (int64_t)flags;
+    ctx->saved_data["K"] = K; ctx->saved_data["degreesToUse"] = degreesToUse;
+    Tensor gradOut = (xysGradOut.has_value() && xysGradOut->defined()) ? *xysGradOut : Tensor();
+    if (gradOut.defined()) {
+        GS_CHECK_DEV(gradOut); GS_CHECK_F32(gradOut);
+        TORCH_CHECK(gradOut.is_contiguous() && gradOut.numel() == 2 * N, "xysGradOut must be a contiguous [N,2] tensor");
+    }
+    ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
+                            tileBins, packed, finalTs, finalIdx, imgRaw,
+                            gradOut.defined() ? gradOut : torch::empty({0}, f32)});
+    Tensor xysOut = xys.detach();
+    ctx->mark_non_differentiable({xysOut, radii});
+    return {img, xysOut, radii};
+}
+
+tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs) {
+    variable_list sv = ctx->get_saved_variables();
+    Tensor means = sv[0], logScales = sv[1], quats = sv[2], viewMat = sv[3], projMat = sv[4];
+    Tensor radii = sv[5], rgbRaw = sv[6], idsSorted = sv[7], tileBins = sv[8], packed = sv[9];
+    Tensor finalTs = sv[10], finalIdx = sv[11], imgRaw = sv[12], gradOut = sv[13];
+    const int64_t N = means.size(0), K = ctx->saved_data["K"].toInt();
+    const int W = (int)ctx->saved_data["imgWidth"].toInt(), H = (int)ctx->saved_data["imgHeight"].toInt();
+    c10::DeviceGuard guard(means.device());
+    gs_stream_t s = current_stream();
+    Tensor v_img = grad_outputs[0].contiguous();
+    GS_CHECK_F32(v_img);
+    const float bg[3] = {(float)ctx->saved_data["bg0"].toDouble(), (float)ctx->saved_data["bg1"].toDouble(),
+                         (float)ctx->saved_data["bg2"].toDouble()};
+    const float cp[3] = {(float)ctx->saved_data["cp0"].toDouble(), (float)ctx->saved_data["cp1"].toDouble(),
+                         (float)ctx->saved_data["cp2"].toDouble()};
+    auto f32 = means.options();
+    Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : torch::empty({N, 2}, f32);
+    Tensor v_conic = torch::empty({N, 3}, f32), v_colors = torch::empty({N, 3}, f32);
+    Tensor v_opacity = torch::empty({N, 1}, f32);
+    const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
+    Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
+    check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
+                                       tileBins.data_ptr<int32_t>(), fptr(packed), bg, fptr(finalTs),
+                                       finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
+                                       fptr(imgRaw), fptr_mut(v_xy), fptr_mut(v_conic),
+                                       fptr_mut(v_colors), fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
+                                       (uint32_t)ctx->saved_data["flags"].toInt(), s),
+                 "gs_rasterize_backward");
+    Tensor v_dc = torch::empty({N, 3}, f32);
+    Tensor v_rest = K > 1 ? torch::empty({N, K - 1, 3}, f32) : Tensor();
+    check_status(gs_sh_backward_fused((int)N, (int)K, (int)ctx->saved_data["degreesToUse"].toInt(),
+                                      fptr(means), cp, fptr(rgbRaw), fptr(v_colors), fptr_mut(v_dc),
+                                      K > 1 ? fptr_mut(v_rest) : nullptr, s),
+                 "gs_sh_backward_fused");
+    GsCamera cam = make_camera(ctx->saved_data["fx"].toDouble(), ctx->saved_data["fy"].toDouble(),
+                               ctx->saved_data["cx"].toDouble(), ctx->saved_data["cy"].toDouble(), H, W,
+                               0.01, 1.0, GS_CAM_LOG_SCALES);
+    Tensor vmHold, pmHold;
+    const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
+    const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
+    Tensor v_means = torch::empty({N, 3}, f32), v_scales = torch::empty({N, 3}, f32);
+    Tensor v_quats = torch::empty({N, 4}, f32);
+    check_status(gs_project_backward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(logScales),
+                                     fptr(quats), radii.data_ptr<int32_t>(), fptr(v_xy), nullptr,
+                                     fptr(v_conic), fptr_mut(v_means), fptr_mut(v_scales),
+                                     fptr_mut(v_quats), s),
+                 "gs_project_backward");
+    Tensor none;
+    return {v_means, v_scales, v_quats, v_opacity, v_dc, v_rest, none, none, none, none, none, none,
+            none, none, none, none, none, none};
+}
+
 // ---- Python-visible registration (torch.ops.opensplat_amd.*) -------------------------------------
 namespace {
 
@@ -355,6 +511,18 @@ Tensor op_spherical_harmonics(int64_t degreesToUse, const Tensor &viewDirs, cons
     return SphericalHarmonics::apply(degreesToUse, viewDirs, coeffs);
 }
 
+std::vector<Tensor> op_splat_render(const Tensor &means, const Tensor &logScales, const Tensor &quats,
+                                    const Tensor &opacityLogits, const Tensor &featuresDc,
+                                    const Tensor &featuresRest, const Tensor &viewMat,
+                                    const Tensor &projMat, const Tensor &camPos, double fx, double fy,
+                                    double cx, double cy, int64_t imgHeight, int64_t imgWidth,
+                                    int64_t degreesToUse, const Tensor &background,
+                                    const c10::optional<Tensor> &xysGradOut) {
+    return SplatRender::apply(means, logScales, quats, opacityLogits, featuresDc, featuresRest, viewMat,
+                              projMat, camPos, fx, fy, cx, cy, imgHeight, imgWidth, degreesToUse,
+                              background, xysGradOut);
+}
+
 void op_set_fast_exp(bool enabled) { gsplatSetFastExp(enabled); }
 
 }  // namespace
@@ -370,5 +538,10 @@ TORCH_LIBRARY(opensplat_amd, m) {
           &op_rasterize_gaussians);
     m.def("spherical_harmonics(int degrees_to_use, Tensor viewdirs, Tensor coeffs) -> Tensor",
           &op_spherical_harmonics);
+    m.def("splat_render(Tensor means, Tensor log_scales, Tensor quats, Tensor opacity_logits, "
+          "Tensor features_dc, Tensor features_rest, Tensor viewmat, Tensor projmat, Tensor cam_pos, "
+          "float fx, float fy, float cx, float cy, int img_height, int img_width, int degrees_to_use, "
+          "Tensor background, Tensor? xys_grad_out=None) -> Tensor[]",
+          &op_splat_render);
     m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
 }

@@ -65,3 +65,13 @@ def rgb2sh(rgb):  # spherical_harmonics.cpp:20-23
 
 def sh2rgb(sh):  # spherical_harmonics.cpp:25-28
     return torch.clamp(sh * _C0 + 0.5, 0.0, 1.0)
+
+
+def splat_render(means, log_scales, quats, opacity_logits, features_dc, features_rest, viewmat,
+                 projmat, cam_pos, fx, fy, cx, cy, img_height, img_width, degrees_to_use, background,
+                 xys_grad_out=None):
+    """Model::forward's render chain as one autograd node (SURVEY.md §8 row f1): raw parameters in,
+    -> [rgb (clamped to <= 1), xys (detached), radii]; d loss / d xys is written to xys_grad_out."""
+    return _ops.splat_render(means, log_scales, quats, opacity_logits, features_dc, features_rest,
+                             viewmat, projmat, cam_pos, fx, fy, cx, cy, img_height, img_width,
+                             degrees_to_use, background, xys_grad_out)

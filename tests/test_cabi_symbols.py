@@ -59,7 +59,7 @@ def test_argument_validation_without_gpu():
     # image side > 65535 -> unsupported
     assert l.gs_project_forward(ctypes.byref(cam), null, null, 5, one, one, one, one, one, one,
                                 one, one, one, one, null) == -2
-    assert l.gs_pack_splats(70000, 16, 5, one, one, one, one, one, null, one, one, null) == -2
+    assert l.gs_pack_splats(70000, 16, 5, one, one, one, one, one, null, one, one, 0, null) == -2
     # N == 0 is a no-op success
     assert l.gs_sh_forward(0, 16, 3, null, null, null, null) == 0
     assert l.gs_project_forward(ctypes.byref(cam), null, null, 0, null, null, null, null, null,

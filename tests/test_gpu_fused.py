@@ -1,0 +1,136 @@
+"""-m gpu: SURVEY.md §8 row f1 — the fused-glue kernels and the SplatRender operator against the
+unfused chain (the reference's own operator sequence with torch element-wise glue, model.cpp:114-222),
+which the other GPU tests tie to the CPU oracle."""
+import numpy as np
+import pytest
+
+from opensplat_amd import scenes
+from tests.util import np_, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_params(s, seed=0):
+    """Raw optimiser parameters that reproduce scene `s` through Model::forward's glue."""
+    rs = np.random.RandomState(seed)
+    log_scales = np.log(s.scales).astype(np.float32)
+    quats_raw = (s.quats * rs.uniform(0.5, 2.0, (s.N, 1))).astype(np.float32)
+    o = np.clip(s.opacities.reshape(-1, 1), 1e-6, 1 - 1e-6)
+    logits = np.log(o / (1 - o)).astype(np.float32)
+    dc = np.ascontiguousarray(s.sh_coeffs[:, 0, :])
+    rest = np.ascontiguousarray(s.sh_coeffs[:, 1:, :])
+    R, t = s.viewmat[:3, :3], s.viewmat[:3, 3]
+    cam_pos = (-R.T @ t).astype(np.float32)
+    return log_scales, quats_raw, logits, dc, rest, cam_pos
+
+
+def _unfused(s, P, v_img):
+    """OpenSplat's Model::forward (GPU branch) with this repo's three operators."""
+    import torch
+
+    from opensplat_amd import ops
+
+    means, ls, q, lo, dc, rest = P
+    cam_pos = to_dev(_raw_params(s)[5])
+    p = ops.project_gaussians(means, torch.exp(ls), 1.0, q / q.norm(2, -1, True), to_dev(s.viewmat),
+                              to_dev(s.projmat), s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+    xys = p[0]
+    xys.retain_grad()
+    colors = torch.cat([dc[:, None, :], rest], 1)
+    dirs = means.detach() - cam_pos
+    dirs = dirs / dirs.norm(2, -1, True)
+    rgbs = ops.spherical_harmonics(s.degrees_to_use, dirs, colors)
+    rgbs = torch.clamp_min(rgbs + 0.5, 0.0)
+    img = ops.rasterize_gaussians(xys, p[1], p[2], p[3], p[4], rgbs, torch.sigmoid(lo), s.H, s.W,
+                                  to_dev(s.background), p[6])
+    img = torch.clamp_max(img, 1.0)
+    img.backward(v_img)
+    return img, xys, p[2]
+
+
+@pytest.mark.parametrize("K,deg", [(16, 3), (4, 1), (1, 0), (9, 2)])
+def test_splat_render_matches_the_unfused_operator_chain(K, deg):
+    import torch
+
+    from opensplat_amd import ops
+
+    s = scenes.camera_scene(6000, 320, 200, K=K, seed=51, znear=1.0, zfar=100.0, yaw_deg=4.0,
+                            degrees_to_use=deg)
+    # brighten so that clamp_max(rgb, 1) is active on part of the image
+    s.sh_coeffs[:, 0, :] += 1.0
+    raw = _raw_params(s)
+    v_img = to_dev(np.random.RandomState(5).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32))
+
+    def leaves():
+        arrs = [s.means, raw[0], raw[1], raw[2], raw[3], raw[4]]
+        return [to_dev(a).requires_grad_(True) for a in arrs]
+
+    A = leaves()
+    img_a, xys_a, radii_a = _unfused(s, A, v_img)
+    B = leaves()
+    xys_grad = torch.zeros((s.N, 2), device="cuda")
+    out = ops.splat_render(B[0], B[1], B[2], B[3], B[4], B[5] if K > 1 else torch.empty(0, device="cuda"),
+                           to_dev(s.viewmat), to_dev(s.projmat), to_dev(raw[5]), s.fx, s.fy, s.cx, s.cy,
+                           s.H, s.W, s.degrees_to_use, to_dev(s.background), xys_grad)
+    out[0].backward(v_img)
+    torch.cuda.synchronize()
+    assert (np_(img_a) >= 1.0).mean() > 0.001                     # the clamp is exercised
+    assert np.array_equal(np_(out[2]), np_(radii_a))
+    assert rel_err(np_(out[1]), np_(xys_a)) < 1e-6
+    # the fused sigmoid / exp differ from torch's by an ulp: a handful of threshold flips at most
+    d = np.abs(np_(out[0]) - np_(img_a)).max(axis=2)
+    assert (d > 1e-5).sum() <= max(4, 2e-5 * d.size), (d > 1e-5).sum()
+    names = ["means", "log_scales", "quats", "opacity_logits", "features_dc", "features_rest"]
+    for n, a, b in zip(names, A, B):
+        if n == "features_rest" and K == 1:
+            continue
+        ga, gb = np_(a.grad), np_(b.grad)
+        assert rel_err(gb, ga) < 2e-3, n
+    assert rel_err(np_(xys_grad), np_(xys_a.grad)) < 2e-3
+
+
+def test_fused_sh_kernels_equal_cat_dirs_sh_clamp():
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(10007, 64, 64, K=16, seed=53, yaw_deg=-7.0)
+    raw = _raw_params(s)
+    means, dc, rest = to_dev(s.means), to_dev(raw[3]), to_dev(raw[4])
+    for deg in [0, 1, 2, 3]:
+        col, rgb = cabi.sh_forward_fused(deg, means, raw[5], dc, rest)
+        dirs = means - to_dev(raw[5])
+        dirs = (dirs / dirs.norm(2, -1, True)).contiguous()
+        ref = cabi.sh_forward(deg, dirs, torch.cat([dc[:, None, :], rest], 1).contiguous())
+        assert np.abs(np_(rgb) - np_(ref)).max() < 2e-6
+        assert np.array_equal(np_(col), np.maximum(np_(rgb) + np.float32(0.5), 0))
+        v = to_dev(np.random.RandomState(deg).randn(s.N, 3).astype(np.float32))
+        v_dc, v_rest = cabi.sh_backward_fused(deg, 16, means, raw[5], rgb, v)
+        gref = cabi.sh_backward(deg, 16, dirs, (v * (rgb + 0.5 >= 0)).contiguous())
+        assert np.abs(np_(v_dc) - np_(gref)[:, 0, :]).max() < 1e-6
+        assert np.abs(np_(v_rest) - np_(gref)[:, 1:, :]).max() < 1e-6
+
+
+def test_log_scale_projection_equals_exp_then_project():
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(5000, 203, 117, K=4, seed=57, znear=1.0, zfar=100.0)
+    raw = _raw_params(s)
+    means, quats = to_dev(s.means), to_dev(raw[1])
+    ls = to_dev(raw[0])
+    cam0 = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H)
+    cam1 = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H,
+                            flags=cabi.GS_CAM_LOG_SCALES)
+    a = cabi.project_forward(cam0, means, torch.exp(ls).contiguous(), quats)
+    b = cabi.project_forward(cam1, means, ls, quats)
+    for k in ["xys", "conics", "depths", "cov2d"]:
+        assert rel_err(np_(b[k]), np_(a[k])) < 1e-5, k
+    rs = np.random.RandomState(1)
+    v_xy, v_conic = to_dev(rs.randn(s.N, 2).astype(np.float32)), to_dev(rs.randn(s.N, 3).astype(np.float32))
+    ga = cabi.project_backward(cam0, means, torch.exp(ls).contiguous(), quats, a["radii"], v_xy, v_conic)
+    gb = cabi.project_backward(cam1, means, ls, quats, b["radii"], v_xy, v_conic)
+    assert rel_err(np_(gb["v_means"]), np_(ga["v_means"])) < 1e-4
+    assert rel_err(np_(gb["v_quats"]), np_(ga["v_quats"])) < 1e-4
+    assert rel_err(np_(gb["v_scales"]), np_(ga["v_scales"] * torch.exp(ls))) < 1e-4
