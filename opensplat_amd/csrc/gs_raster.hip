@@ -119,10 +119,27 @@ __device__ __forceinline__ void stage_entry(Staged *dst, const Rec &r, int tile_
 
 __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 
+// Work units.  A wave walking a tile's list alone on its SIMD is latency-bound (~4x slower than
+// its share of a saturated SIMD), and a launch ends with such stragglers: measured ~100 us of
+// each compositing kernel at C2.  Tiles from `split_from` on (in dispatch order) are therefore
+// handled by TWO waves, one per 8-row half (`half` = 0/1, each skipping entries that miss its
+// rows): the tail is made of twice as many units of ~60 % the length.  half = -1: whole tile.
+__device__ __forceinline__ int decode_unit(int block, int split_from, int num_tiles, int &half) {
+    half = -1;
+    int lin = block;
+    if (block >= split_from) {
+        const int r = block - split_from;
+        lin = split_from + (r >> 1);
+        half = r & 1;
+    }
+    return xcd_swizzle(lin, num_tiles);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT, bool PREFETCH>
 __global__ void __launch_bounds__(64)
-k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ ids,
+k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
+                    const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                     float bg1, float bg2, float *__restrict__ out_img,
                     float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
@@ -130,7 +147,10 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
-    const int tile = xcd_swizzle(blockIdx.x, num_tiles);
+    int half;
+    const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
+    // rows of the tile this wave owns, as a filter on the entries' row-mask bits
+    const uint32_t keep = half < 0 ? 0xFFFFFFFFu : (0xFFFFu | (0xFFu << (16 + 8 * half)));
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
     if (EXACT) load_exp_table(exp_tab, lane, 64);
 
@@ -144,7 +164,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
-        const float v = (px < W && py < H) ? (float)py : qnan();
+        const bool mine = half < 0 || (k >> 1) == half;
+        const float v = (px < W && py < H && mine) ? (float)py : qnan();
         if (k & 1) py2[k >> 1].y = v; else py2[k >> 1].x = v;
         last[k] = -1;
     }
@@ -172,7 +193,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         const int n = min(kChunk, range.y - c0);
         for (int t = 0; t < n; t++) {
             const Staged &e = stage[t];
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(e.mask);
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(e.mask) & keep;
             const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(e.smax));
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
             f2 dx2 = e.xx - pxf2;  // {xCam, xCam}
@@ -254,7 +275,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
-        if (px < W && py < H) {
+        if (px < W && py < H && (half < 0 || (k >> 1) == half)) {
             const size_t pix = (size_t)py * W + px;
             const int h = k >> 1;
             const float Tk = (k & 1) ? T2[h].y : T2[h].x;
@@ -335,7 +356,8 @@ __global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ ids,
+k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, int split_from,
+                     const int32_t *__restrict__ ids,
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                      float bg1, float bg2, const float *__restrict__ final_Ts,
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
@@ -344,7 +366,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
-    const int tile = xcd_swizzle(blockIdx.x, num_tiles);
+    int half;
+    const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
+    const uint32_t keep = half < 0 ? 0xFFFFFFFFu : (0xFFFFu | (0xFFu << (16 + 8 * half)));
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
     if (EXACT) load_exp_table(exp_tab, lane, 64);
 
@@ -361,7 +385,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         const int py = tile_y0 + ly + 4 * k;
         float Tfin = 1.0f, o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, oa = 0.0f;
         int l = -1;
-        if (px < W && py < H) {
+        if (px < W && py < H && (half < 0 || (k >> 1) == half)) {
             const size_t pix = (size_t)py * W + px;
             Tfin = final_Ts[pix];
             l = final_idx[pix];
@@ -413,7 +437,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         const int n = min(kChunk, hi - range.x + 1);
         for (int t = 0; t < n; t++) {
             const Staged &en = stage[t];
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(en.mask);
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(en.mask) & keep;
             const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(en.smax));
             const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
             const int e = hi - t;  // index of this entry in the sorted list
@@ -604,6 +628,21 @@ extern "C" int gs_debug_stats(unsigned long long *host16, int reset) {
 }
 #endif
 
+namespace gs {
+// First tile (in dispatch order) handled by two half-tile waves: the last `percent` % of the tiles.
+// Measured at C2 (scripts/ab_raster.py): forward 466 us unsplit, 447 us at 20 %, 463 at 40 %, 531 at
+// 100 %; the backward only loses (733 / 739 / 757 / 866 us) because its per-entry reduction and
+// atomic are paid by both halves — so 20 % forward, 0 % backward.
+// Experimental override for A/B runs: flags bits 8..15 = percent + 1.
+constexpr int kSplitPercentForward = 20, kSplitPercentBackward = 0;
+static inline int split_point(int tiles, uint32_t flags, int pct) {
+    const int o = (int)((flags >> 8) & 0xFFu);
+    if (o) pct = o - 1;
+    if (pct > 100) pct = 100;
+    return tiles - (int)((int64_t)tiles * pct / 100);
+}
+}  // namespace gs
+
 // Test/measurement hook: HIP events recorded immediately before and after the NEXT compositing
 // kernel launched by this thread (k_rasterize_forward or k_rasterize_backward alone, without the
 // memset / record-splitting kernels around it) — bench.py's roofline.achieved uses it.
@@ -650,14 +689,16 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentForward);
+    const int units = split_from + 2 * (tiles - split_from);
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(tiles), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
+        hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(units), dim3(64), 0, s, W, H,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], out_img, final_Ts, final_idx, clamped);
     else
-        hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(tiles), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
+        hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(units), dim3(64), 0, s, W, H,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
@@ -693,15 +734,17 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     float *gacc = static_cast<float *>(workspace);
     GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
+    const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentBackward);
+    const int units = split_from + 2 * (tiles - split_from);
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(tiles), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
+        hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(units), dim3(64), 0, s, W, H,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     else
-        hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(tiles), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, gaussian_ids_sorted, bins, pk, background[0],
+        hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(units), dim3(64), 0, s, W, H,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
                            background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     gs::ev_after(s);
