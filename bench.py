@@ -113,13 +113,22 @@ class Pipeline:
         rgb = cabi.sh_forward(s.degrees_to_use, self.dirs, self.coeffs, out=self.sh_rgb)
         colors = torch.clamp_min(rgb + 0.5, 0.0)  # model.cpp:192
         mark()
-        b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
-                              self.opac, p["cov2d"], self.ws)
+        # binning sized from the previous step's intersection count (no host sync in the middle of
+        # the forward); the count is validated once the forward kernel has been enqueued
+        while True:
+            b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
+                                  self.opac, p["cov2d"], self.ws, speculative=True)
+            mark_bin = torch.cuda.Event(enable_timing=True) if events is not None else None
+            if mark_bin is not None:
+                mark_bin.record()
+            if kernel_events is not None:
+                cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
+            f = cabi.rasterize_forward(s.W, s.H, b, s.background, self.flags, out=self.fwd)
+            if cabi.validate_binning(b):
+                break
         self.num_isects = b.num_isects
-        mark()
-        if kernel_events is not None:
-            cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
-        f = cabi.rasterize_forward(s.W, s.H, b, s.background, self.flags, out=self.fwd)
+        if events is not None:
+            events.append(mark_bin)
         mark()
         if kernel_events is not None:
             cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])

@@ -118,17 +118,18 @@ int gs_sh_backward(int N, int K, int degrees_to_use, const float *dirs, const fl
 
 /* Fused-glue variants (row f1) of the two calls above, replacing torch::cat (model.cpp:114), the
  * view-direction computation (model.cpp:176-177) and clamp_min(rgb + 0.5, 0) (model.cpp:192):
- *   fwd: means[N,3], cam_pos (host float[3]: camera centre in world space), features_dc[N,3],
+ *   fwd: means[N,3], cam_pos (float[3] in host or device memory: camera centre in world space),
+ *        features_dc[N,3],
  *        features_rest[N,K-1,3] (NULL iff K == 1) -> colors[N,3] = max(SH(dir) + 0.5, 0) and
  *        rgb_raw[N,3] = SH(dir), dir = normalize(means - cam_pos)
  *   bwd: v_colors[N,3] (gradient w.r.t. the clamped colours) + rgb_raw -> v_dc[N,3],
  *        v_rest[N,K-1,3]; no gradient to the means (the reference detaches them, model.cpp:176). */
 int gs_sh_forward_fused(int N, int K, int degrees_to_use, const float *means,
-                        const float *cam_pos /*host[3]*/, const float *features_dc,
+                        const float *cam_pos /*host or device [3]*/, const float *features_dc,
                         const float *features_rest, float *colors, float *rgb_raw,
                         gs_stream_t stream);
 int gs_sh_backward_fused(int N, int K, int degrees_to_use, const float *means,
-                         const float *cam_pos /*host[3]*/, const float *rgb_raw,
+                         const float *cam_pos /*host or device [3]*/, const float *rgb_raw,
                          const float *v_colors, float *v_dc, float *v_rest, gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -171,10 +172,15 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
 /* Fills every tile's segment of gaussian_ids_sorted[capacity] with the ids of the Gaussians
  * overlapping the tile, ordered by `depths` (any finite float key sorts correctly; ties in
  * Gaussian-index order) — the result of the reference's global (tile | depth) sort + gather,
- * built with a counting scatter and one on-chip sort per tile.  capacity must be >= M (the
- * total of gs_bin_scan); slots beyond capacity are never written. */
+ * built with a counting scatter and one on-chip sort per tile.
+ * capacity should be >= M (the total of gs_bin_scan).  It may be a guess made WITHOUT reading M
+ * (no host synchronisation between gs_bin_scan and gs_bin_sort): slots beyond capacity are never
+ * written and tile_bins is clamped to capacity, so that the compositing kernels stay inside the
+ * buffer; the caller compares the true M (num_isects_host, valid once the stream has been
+ * synchronised — e.g. after the forward kernel has been enqueued) with capacity and repeats
+ * scan + sort + compositing with a larger buffer if it was exceeded. */
 int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
-                const int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
+                int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
 /* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
@@ -201,10 +207,11 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            64-byte per-Gaussian records in `workspace` (gs_rasterize_backward_workspace_bytes(N)
  *            bytes, 64-byte aligned) and split into the four tensors at the end.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
- *            rasterize_gaussians.cpp:108).  background is a host float[3].               */
+ *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
+ *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
 int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          const int32_t *tile_bins, const float *packed,
-                         const float *background /*host[3]*/, float *out_img, float *final_Ts,
+                         const float *background /*host or device [3]*/, float *out_img, float *final_Ts,
                          int32_t *final_idx,
                          float *out_img_clamped /*[H,W,3], required with GS_FLAG_CLAMP_IMAGE*/,
                          uint32_t flags, gs_stream_t stream);
@@ -213,7 +220,7 @@ size_t gs_rasterize_backward_workspace_bytes(int N);
 
 int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
                           const int32_t *tile_bins, const float *packed,
-                          const float *background /*host[3]*/, const float *final_Ts,
+                          const float *background /*host or device [3]*/, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out,
                           const float *v_out_alpha /*nullable*/,
                           const float *out_img /*raw image, required with GS_FLAG_CLAMP_IMAGE*/,

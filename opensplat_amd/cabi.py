@@ -182,11 +182,13 @@ GS_ERR_CAPACITY = -5
 
 
 def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
-                 workspace: BinWorkspace | None = None, flags=0) -> Binned:
-    """pack -> gs_bin_and_sort (count + scan, one sync to read M, scatter + per-tile sort).
+                 workspace: BinWorkspace | None = None, flags=0, speculative=False) -> Binned:
+    """pack -> count + scan -> scatter + per-tile sort.
 
-    The id buffer and the workspace live in `workspace` and only grow: the first call (and any
-    call whose M exceeds the capacity) pays one retry."""
+    Default: gs_bin_and_sort (one stream sync to read the intersection count M, like the
+    reference).  speculative=True: the id buffer keeps the capacity of earlier calls and NOTHING
+    synchronises; the caller enqueues the forward kernel and then calls validate_binning(), which
+    drains the stream and tells whether M fitted (if not: call again — the buffers have grown)."""
     l = lib()
     N = xys.shape[0]
     dev = xys.device
@@ -204,6 +206,16 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         ws_bytes = l.gs_bin_workspace_bytes(N, cap, W, H)
         ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
         ids = w.get("ids_sorted", (cap,), torch.int32, dev)
+        if speculative:
+            _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
+                                 C.c_void_p(m_host.data_ptr()), _p(ws), C.c_size_t(ws_bytes),
+                                 _stream()), "gs_bin_scan")
+            _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
+                                 _p(depths), _p(tile_bins), _p(ids), _p(ws), C.c_size_t(ws_bytes),
+                                 _stream()), "gs_bin_sort")
+            b = Binned(packed, tiles_hit, -1, ids, tile_bins)
+            b.m_host, b.capacity, b.workspace = m_host, cap, w
+            return b
         rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
                                _p(depths), _p(tile_bins), _p(ids), C.c_void_p(m_host.data_ptr()),
                                _p(ws), C.c_size_t(ws_bytes), _stream())
@@ -214,6 +226,18 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         _check(rc, "gs_bin_and_sort")
         break
     return Binned(packed, tiles_hit, M, ids[:M], tile_bins)
+
+
+def validate_binning(b: Binned) -> bool:
+    """After a speculative bin_and_sort + the forward kernel: drain the stream, read M."""
+    torch.cuda.current_stream().synchronize()
+    M = int(b.m_host[0])
+    b.num_isects = M
+    if M > b.capacity:
+        b.workspace.capacity = M + M // 8 + 1024
+        return False
+    b.gaussian_ids_sorted = b.gaussian_ids_sorted[:M]
+    return True
 
 
 def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):

@@ -528,7 +528,7 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
 
 template <int PL, int B>
 __global__ void __launch_bounds__(64)
-k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int2 *__restrict__ bins,
                    const uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
     constexpr int CAP = 64 * PL, PER = B / 64;
     __shared__ uint64_t out[CAP];
@@ -536,6 +536,11 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict_
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
+    // capacity overflow (the caller sized the id list from a stale count): make the ranges safe to
+    // walk — the compositing kernels then read inside the buffer; the caller detects the overflow
+    // from the true total and repeats the call
+    if (clamp_bins && range.y > capacity && threadIdx.x == 0)
+        bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
     if (n <= lo_n || n > hi_n) return;
     const int lane = threadIdx.x;
     const uint64_t *src = keys + start;
@@ -717,7 +722,7 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
 }
 
 extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed,
-                           const float *depths, const int32_t *tile_bins,
+                           const float *depths, int32_t *tile_bins,
                            int32_t *gaussian_ids_sorted, void *workspace, size_t workspace_bytes,
                            gs_stream_t stream) {
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
@@ -754,11 +759,9 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory
-    hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                       bins, keys, gaussian_ids_sorted);
-    GS_LAUNCH_CHECK();
+    int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
     hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                       capacity, bins, keys, gaussian_ids_sorted);
+                       capacity, 0, bins_rw, keys, gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
     {
         constexpr int CAP = 8192, B = 4096, NT = 256;
@@ -770,6 +773,10 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                            CAP, capacity, bins, keys, gaussian_ids_sorted);
         GS_LAUNCH_CHECK();
     }
+    // (the short class last: it also clamps overflowing ranges, after the others have read them)
+    hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+                       1, bins_rw, keys, gaussian_ids_sorted);
+    GS_LAUNCH_CHECK();
     return GS_OK;
 }
 

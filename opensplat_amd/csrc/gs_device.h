@@ -34,6 +34,18 @@ void set_hip_error(hipError_t e, const char *what);
 
 #define GS_LAUNCH_CHECK() GS_HIP_CHECK(hipGetLastError())
 
+// Small read-only arguments (background colour, camera position) may be handed over as host OR
+// device memory: a device tensor is then read by the kernel itself instead of being copied to the
+// host first (which would synchronise the stream).
+inline bool on_device(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
 // ---- DPP cross-lane primitives --------------------------------------------------------------
 // dpp_ctrl encodings (gfx9): quad_perm = p0|p1<<2|p2<<4|p3<<6; 0x140 row_mirror;
 // 0x141 row_half_mirror.

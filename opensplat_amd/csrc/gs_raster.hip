@@ -141,12 +141,16 @@ __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
                     const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
-                    float bg1, float bg2, float *__restrict__ out_img,
+                    float bg1, float bg2, const float *__restrict__ bg_dev,
+                    float *__restrict__ out_img,
                     float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
                     float *__restrict__ out_clamped) {
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
+    if (bg_dev) {  // background handed over as a device tensor (no host copy, no sync)
+        bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
+    }
     int half;
     const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
     // rows of the tile this wave owns, as a filter on the entries' row-mask bits
@@ -359,13 +363,17 @@ __global__ void __launch_bounds__(64)
 k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, int split_from,
                      const int32_t *__restrict__ ids,
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
-                     float bg1, float bg2, const float *__restrict__ final_Ts,
+                     float bg1, float bg2, const float *__restrict__ bg_dev,
+                     const float *__restrict__ final_Ts,
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                      const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                      float *__restrict__ gacc) {
     __shared__ Staged stage[kChunk];
     __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
+    if (bg_dev) {
+        bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
+    }
     int half;
     const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
     const uint32_t keep = half < 0 ? 0xFFFFFFFFu : (0xFFFFu | (0xFFu << (16 + 8 * half)));
@@ -691,15 +699,16 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentForward);
     const int units = split_from + 2 * (tiles - split_from);
+    const float *bg_dev = gs::on_device(background) ? background : nullptr;
+    const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
+                bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], out_img, final_Ts, final_idx, clamped);
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     else
         hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], out_img, final_Ts, final_idx, clamped);
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -736,16 +745,17 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
     const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentBackward);
     const int units = split_from + 2 * (tiles - split_from);
+    const float *bg_dev = gs::on_device(background) ? background : nullptr;
+    const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
+                bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     else
         hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, background[0],
-                           background[1], background[2], final_Ts, final_idx, v_out, v_out_alpha,
+                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();

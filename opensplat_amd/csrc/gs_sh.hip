@@ -234,10 +234,11 @@ __device__ __forceinline__ void view_dir(const float *__restrict__ means, int64_
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
 k_sh_forward_fused(int N, int nb, const float *__restrict__ means, float cx, float cy, float cz,
-                   const float *__restrict__ dc, const float *__restrict__ rest,
+                   const float *__restrict__ cp_dev, const float *__restrict__ dc, const float *__restrict__ rest,
                    float *__restrict__ colors, float *__restrict__ rgb_raw) {
     constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *slab = smem + wave * (64 * ROWP);
     const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
@@ -285,7 +286,7 @@ k_sh_forward_fused(int N, int nb, const float *__restrict__ means, float cx, flo
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
 k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, float cy, float cz,
-                    const float *__restrict__ rgb_raw, const float *__restrict__ v_colors,
+                    const float *__restrict__ cp_dev, const float *__restrict__ rgb_raw, const float *__restrict__ v_colors,
                     float *__restrict__ v_dc, float *__restrict__ v_rest) {
     constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -293,6 +294,7 @@ k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, fl
     float *slab = smem + wave * (64 * ROWP);
     const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
     const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
     if (lane < cnt) {
         const int64_t g = g0 + lane;
         float x, y, z;
@@ -339,8 +341,10 @@ static int launch_fwd_fused(int N, int nb, const float *means, const float *cp, 
                             const float *rest, float *colors, float *rgb_raw, hipStream_t s) {
     constexpr int BLK = ShSplit<K>::kBlock;
     size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    const bool dev = on_device(cp);
     hipLaunchKernelGGL(k_sh_forward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
-                       means, cp[0], cp[1], cp[2], dc, rest, colors, rgb_raw);
+                       means, dev ? 0.f : cp[0], dev ? 0.f : cp[1], dev ? 0.f : cp[2],
+                       dev ? cp : nullptr, dc, rest, colors, rgb_raw);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
@@ -350,8 +354,10 @@ static int launch_bwd_fused(int N, int nb, const float *means, const float *cp, 
                             const float *v_colors, float *v_dc, float *v_rest, hipStream_t s) {
     constexpr int BLK = ShSplit<K>::kBlock;
     size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    const bool dev = on_device(cp);
     hipLaunchKernelGGL(k_sh_backward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
-                       means, cp[0], cp[1], cp[2], rgb_raw, v_colors, v_dc, v_rest);
+                       means, dev ? 0.f : cp[0], dev ? 0.f : cp[1], dev ? 0.f : cp[2],
+                       dev ? cp : nullptr, rgb_raw, v_colors, v_dc, v_rest);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

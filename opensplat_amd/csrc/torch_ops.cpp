@@ -65,6 +65,13 @@ const float *matrix_arg(const Tensor &m, Tensor &holder, float *host_dst) {
     return nullptr;
 }
 
+// float[3] arguments (background, camera position): the kernels read host or device memory, so a
+// device tensor is handed over as it is — no copy to the host, no synchronisation
+const float *vec3_arg(const Tensor &t, Tensor &holder) {
+    holder = t.detach().to(torch::kFloat32).contiguous();
+    return holder.data_ptr<float>();
+}
+
 }  // namespace
 
 void gsplatSetFastExp(bool enabled) { g_fast_exp.store(enabled); }
@@ -167,7 +174,9 @@ tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_ou
 }
 
 // ---- binning ------------------------------------------------------------------------------------
-std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
+static std::atomic<int64_t> g_capacityHint{0};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
     const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth,
     bool opacityIsLogit) {
@@ -186,34 +195,35 @@ std::tuple<Tensor, Tensor, Tensor, int64_t> binAndSortGaussians(
                                 opacityIsLogit ? GS_FLAG_LOGIT_OPACITY : 0u, s),
                  "gs_pack_splats");
 
-    // The intersection count sizes the id list: one pinned int, one stream sync inside
-    // gs_bin_and_sort — the same place the reference blocks (rasterize_gaussians.cpp:62-63).
-    // The capacity guess is the last count seen by this process (+12.5 %); a miss costs one retry.
-    static std::atomic<int64_t> capacityHint{0};
+    // The id list is sized from the last intersection count this process saw (+12.5 %) and the
+    // count of THIS call is only read back after the caller has enqueued the compositing kernel
+    // (validateBinning): the stream never idles waiting for the host, where the reference blocks
+    // in the middle of the forward (rasterize_gaussians.cpp:62-63).  A stale guess costs one repeat.
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     Tensor tileBins = torch::empty({tiles, 2}, i32);
     Tensor mHost = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    Tensor idsSorted;
-    int64_t M = 0;
-    for (;;) {
-        int64_t cap = std::max<int64_t>(capacityHint.load(), 1024);
-        idsSorted = torch::empty({cap}, i32);
-        size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
-        Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
-        int rc = gs_bin_and_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
-                                 tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                                 mHost.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s);
-        M = mHost.data_ptr<int32_t>()[0];
-        if (rc == GS_ERR_CAPACITY) {
-            capacityHint.store(M + M / 8 + 1024);
-            continue;
-        }
-        check_status(rc, "gs_bin_and_sort");
-        capacityHint.store(M + M / 8 + 1024);
-        break;
-    }
-    idsSorted = idsSorted.narrow(0, 0, M);
-    return std::make_tuple(packed, idsSorted, tileBins, M);
+    const int64_t cap = std::max<int64_t>(g_capacityHint.load(), 1024);
+    Tensor idsSorted = torch::empty({cap}, i32);
+    size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
+    Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
+    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
+                             mHost.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
+                 "gs_bin_scan");
+    check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
+                             tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
+                             ws.data_ptr(), wsBytes, s),
+                 "gs_bin_sort");
+    return std::make_tuple(packed, idsSorted, tileBins, mHost);
+}
+
+// Blocks until the stream has drained, then checks the intersection count of the binning against
+// the capacity it ran with.  false -> the lists were truncated: repeat binning + compositing.
+bool validateBinning(const Tensor &mHost, const Tensor &idsSorted) {
+    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
+    const int64_t M = mHost.data_ptr<int32_t>()[0];
+    g_capacityHint.store(M + M / 8 + 1024);
+    return M <= idsSorted.size(0);
+
 }
 
 // ---- RasterizeGaussians -------------------------------------------------------------------------
@@ -244,29 +254,30 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     conics = conics.contiguous(); colors = colors.contiguous(); opacity = opacity.contiguous();
     const int W = (int)imgWidth, H = (int)imgHeight;
 
-    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
-    Tensor packed = std::get<0>(b), idsSorted = std::get<1>(b), tileBins = std::get<2>(b);
-
-    Tensor bgHost = background.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-    const float *bg = bgHost.data_ptr<float>();
+    uint32_t flags = g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u;
+    Tensor bgHold;
+    const float *bg = vec3_arg(background, bgHold);
     auto f32 = xys.options();
     Tensor outImg = torch::empty({H, W, 3}, f32), finalTs = torch::empty({H, W}, f32);
     Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
-    const uint32_t flags = g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u;
-    check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
-                                      tileBins.data_ptr<int32_t>(), fptr(packed), bg,
-                                      fptr_mut(outImg), fptr_mut(finalTs),
-                                      finalIdx.data_ptr<int32_t>(), nullptr, flags, current_stream()),
-                 "gs_rasterize_forward");
+    Tensor packed, idsSorted, tileBins;
+    for (;;) {
+        auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
+        packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
+        check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
+                                          tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                          fptr_mut(outImg), fptr_mut(finalTs),
+                                          finalIdx.data_ptr<int32_t>(), nullptr, flags,
+                                          current_stream()),
+                     "gs_rasterize_forward");
+        if (validateBinning(std::get<3>(b), idsSorted)) break;
+    }
 
     ctx->saved_data["imgWidth"] = imgWidth;
     ctx->saved_data["imgHeight"] = imgHeight;
-    ctx->saved_data["bg0"] = (double)bg[0];
-    ctx->saved_data["bg1"] = (double)bg[1];
-    ctx->saved_data["bg2"] = (double)bg[2];
     ctx->saved_data["flags"] = (int64_t)flags;
     ctx->saved_data["numPoints"] = N;
-    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx});
+    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold});
     return outImg;
 }
 
@@ -275,13 +286,11 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     const int64_t N = ctx->saved_data["numPoints"].toInt();
     variable_list saved = ctx->get_saved_variables();
     Tensor idsSorted = saved[0], tileBins = saved[1], packed = saved[2];
-    Tensor finalTs = saved[3], finalIdx = saved[4];
+    Tensor finalTs = saved[3], finalIdx = saved[4], bgHold = saved[5];
     c10::DeviceGuard guard(packed.device());
     Tensor v_outImg = grad_outputs[0].contiguous();
     GS_CHECK_F32(v_outImg);
-    const float bg[3] = {(float)ctx->saved_data["bg0"].toDouble(),
-                         (float)ctx->saved_data["bg1"].toDouble(),
-                         (float)ctx->saved_data["bg2"].toDouble()};
+    const float *bg = bgHold.data_ptr<float>();
     auto f32 = packed.options();
     Tensor v_xy = torch::empty({N, 2}, f32), v_conic = torch::empty({N, 3}, f32);
     Tensor v_colors = torch::empty({N, 3}, f32), v_opacity = torch::empty({N, 1}, f32);
@@ -378,9 +387,8 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     Tensor vmHold, pmHold;
     const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
     const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
-    Tensor cpHost = camPos.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-    Tensor bgHost = background.detach().to(torch::kCPU, torch::kFloat32).contiguous();
-    const float *cp = cpHost.data_ptr<float>(), *bg = bgHost.data_ptr<float>();
+    Tensor cpHold;
+    const float *cp = vec3_arg(camPos, cpHold);
 
     auto f32 = means.options();
     auto i32 = means.options().dtype(torch::kInt32);
@@ -399,25 +407,27 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
                                      fptr(featuresDc), hasRest ? fptr(featuresRest) : nullptr,
                                      fptr_mut(colors), fptr_mut(rgbRaw), s),
                  "gs_sh_forward_fused");
-    auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacityLogits, cov2d, H, W, true);
-    Tensor packed = std::get<0>(b), idsSorted = std::get<1>(b), tileBins = std::get<2>(b);
     Tensor imgRaw = torch::empty({H, W, 3}, f32), img = torch::empty({H, W, 3}, f32);
     Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
-    const uint32_t flags = (g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u) | GS_FLAG_CLAMP_IMAGE |
-                           GS_FLAG_LOGIT_OPACITY;
-    check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
-                                      tileBins.data_ptr<int32_t>(), fptr(packed), bg,
-                                      fptr_mut(imgRaw), fptr_mut(finalTs),
-                                      finalIdx.data_ptr<int32_t>(), fptr_mut(img), flags, s),
-                 "gs_rasterize_forward");
+    uint32_t flags = (g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u) | GS_FLAG_CLAMP_IMAGE |
+                     GS_FLAG_LOGIT_OPACITY;
+    Tensor bgHold;
+    const float *bg = vec3_arg(background, bgHold);
+    Tensor packed, idsSorted, tileBins;
+    for (;;) {
+        auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacityLogits, cov2d, H, W, true);
+        packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
+        check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
+                                          tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                          fptr_mut(imgRaw), fptr_mut(finalTs),
+                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), flags, s),
+                     "gs_rasterize_forward");
+        if (validateBinning(std::get<3>(b), idsSorted)) break;
+    }
 
     ctx->saved_data["imgWidth"] = imgWidth; ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
     ctx->saved_data["cx"] = cx; ctx->saved_data["cy"] = cy;
-    ctx->saved_data["bg0"] = (double)bg[0]; ctx->saved_data["bg1"] = (double)bg[1];
-    ctx->saved_data["bg2"] = (double)bg[2];
-    ctx->saved_data["cp0"] = (double)cp[0]; ctx->saved_data["cp1"] = (double)cp[1];
-    ctx->saved_data["cp2"] = (double)cp[2];
     ctx->saved_data["flags"] = (int64_t)flags;
     ctx->saved_data["K"] = K; ctx->saved_data["degreesToUse"] = degreesToUse;
     Tensor gradOut = (xysGradOut.has_value() && xysGradOut->defined()) ? *xysGradOut : Tensor();
@@ -427,7 +437,7 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     }
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
-                            gradOut.defined() ? gradOut : torch::empty({0}, f32)});
+                            gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};
@@ -437,17 +447,15 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     variable_list sv = ctx->get_saved_variables();
     Tensor means = sv[0], logScales = sv[1], quats = sv[2], viewMat = sv[3], projMat = sv[4];
     Tensor radii = sv[5], rgbRaw = sv[6], idsSorted = sv[7], tileBins = sv[8], packed = sv[9];
-    Tensor finalTs = sv[10], finalIdx = sv[11], imgRaw = sv[12], gradOut = sv[13];
+    Tensor finalTs = sv[10], finalIdx = sv[11], imgRaw = sv[12], gradOut = sv[13], bgHold = sv[14], cpHold = sv[15];
     const int64_t N = means.size(0), K = ctx->saved_data["K"].toInt();
     const int W = (int)ctx->saved_data["imgWidth"].toInt(), H = (int)ctx->saved_data["imgHeight"].toInt();
     c10::DeviceGuard guard(means.device());
     gs_stream_t s = current_stream();
     Tensor v_img = grad_outputs[0].contiguous();
     GS_CHECK_F32(v_img);
-    const float bg[3] = {(float)ctx->saved_data["bg0"].toDouble(), (float)ctx->saved_data["bg1"].toDouble(),
-                         (float)ctx->saved_data["bg2"].toDouble()};
-    const float cp[3] = {(float)ctx->saved_data["cp0"].toDouble(), (float)ctx->saved_data["cp1"].toDouble(),
-                         (float)ctx->saved_data["cp2"].toDouble()};
+    const float *bg = bgHold.data_ptr<float>();
+    const float *cp = cpHold.data_ptr<float>();
     auto f32 = means.options();
     Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : torch::empty({N, 2}, f32);
     Tensor v_conic = torch::empty({N, 3}, f32), v_colors = torch::empty({N, 3}, f32);
