@@ -428,3 +428,32 @@ def test_equal_depths_fall_back_to_the_network_sort(N):
         seg = ids[a:e]
         want = np.array(sorted(seg.tolist(), key=lambda g: (d[g], g)), dtype=seg.dtype)
         assert np.array_equal(seg, want)
+
+
+def test_speculative_binning_survives_a_too_small_id_buffer():
+    """No host sync between scan and sort: the id list is sized from a guess.  A guess that is too
+    small must not make any kernel leave its buffers (tile ranges are clamped), must be reported
+    by validate_binning(), and the repeated call must give the synchronous path's result."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(20000, 320, 200, K=0, seed=61, znear=1.0, zfar=100.0)
+    ref = hip_pipeline(s, backward=False)
+    p = ref
+    opac = to_dev(s.opacities.reshape(-1))
+    ws = cabi.BinWorkspace()
+    assert ws.capacity == 0                                   # -> 1024 slots, far below M
+    b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], p["colors"], opac,
+                          p["cov2d"], ws, speculative=True)
+    f = cabi.rasterize_forward(s.W, s.H, b, s.background)
+    assert not cabi.validate_binning(b)
+    assert b.num_isects == ref["binned"].num_isects > 1024
+    assert int(np_(b.tile_bins).max()) <= 1024                # clamped to the capacity
+    b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], p["colors"], opac,
+                          p["cov2d"], ws, speculative=True)
+    f = cabi.rasterize_forward(s.W, s.H, b, s.background)
+    assert cabi.validate_binning(b)
+    torch.cuda.synchronize()
+    assert np.array_equal(np_(f["img"]), np_(ref["img"]))
+    assert np.array_equal(np_(b.gaussian_ids_sorted), np_(ref["binned"].gaussian_ids_sorted))
