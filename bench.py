@@ -2,9 +2,16 @@
 """bench.py — full forward+backward rasterizations per second of the MI355X rasterizer.
 
 One "step" = one complete pass of the hot path over one camera (BASELINE.json metric):
-    project fwd -> SH fwd -> clamp_min(+0.5) -> pack/scan/sort/bin -> composite fwd
-    -> composite bwd -> clamp backward -> SH bwd -> project bwd   [-> RCCL all-reduce if N > 1]
-producing the image and all six parameter gradients.  Every stage goes through the C ABI of
+    project fwd -> SH fwd (+0.5, clamp_min 0) -> pack / count / scan / scatter / per-tile sort
+    -> composite fwd -> composite bwd -> SH bwd (clamp mask) -> project bwd
+    [-> RCCL all-reduce if N > 1]
+producing the image and the gradients of OpenSplat's six parameter tensors (means, scales, quats,
+opacities, featuresDc, featuresRest).  The element-wise glue between the three operators
+(model.cpp:114,176-177,192: cat, view directions, +0.5 / clamp_min) runs inside the SH kernels
+(row f1 variants gs_sh_forward_fused / gs_sh_backward_fused) — same arithmetic, no extra passes.
+The intersection count that sizes the id list is taken from the previous step and validated once
+per step after everything has been enqueued (see gs_bin_sort in include/gsplat_hip.h); a step
+whose guess was too small is repeated inside the timed region.  Every stage goes through the C ABI of
 libgsplat_hip.so (include/gsplat_hip.h); torch only provides device memory, the stream and, for
 N > 1, torch.distributed (nccl == RCCL).
 
@@ -66,7 +73,11 @@ class Pipeline:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.means, self.scales, self.quats = t(s.means), t(s.scales), t(s.quats)
         self.opac = t(s.opacities.reshape(-1))
-        self.dirs, self.coeffs = t(s.dirs), t(s.sh_coeffs)
+        self.features_dc = t(s.sh_coeffs[:, 0, :])      # as OpenSplat stores them (model.hpp)
+        self.features_rest = t(s.sh_coeffs[:, 1:, :])
+        R, tr = s.viewmat[:3, :3], s.viewmat[:3, 3]
+        self.cam_pos = t((-R.T @ tr).astype(np.float32))   # camera centre, model.cpp:95
+        self.background = t(np.asarray(s.background, dtype=np.float32))
         self.v_out = t(s.v_out)
         self.vm_dev, self.pm_dev = t(s.viewmat), t(s.projmat)
         self.cam = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H)
@@ -77,7 +88,7 @@ class Pipeline:
                          radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
                          num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
                          cov2d=torch.empty((N, 3), **f))
-        self.sh_rgb = torch.empty((N, 3), **f)
+        self.sh_out = (torch.empty((N, 3), **f), torch.empty((N, 3), **f))  # colours, raw rgb
         self.ws = cabi.BinWorkspace()
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i))
@@ -85,12 +96,15 @@ class Pipeline:
         self.bwd_ws = torch.empty((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
                                   device=dev, dtype=torch.uint8)
         self.g2d = torch.zeros(N * 9, **f)
-        self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
-                           v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.g2d[8 * N:])
         self.grads = dist.GradBuffer(N, K, dev)
+        # the opacity gradient goes straight into the flat all-reduce buffer
+        self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
+                           v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.grads.v_opacity)
         self.pb_out = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
                            v_quats=self.grads.v_quats)
         self.num_isects = 0
+        self.multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size() > 1
         self.stage_names = ["project_fwd", "sh_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
                             "sh_bwd", "project_bwd", "allreduce"]
 
@@ -106,44 +120,60 @@ class Pipeline:
                 e.record()
                 events.append(e)
 
-        mark()
-        p = cabi.project_forward(self.cam, self.means, self.scales, self.quats, self.vm_dev,
-                                 self.pm_dev, out=self.proj)
-        mark()
-        rgb = cabi.sh_forward(s.degrees_to_use, self.dirs, self.coeffs, out=self.sh_rgb)
-        colors = torch.clamp_min(rgb + 0.5, 0.0)  # model.cpp:192
-        mark()
-        # binning sized from the previous step's intersection count (no host sync in the middle of
-        # the forward); the count is validated once the forward kernel has been enqueued
         while True:
+            ev_local = []
+
+            def mark():
+                if events is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    ev_local.append(e)
+
+            mark()
+            p = cabi.project_forward(self.cam, self.means, self.scales, self.quats, self.vm_dev,
+                                     self.pm_dev, out=self.proj)
+            mark()
+            colors, rgb_raw = cabi.sh_forward_fused(s.degrees_to_use, self.means, self.cam_pos,
+                                                    self.features_dc, self.features_rest,
+                                                    out=self.sh_out)
+            mark()
             b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
                                   self.opac, p["cov2d"], self.ws, speculative=True)
-            mark_bin = torch.cuda.Event(enable_timing=True) if events is not None else None
-            if mark_bin is not None:
-                mark_bin.record()
+            mark()
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
-            f = cabi.rasterize_forward(s.W, s.H, b, s.background, self.flags, out=self.fwd)
-            if cabi.validate_binning(b):
+            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
+            mark()
+            if kernel_events is not None:
+                cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
+            g = cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"],
+                                        f["final_idx"], self.v_out, self.flags, out=self.rgrads,
+                                        workspace=self.bwd_ws)
+            mark()
+            # the one host<->device rendezvous of the step: was the id list large enough?  With
+            # several ranks it has to happen before the first collective (a rank repeating its step
+            # alone would leave the others waiting), otherwise after everything has been enqueued.
+            if self.multi and not cabi.validate_binning(b):
+                continue
+            cabi.sh_backward_fused(s.degrees_to_use, s.K, self.means, self.cam_pos, rgb_raw,
+                                   g["v_colors"], out=(self.grads.v_dc, self.grads.v_rest))
+            w1 = self.dist.allreduce_sh_async(self.grads)  # overlaps the projection backward
+            mark()
+            cabi.project_backward(self.cam, self.means, self.scales, self.quats, p["radii"], g["v_xy"],
+                                  g["v_conic"], None, self.vm_dev, self.pm_dev, out=self.pb_out)
+            mark()
+            if self.multi or cabi.validate_binning(b):
                 break
         self.num_isects = b.num_isects
         if events is not None:
-            events.append(mark_bin)
-        mark()
-        if kernel_events is not None:
-            cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
-        g = cabi.rasterize_backward(s.W, s.H, s.N, b, s.background, f["final_Ts"], f["final_idx"],
-                                    self.v_out, self.flags, out=self.rgrads, workspace=self.bwd_ws)
-        mark()
-        v_rgb = g["v_colors"] * (rgb > -0.5)  # backward of clamp_min(rgb + 0.5, 0)
-        cabi.sh_backward(s.degrees_to_use, s.K, self.dirs, v_rgb, out=self.grads.v_sh)
-        w1 = self.dist.allreduce_sh_async(self.grads)  # overlaps the projection backward
-        mark()
-        # opacity gradient: the op surface returns d/d(sigmoid(opacity)); copy into the flat buffer
-        self.grads.v_opacity.copy_(g["v_opacity"])
-        cabi.project_backward(self.cam, self.means, self.scales, self.quats, p["radii"], g["v_xy"],
-                              g["v_conic"], None, self.vm_dev, self.pm_dev, out=self.pb_out)
-        mark()
+            events.extend(ev_local)
+
+        def mark():
+            if events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                events.append(e)
+
         w2 = self.dist.allreduce_rest_async(self.grads)
         self.dist.wait_all(w1, w2)
         mark()

@@ -246,7 +246,7 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
         out = dict(img=torch.empty((H, W, 3), device=dev, dtype=torch.float32),
                    final_Ts=torch.empty((H, W), device=dev, dtype=torch.float32),
                    final_idx=torch.empty((H, W), device=dev, dtype=torch.int32))
-    bg = (C.c_float * 3)(*[float(b) for b in background])
+    bg = _vec3(background)
     _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
                                       _p(out["final_Ts"]), _p(out["final_idx"]),
@@ -264,7 +264,7 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
     ws_bytes = lib().gs_rasterize_backward_workspace_bytes(N)
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
-    bg = (C.c_float * 3)(*[float(b) for b in background])
+    bg = _vec3(background)
     _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N),
                                        _p(binned.gaussian_ids_sorted), _p(binned.tile_bins),
                                        _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
@@ -298,24 +298,35 @@ def time_next_kernel(ev_start, ev_stop):
            "gs_debug_time_next_kernel")
 
 
-def sh_forward_fused(degrees_to_use, means, cam_pos, features_dc, features_rest):
+def _vec3(v):
+    """float[3] argument: a device tensor is passed as a device pointer, anything else by value."""
+    if isinstance(v, torch.Tensor) and v.is_cuda:
+        return _p(v)
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def sh_forward_fused(degrees_to_use, means, cam_pos, features_dc, features_rest, out=None):
     """-> (colors = max(SH + 0.5, 0), rgb_raw); features_rest [N, K-1, 3] or None for K = 1."""
     N = means.shape[0]
     K = 1 + (features_rest.shape[1] if features_rest is not None else 0)
-    colors = torch.empty((N, 3), device=means.device, dtype=torch.float32)
-    raw = torch.empty((N, 3), device=means.device, dtype=torch.float32)
-    cp = (C.c_float * 3)(*[float(v) for v in cam_pos])
+    if out is None:
+        out = (torch.empty((N, 3), device=means.device, dtype=torch.float32),
+               torch.empty((N, 3), device=means.device, dtype=torch.float32))
+    colors, raw = out
+    cp = _vec3(cam_pos)
     _check(lib().gs_sh_forward_fused(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(means), cp,
                                      _p(features_dc), _p(features_rest), _p(colors), _p(raw),
                                      _stream()), "gs_sh_forward_fused")
     return colors, raw
 
 
-def sh_backward_fused(degrees_to_use, K, means, cam_pos, rgb_raw, v_colors):
+def sh_backward_fused(degrees_to_use, K, means, cam_pos, rgb_raw, v_colors, out=None):
     N = means.shape[0]
-    v_dc = torch.empty((N, 3), device=means.device, dtype=torch.float32)
-    v_rest = torch.empty((N, K - 1, 3), device=means.device, dtype=torch.float32) if K > 1 else None
-    cp = (C.c_float * 3)(*[float(v) for v in cam_pos])
+    if out is None:
+        out = (torch.empty((N, 3), device=means.device, dtype=torch.float32),
+               torch.empty((N, K - 1, 3), device=means.device, dtype=torch.float32) if K > 1 else None)
+    v_dc, v_rest = out
+    cp = _vec3(cam_pos)
     _check(lib().gs_sh_backward_fused(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), _p(means), cp,
                                       _p(rgb_raw), _p(v_colors), _p(v_dc), _p(v_rest), _stream()),
            "gs_sh_backward_fused")

@@ -336,6 +336,56 @@ k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, fl
     }
 }
 
+// K = 16 fused forward, four lanes per Gaussian (see k_sh_forward16_quad): lane q combines the
+// coefficients c = 12q .. 12q+11 of the virtual [dc | rest] row.  Rows of features_rest are 180 bytes,
+// so the 16-byte loads are only 4-byte aligned — gfx950 global loads allow that.
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ void __launch_bounds__(256)
+k_sh_forward_fused16_quad(int N, int nb, const float *__restrict__ means, float cx, float cy,
+                          float cz, const float *__restrict__ cp_dev, const float *__restrict__ dc,
+                          const float *__restrict__ rest, float *__restrict__ colors,
+                          float *__restrict__ rgb_raw) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = t >> 2;
+    const int q = (int)(t & 3);
+    if (g >= N) return;  // whole quads drop out together
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
+    float x, y, z;
+    view_dir(means, g, cx, cy, cz, x, y, z);
+    float r[25];
+    sh_basis(nb, x, y, z, r);
+    const float *row = rest + g * 45;
+    float4_u a, b, c;
+    if (q == 0) {  // {dc0 dc1 dc2 r0 | r1 r2 r3 r4 | r5 r6 r7 r8}
+        a.x = dc[3 * g]; a.y = dc[3 * g + 1]; a.z = dc[3 * g + 2]; a.w = row[0];
+        b = *reinterpret_cast<const float4_u *>(row + 1);
+        c = *reinterpret_cast<const float4_u *>(row + 5);
+    } else {
+        const float *p = row + 12 * q - 3;
+        a = *reinterpret_cast<const float4_u *>(p);
+        b = *reinterpret_cast<const float4_u *>(p + 4);
+        c = *reinterpret_cast<const float4_u *>(p + 8);
+    }
+    const float r0 = q == 0 ? r[0] : q == 1 ? r[4] : q == 2 ? r[8] : r[12];
+    const float r1 = q == 0 ? r[1] : q == 1 ? r[5] : q == 2 ? r[9] : r[13];
+    const float r2 = q == 0 ? r[2] : q == 1 ? r[6] : q == 2 ? r[10] : r[14];
+    const float r3 = q == 0 ? r[3] : q == 1 ? r[7] : q == 2 ? r[11] : r[15];
+    float c0 = r0 * a.x + r1 * a.w + r2 * b.z + r3 * c.y;
+    float c1 = r0 * a.y + r1 * b.x + r2 * b.w + r3 * c.z;
+    float c2 = r0 * a.z + r1 * b.y + r2 * c.x + r3 * c.w;
+    c0 += dpp_f<0xB1>(c0); c1 += dpp_f<0xB1>(c1); c2 += dpp_f<0xB1>(c2);  // quad_perm [1,0,3,2]
+    c0 += dpp_f<0x4E>(c0); c1 += dpp_f<0x4E>(c1); c2 += dpp_f<0x4E>(c2);  // quad_perm [2,3,0,1]
+    if (q == 0) {
+        rgb_raw[3 * g + 0] = c0;
+        rgb_raw[3 * g + 1] = c1;
+        rgb_raw[3 * g + 2] = c2;
+        colors[3 * g + 0] = fmaxf(c0 + 0.5f, 0.0f);
+        colors[3 * g + 1] = fmaxf(c1 + 0.5f, 0.0f);
+        colors[3 * g + 2] = fmaxf(c2 + 0.5f, 0.0f);
+    }
+}
+
 template <int K>
 static int launch_fwd_fused(int N, int nb, const float *means, const float *cp, const float *dc,
                             const float *rest, float *colors, float *rgb_raw, hipStream_t s) {
@@ -433,7 +483,16 @@ extern "C" int gs_sh_forward_fused(int N, int K, int degrees_to_use, const float
     case 1: return gs::launch_fwd_fused<1>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     case 4: return gs::launch_fwd_fused<4>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     case 9: return gs::launch_fwd_fused<9>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
-    case 16: return gs::launch_fwd_fused<16>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
+    case 16: {
+        const bool dev = gs::on_device(cam_pos);
+        const int64_t threads = (int64_t)N * 4;
+        hipLaunchKernelGGL(gs::k_sh_forward_fused16_quad, dim3((unsigned)((threads + 255) / 256)),
+                           dim3(256), 0, s, N, nb, means, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
+                           dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr, features_dc, features_rest,
+                           colors, rgb_raw);
+        GS_LAUNCH_CHECK();
+        return GS_OK;
+    }
     default: return gs::launch_fwd_fused<25>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     }
 }

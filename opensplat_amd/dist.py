@@ -5,9 +5,10 @@ The reference has no distributed code at all; the partitioning
 BASELINE.json's north_star.  `torch.distributed` backend "nccl" is RCCL on ROCm (xGMI between the
 8 GPUs of a node); the CPU tests run the same code over "gloo".
 
-GradBuffer lays the six gradient tensors out in ONE flat fp32 buffer, SH first:
+GradBuffer lays the gradient tensors of OpenSplat's six parameter groups (model.hpp: means, scales,
+quats, featuresDc, featuresRest, opacities) out in ONE flat fp32 buffer, SH first:
 
-    [ v_sh N*K*3 | v_means N*3 | v_scales N*3 | v_quats N*4 | v_opacity N ]
+    [ v_features_rest N*(K-1)*3 | v_features_dc N*3 | v_means N*3 | v_scales N*3 | v_quats N*4 | v_opacity N ]
 
 so that (a) the backward kernels write straight into it through the C ABI (no gather copy),
 (b) the SH block — 81 % of the bytes at K = 16 — can be all-reduced as soon as SH-backward has
@@ -27,8 +28,8 @@ class GradBuffer:
     def __init__(self, N: int, K: int, device):
         self.N, self.K = N, K
         kk = max(K, 1)
-        sizes = [("v_sh", N * kk * 3), ("v_means", N * 3), ("v_scales", N * 3), ("v_quats", N * 4),
-                 ("v_opacity", N)]
+        sizes = [("v_rest", N * (kk - 1) * 3), ("v_dc", N * 3), ("v_means", N * 3),
+                 ("v_scales", N * 3), ("v_quats", N * 4), ("v_opacity", N)]
         total = sum(n for _, n in sizes)
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = {}
@@ -36,8 +37,9 @@ class GradBuffer:
         for name, n in sizes:
             self.views[name] = self.flat[o:o + n]
             o += n
-        self.sh_numel = sizes[0][1]
-        self.v_sh = self.views["v_sh"].view(N, kk, 3) if K > 0 else self.views["v_sh"].view(N, 3)
+        self.sh_numel = sizes[0][1] + sizes[1][1]
+        self.v_rest = self.views["v_rest"].view(N, kk - 1, 3)
+        self.v_dc = self.views["v_dc"].view(N, 3)
         self.v_means = self.views["v_means"].view(N, 3)
         self.v_scales = self.views["v_scales"].view(N, 3)
         self.v_quats = self.views["v_quats"].view(N, 4)

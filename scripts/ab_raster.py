@@ -17,8 +17,8 @@ pipe = bench.Pipeline(s, torch.device("cuda:0"), 0)
 pipe.step()
 torch.cuda.synchronize()
 p = pipe.proj
-rgb = cabi.sh_forward(s.degrees_to_use, pipe.dirs, pipe.coeffs, out=pipe.sh_rgb)
-colors = torch.clamp_min(rgb + 0.5, 0.0)
+colors, _ = cabi.sh_forward_fused(s.degrees_to_use, pipe.means, pipe.cam_pos, pipe.features_dc,
+                                  pipe.features_rest)
 b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors, pipe.opac,
                       p["cov2d"], pipe.ws)
 

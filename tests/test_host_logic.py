@@ -49,15 +49,16 @@ def test_grad_buffer_layout():
     g = GradBuffer(N, K, torch.device("cpu"))
     assert g.flat.numel() == N * (3 * K + 3 + 3 + 4 + 1) == N * 59
     assert g.nbytes == 4 * N * 59                                  # 236 B/Gaussian
-    g.v_sh.fill_(1); g.v_means.fill_(2); g.v_scales.fill_(3); g.v_quats.fill_(4); g.v_opacity.fill_(5)
+    g.v_rest.fill_(1); g.v_dc.fill_(6); g.v_means.fill_(2); g.v_scales.fill_(3); g.v_quats.fill_(4)
+    g.v_opacity.fill_(5)
     f = g.flat
     o = 0
-    for val, n in [(1, N * K * 3), (2, N * 3), (3, N * 3), (4, N * 4), (5, N)]:
+    for val, n in [(1, N * (K - 1) * 3), (6, N * 3), (2, N * 3), (3, N * 3), (4, N * 4), (5, N)]:
         assert (f[o:o + n] == val).all()
         o += n
     assert g.sh_block().numel() + g.rest_block().numel() == f.numel()
     assert g.sh_block().data_ptr() == f.data_ptr()
-    assert g.v_sh.is_contiguous() and g.v_quats.is_contiguous()
+    assert g.v_rest.is_contiguous() and g.v_dc.is_contiguous() and g.v_quats.is_contiguous()
     assert abs(g.sh_block().numel() / f.numel() - 48 / 59) < 1e-9  # 81 % of the bytes
 
 
