@@ -161,8 +161,8 @@ size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
 
 /* Counts the intersections of every 16x16 tile (rectangles of the packed records) and scans the
  * counts:  tile_bins[tiles,2] = [start, end) of each tile's segment in the sorted id list.
- * The total M is also copied (async, on `stream`) to *num_isects_host, which must be pinned host
- * memory or NULL; the caller synchronises the stream before reading it (the reference syncs at
+ * The total M is also stored (by the scan kernel itself, in stream order) to *num_isects_host,
+ * which must be PINNED, device-mapped host memory (hipHostMalloc / a torch pinned tensor) or NULL; the caller synchronises the stream before reading it (the reference syncs at
  * the same place, rasterize_gaussians.cpp:63) — or does not read it at all and passes a
  * sufficient capacity to gs_bin_sort. */
 int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,

@@ -201,14 +201,16 @@ __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
-             int32_t *__restrict__ total_dev) {
+             int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host) {
     extern __shared__ int32_t c_lds[];
     __shared__ int32_t part[1024];
     const int t = threadIdx.x;
     const int per = (tiles + 1023) / 1024;
     const int lo = min(t * per, tiles), hi = min(lo + per, tiles);
     if (use_lds) {
-        for (int i = t; i < tiles; i += 1024) c_lds[skew(i)] = counts[i];
+        for (int i = t; i < tiles; i += 1024) {
+            c_lds[skew(i)] = counts[i];
+        }
         __syncthreads();
     }
     int32_t sum = 0;
@@ -244,7 +246,11 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
             run += c;
         }
     }
-    if (t == 1023) *total_dev = part[1023];
+    if (t == 1023) {
+        *total_dev = part[1023];
+        // pinned (device-mapped) host memory: the store lands there without a copy kernel
+        if (total_host) *total_host = part[1023];
+    }
 }
 
 // ---- 3. scatter --------------------------------------------------------------------------------
@@ -712,12 +718,9 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
         hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
-                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev);
+                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host);
     }
     GS_LAUNCH_CHECK();
-    if (num_isects_host)
-        GS_HIP_CHECK(hipMemcpyAsync(num_isects_host, total_dev, sizeof(int32_t),
-                                    hipMemcpyDeviceToHost, s));
     return GS_OK;
 }
 
