@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--fast-exp", action="store_true",
                     help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hot", type=float, default=0.0,
+                    help="experiment: fraction of the Gaussians concentrated in a 48x48 px window")
     ap.add_argument("--cpu-gaussians", type=int, default=0,
                     help="Gaussians in the CPU-baseline sample (0 = the whole workload)")
     return ap.parse_args()
@@ -256,7 +258,7 @@ def main():
         cfg = "c2" if world == 1 else "c4"
     if cfg == "c2":
         scene = scenes.camera_scene(args.gaussians, args.width, args.height, K=16, seed=1,
-                                    sigma_px=(0.5, 4.0), name="C2")
+                                    sigma_px=(0.5, 4.0), name="C2", hot=(args.hot, 48))
         workload = "C2: %d Gaussians, %dx%d, SH degree 3 (K=16), 16x16 tiles, seed 1" % (
             args.gaussians, args.width, args.height)
     elif cfg == "c3":

@@ -161,12 +161,13 @@ size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
 
 /* Counts the intersections of every 16x16 tile (rectangles of the packed records) and scans the
  * counts:  tile_bins[tiles,2] = [start, end) of each tile's segment in the sorted id list.
- * The total M is also stored (by the scan kernel itself, in stream order) to *num_isects_host,
- * which must be PINNED, device-mapped host memory (hipHostMalloc / a torch pinned tensor) or NULL; the caller synchronises the stream before reading it (the reference syncs at
+ * {M, longest tile list} are also stored (by the scan kernel itself, in stream order) to
+ * num_isects_host[0..1], which must be PINNED, device-mapped host memory of two int32
+ * (hipHostMalloc / a torch pinned tensor) or NULL; the caller synchronises the stream before reading it (the reference syncs at
  * the same place, rasterize_gaussians.cpp:63) — or does not read it at all and passes a
  * sufficient capacity to gs_bin_sort. */
 int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
-                int32_t *num_isects_host /*host, nullable*/, void *workspace,
+                int32_t *num_isects_host /*pinned host int32[2], nullable*/, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
 /* Fills every tile's segment of gaussian_ids_sorted[capacity] with the ids of the Gaussians
@@ -192,7 +193,8 @@ int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, cons
  * reference blocks). */
 int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
                     const float *depths, int32_t *tile_bins, int32_t *gaussian_ids_sorted,
-                    int32_t *num_isects_host /*host*/, void *workspace, size_t workspace_bytes,
+                    int32_t *num_isects_host /*pinned host int32[2]*/, void *workspace,
+                    size_t workspace_bytes,
                     gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -206,6 +208,10 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            accumulates into them).  Partial gradients are accumulated with fp32 atomics into
  *            64-byte per-Gaussian records in `workspace` (gs_rasterize_backward_workspace_bytes(N)
  *            bytes, 64-byte aligned) and split into the four tensors at the end.
+ *            list_stats: {M, longest tile list} as gs_bin_scan stored them for this or an earlier
+ *            frame (read on the host at call time; NULL or stale values are fine): when one tile's
+ *            list is much longer than the average, that tile is composited by two or four waves
+ *            (8 or 4 pixel rows each) instead of one — scheduling only, same results.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
@@ -214,7 +220,8 @@ int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          const float *background /*host or device [3]*/, float *out_img, float *final_Ts,
                          int32_t *final_idx,
                          float *out_img_clamped /*[H,W,3], required with GS_FLAG_CLAMP_IMAGE*/,
-                         uint32_t flags, gs_stream_t stream);
+                         const int32_t *list_stats /*host int32[2], nullable*/, uint32_t flags,
+                         gs_stream_t stream);
 
 size_t gs_rasterize_backward_workspace_bytes(int N);
 
@@ -225,7 +232,8 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const float *v_out_alpha /*nullable*/,
                           const float *out_img /*raw image, required with GS_FLAG_CLAMP_IMAGE*/,
                           float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-                          void *workspace, size_t workspace_bytes, uint32_t flags,
+                          void *workspace, size_t workspace_bytes,
+                          const int32_t *list_stats /*host int32[2], nullable*/, uint32_t flags,
                           gs_stream_t stream);
 
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact

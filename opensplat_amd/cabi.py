@@ -164,7 +164,9 @@ class BinWorkspace:
     def __init__(self):
         self.ws = None
         self.capacity = 0   # entries the id buffer / sort workspace currently hold
-        self.m_host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
+        # pinned {M, longest tile list}: written by the scan kernel, read by the host
+        self.m_host = torch.zeros(2, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
+        self.list_stats = (C.c_int32 * 2)(0, 0)   # last validated values: scheduling hint
         self.bufs = {}
 
     def get(self, name, shape, dtype, device):
@@ -200,7 +202,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
     _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
                             _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
                             C.c_uint32(flags), _stream()), "gs_pack_splats")
-    m_host = w.m_host if w.m_host is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+    m_host = w.m_host if w.m_host is not None else torch.zeros(2, dtype=torch.int32).pin_memory()
     while True:
         cap = max(w.capacity, 1024)
         ws_bytes = l.gs_bin_workspace_bytes(N, cap, W, H)
@@ -215,6 +217,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                                  _stream()), "gs_bin_sort")
             b = Binned(packed, tiles_hit, -1, ids, tile_bins)
             b.m_host, b.capacity, b.workspace = m_host, cap, w
+            b.list_stats = w.list_stats   # from the previous validated frame
             return b
         rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
                                _p(depths), _p(tile_bins), _p(ids), C.c_void_p(m_host.data_ptr()),
@@ -225,7 +228,10 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
             continue
         _check(rc, "gs_bin_and_sort")
         break
-    return Binned(packed, tiles_hit, M, ids[:M], tile_bins)
+    w.list_stats[0], w.list_stats[1] = int(m_host[0]), int(m_host[1])
+    b = Binned(packed, tiles_hit, M, ids[:M], tile_bins)
+    b.list_stats = w.list_stats
+    return b
 
 
 def validate_binning(b: Binned) -> bool:
@@ -233,6 +239,7 @@ def validate_binning(b: Binned) -> bool:
     torch.cuda.current_stream().synchronize()
     M = int(b.m_host[0])
     b.num_isects = M
+    b.workspace.list_stats[0], b.workspace.list_stats[1] = M, int(b.m_host[1])
     if M > b.capacity:
         b.workspace.capacity = M + M // 8 + 1024
         return False
@@ -250,8 +257,8 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
     _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
                                       _p(out["final_Ts"]), _p(out["final_idx"]),
-                                      _p(out.get("img_clamped")), C.c_uint32(flags),
-                                      _stream()), "gs_rasterize_forward")
+                                      _p(out.get("img_clamped")), getattr(binned, "list_stats", None),
+                                      C.c_uint32(flags), _stream()), "gs_rasterize_forward")
     return out
 
 
@@ -270,7 +277,9 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
                                        _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
                                        _p(v_out_alpha), _p(img_raw), _p(out["v_xy"]), _p(out["v_conic"]),
                                        _p(out["v_colors"]), _p(out["v_opacity"]), _p(workspace),
-                                       C.c_size_t(workspace.numel()), C.c_uint32(flags), _stream()),
+                                       C.c_size_t(workspace.numel()),
+                                       getattr(binned, "list_stats", None), C.c_uint32(flags),
+                                       _stream()),
            "gs_rasterize_backward")
     return out
 

@@ -213,9 +213,14 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
         }
         __syncthreads();
     }
-    int32_t sum = 0;
-    if (use_lds) for (int i = lo; i < hi; i++) sum += c_lds[skew(i)];
-    else for (int i = lo; i < hi; i++) sum += counts[i];
+    int32_t sum = 0, longest = 0;
+    if (use_lds) for (int i = lo; i < hi; i++) { const int32_t c = c_lds[skew(i)]; sum += c; longest = max(longest, c); }
+    else for (int i = lo; i < hi; i++) { const int32_t c = counts[i]; sum += c; longest = max(longest, c); }
+    // longest list of the frame (steers how many waves share a tile in the compositing kernels)
+    __shared__ int32_t s_longest;
+    if (t == 0) s_longest = 0;
+    __syncthreads();
+    atomicMax(&s_longest, longest);
     part[t] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partials
@@ -248,8 +253,11 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
     }
     if (t == 1023) {
         *total_dev = part[1023];
-        // pinned (device-mapped) host memory: the store lands there without a copy kernel
-        if (total_host) *total_host = part[1023];
+        // pinned (device-mapped) host memory: the stores land there without a copy kernel
+        if (total_host) {
+            total_host[0] = part[1023];
+            total_host[1] = s_longest;
+        }
     }
 }
 

@@ -120,25 +120,52 @@ __device__ __forceinline__ void stage_entry(Staged *dst, const Rec &r, int tile_
 __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 
 // Work units.  A wave walking a tile's list alone on its SIMD is latency-bound (~4x slower than
-// its share of a saturated SIMD), and a launch ends with such stragglers: measured ~100 us of
-// each compositing kernel at C2.  Tiles from `split_from` on (in dispatch order) are therefore
-// handled by TWO waves, one per 8-row half (`half` = 0/1, each skipping entries that miss its
-// rows): the tail is made of twice as many units of ~60 % the length.  half = -1: whole tile.
-__device__ __forceinline__ int decode_unit(int block, int split_from, int num_tiles, int &half) {
-    half = -1;
-    int lin = block;
-    if (block >= split_from) {
-        const int r = block - split_from;
-        lin = split_from + (r >> 1);
-        half = r & 1;
+// its share of a saturated SIMD), so (1) a launch ends with stragglers — measured ~100 us of each
+// compositing kernel at C2 — and (2) one tile with a very long list (real captures have them) can
+// dominate the whole launch.  A tile can therefore be handled by 1, 2 or 4 waves, each owning a
+// set of pixel rows (16, 8 or 4 of them) and skipping the entries that miss its rows:
+//   * Sched.mult == 1: one wave per tile, except that tiles from `split_from` on (in dispatch
+//     order, the tail of the launch) get two half-tile waves;
+//   * Sched.mult == 2 / 4 (chosen by the host when the previous frame had a list longer than
+//     t2 / t4): `mult` blocks per tile; a tile whose list is longer than t4 is split in four,
+//     longer than t2 in two, otherwise block 0 takes the whole tile and the others exit.
+// Returns the 16-bit set of tile rows this wave owns (0 = nothing to do); pixel k of a lane
+// (rows ly + 4k) is owned iff bit 4k is set.
+struct Sched {
+    int split_from, mult, t2, t4;
+};
+
+__device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int num_tiles,
+                                                const int2 *__restrict__ bins, int &tile) {
+    if (sc.mult <= 1) {
+        int lin = block;
+        uint32_t rows = 0xFFFFu;
+        if (block >= sc.split_from) {
+            const int r = block - sc.split_from;
+            lin = sc.split_from + (r >> 1);
+            rows = 0xFFu << (8 * (r & 1));
+        }
+        tile = xcd_swizzle(lin, num_tiles);
+        return rows;
     }
-    return xcd_swizzle(lin, num_tiles);
+    // blocks [0, (mult-1)*tiles): parts 1..mult-1 of every tile — almost all of them exit at once,
+    // the few that belong to long lists start right at the beginning of the launch; then part 0 of
+    // every tile.  (Interleaving the parts tile by tile would leave three quarters of every CU's
+    // workgroup slots to blocks that exit, and the real ones latency-bound.)
+    const int extra = (sc.mult - 1) * num_tiles;
+    const int part = block < extra ? 1 + block / num_tiles : 0;
+    tile = xcd_swizzle(block < extra ? block % num_tiles : block - extra, num_tiles);
+    const int2 range = bins[tile];
+    const int n = range.y - range.x;
+    const int split = (sc.mult >= 4 && n > sc.t4) ? 4 : (n > sc.t2 ? 2 : 1);
+    if (part >= split) return 0u;
+    return split == 1 ? 0xFFFFu : split == 2 ? (0xFFu << (8 * part)) : (0xFu << (4 * part));
 }
 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT, bool PREFETCH>
 __global__ void __launch_bounds__(64)
-k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
+k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                     const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                     float bg1, float bg2, const float *__restrict__ bg_dev,
@@ -151,10 +178,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
     if (bg_dev) {  // background handed over as a device tensor (no host copy, no sync)
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
-    int half;
-    const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
+    int tile;
+    const uint32_t rows = decode_unit(blockIdx.x, sched, num_tiles, bins, tile);
+    if (rows == 0u) return;
     // rows of the tile this wave owns, as a filter on the entries' row-mask bits
-    const uint32_t keep = half < 0 ? 0xFFFFFFFFu : (0xFFFFu | (0xFFu << (16 + 8 * half)));
+    const uint32_t keep = 0xFFFFu | (rows << 16);
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
     if (EXACT) load_exp_table(exp_tab, lane, 64);
 
@@ -168,7 +196,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
-        const bool mine = half < 0 || (k >> 1) == half;
+        const bool mine = ((rows >> (4 * k)) & 1u) != 0u;
         const float v = (px < W && py < H && mine) ? (float)py : qnan();
         if (k & 1) py2[k >> 1].y = v; else py2[k >> 1].x = v;
         last[k] = -1;
@@ -279,7 +307,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, int split_from,
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int py = tile_y0 + ly + 4 * k;
-        if (px < W && py < H && (half < 0 || (k >> 1) == half)) {
+        if (px < W && py < H && ((rows >> (4 * k)) & 1u)) {
             const size_t pix = (size_t)py * W + px;
             const int h = k >> 1;
             const float Tk = (k & 1) ? T2[h].y : T2[h].x;
@@ -360,7 +388,7 @@ __global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, int split_from,
+k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                      const int32_t *__restrict__ ids,
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                      float bg1, float bg2, const float *__restrict__ bg_dev,
@@ -374,9 +402,10 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, int split_from,
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
-    int half;
-    const int tile = decode_unit(blockIdx.x, split_from, num_tiles, half);
-    const uint32_t keep = half < 0 ? 0xFFFFFFFFu : (0xFFFFu | (0xFFu << (16 + 8 * half)));
+    int tile;
+    const uint32_t rows = decode_unit(blockIdx.x, sched, num_tiles, bins, tile);
+    if (rows == 0u) return;
+    const uint32_t keep = 0xFFFFu | (rows << 16);
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
     if (EXACT) load_exp_table(exp_tab, lane, 64);
 
@@ -393,7 +422,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, int split_from,
         const int py = tile_y0 + ly + 4 * k;
         float Tfin = 1.0f, o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, oa = 0.0f;
         int l = -1;
-        if (px < W && py < H && (half < 0 || (k >> 1) == half)) {
+        if (px < W && py < H && ((rows >> (4 * k)) & 1u)) {
             const size_t pix = (size_t)py * W + px;
             Tfin = final_Ts[pix];
             l = final_idx[pix];
@@ -637,17 +666,38 @@ extern "C" int gs_debug_stats(unsigned long long *host16, int reset) {
 #endif
 
 namespace gs {
-// First tile (in dispatch order) handled by two half-tile waves: the last `percent` % of the tiles.
-// Measured at C2 (scripts/ab_raster.py): forward 466 us unsplit, 447 us at 20 %, 463 at 40 %, 531 at
-// 100 %; the backward only loses (733 / 739 / 757 / 866 us) because its per-entry reduction and
-// atomic are paid by both halves — so 20 % forward, 0 % backward.
-// Experimental override for A/B runs: flags bits 8..15 = percent + 1.
+// Launch schedule (see decode_unit).  list_stats = { M, longest tile list } as gs_bin_scan reported
+// them for this or an EARLIER frame (host memory; may be NULL or stale — it only steers how many
+// waves share a tile, every choice renders the same image).
+// Tail split, measured at C2 (scripts/ab_raster.py): forward 466 us unsplit, 447 us with the last
+// 20 % of the tiles split, 463 at 40 %, 531 at 100 %; the backward only loses (733 / 739 / 757 /
+// 866 us) because its per-entry reduction and atomic are paid by both halves — 20 % / 0 %.
+// Experimental overrides for A/B runs: flags bits 8..15 = tail percent + 1, bits 16..17 = mult.
 constexpr int kSplitPercentForward = 20, kSplitPercentBackward = 0;
-static inline int split_point(int tiles, uint32_t flags, int pct) {
+static inline Sched make_sched(int tiles, uint32_t flags, int tail_pct, const int32_t *list_stats,
+                               int &units) {
+    Sched sc;
     const int o = (int)((flags >> 8) & 0xFFu);
-    if (o) pct = o - 1;
-    if (pct > 100) pct = 100;
-    return tiles - (int)((int64_t)tiles * pct / 100);
+    if (o) tail_pct = o - 1;
+    if (tail_pct > 100) tail_pct = 100;
+    sc.split_from = tiles - (int)((int64_t)tiles * tail_pct / 100);
+    sc.mult = 1;
+    sc.t2 = sc.t4 = 0x7fffffff;
+    if (list_stats && list_stats[0] > 0) {
+        const int64_t avg = list_stats[0] / tiles > 64 ? list_stats[0] / tiles : 64;
+        const int64_t t2 = 3 * avg + 256, t4 = 6 * avg + 512;
+        sc.t2 = (int)(t2 < 0x7fffffff ? t2 : 0x7fffffff);
+        sc.t4 = (int)(t4 < 0x7fffffff ? t4 : 0x7fffffff);
+        sc.mult = list_stats[1] > sc.t4 ? 4 : (list_stats[1] > sc.t2 ? 2 : 1);
+    }
+    const int force = (int)((flags >> 16) & 3u);
+    if (force) {  // experiment: force the multiplicity, every tile split
+        sc.mult = force == 3 ? 4 : force;
+        sc.t2 = sc.mult >= 2 ? 0 : 0x7fffffff;
+        sc.t4 = sc.mult >= 4 ? 0 : 0x7fffffff;
+    }
+    units = sc.mult > 1 ? sc.mult * tiles : sc.split_from + 2 * (tiles - sc.split_from);
+    return sc;
 }
 }  // namespace gs
 
@@ -683,7 +733,8 @@ extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stre
 extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                                     const int32_t *tile_bins, const float *packed,
                                     const float *background, float *out_img, float *final_Ts,
-                                    int32_t *final_idx, float *out_img_clamped, uint32_t flags,
+                                    int32_t *final_idx, float *out_img_clamped,
+                                    const int32_t *list_stats, uint32_t flags,
                                     gs_stream_t stream) {
     if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
@@ -697,18 +748,18 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
-    const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentForward);
-    const int units = split_from + 2 * (tiles - split_from);
+    int units;
+    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentForward, list_stats, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
+                           tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     else
         hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
+                           tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -724,7 +775,8 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                                      const int32_t *final_idx, const float *v_out,
                                      const float *v_out_alpha, const float *out_img, float *v_xy,
                                      float *v_conic, float *v_colors, float *v_opacity,
-                                     void *workspace, size_t workspace_bytes, uint32_t flags,
+                                     void *workspace, size_t workspace_bytes,
+                                     const int32_t *list_stats, uint32_t flags,
                                      gs_stream_t stream) {
     if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
@@ -743,19 +795,19 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     float *gacc = static_cast<float *>(workspace);
     GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
-    const int split_from = gs::split_point(tiles, flags, gs::kSplitPercentBackward);
-    const int units = split_from + 2 * (tiles - split_from);
+    int units;
+    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentBackward, list_stats, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
         hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
+                           tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     else
         hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(units), dim3(64), 0, s, W, H,
-                           tiles_x, tiles, split_from, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
+                           tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();

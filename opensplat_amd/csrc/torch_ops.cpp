@@ -175,6 +175,8 @@ tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_ou
 
 // ---- binning ------------------------------------------------------------------------------------
 static std::atomic<int64_t> g_capacityHint{0};
+// {M, longest tile list} of the last validated frame: scheduling hint for the compositing kernels
+static int32_t g_listStats[2] = {0, 0};
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
@@ -201,7 +203,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     // in the middle of the forward (rasterize_gaussians.cpp:62-63).  A stale guess costs one repeat.
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     Tensor tileBins = torch::empty({tiles, 2}, i32);
-    Tensor mHost = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    Tensor mHost = torch::zeros({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
     const int64_t cap = std::max<int64_t>(g_capacityHint.load(), 1024);
     Tensor idsSorted = torch::empty({cap}, i32);
     size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
@@ -221,6 +223,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
 bool validateBinning(const Tensor &mHost, const Tensor &idsSorted) {
     c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
     const int64_t M = mHost.data_ptr<int32_t>()[0];
+    g_listStats[0] = (int32_t)M;
+    g_listStats[1] = mHost.data_ptr<int32_t>()[1];
     g_capacityHint.store(M + M / 8 + 1024);
     return M <= idsSorted.size(0);
 
@@ -267,7 +271,7 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
         check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
                                           tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                           fptr_mut(outImg), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), nullptr, flags,
+                                          finalIdx.data_ptr<int32_t>(), nullptr, g_listStats, flags,
                                           current_stream()),
                      "gs_rasterize_forward");
         if (validateBinning(std::get<3>(b), idsSorted)) break;
@@ -301,7 +305,7 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
                                        fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
                                        nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
                                        nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
-                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
+                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes, g_listStats,
                                        (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
                  "gs_rasterize_backward");
     Tensor none;
@@ -420,7 +424,8 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
         check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
                                           tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                           fptr_mut(imgRaw), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), flags, s),
+                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), g_listStats,
+                                          flags, s),
                      "gs_rasterize_forward");
         if (validateBinning(std::get<3>(b), idsSorted)) break;
     }
@@ -467,7 +472,7 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
                                        finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
                                        fptr(imgRaw), fptr_mut(v_xy), fptr_mut(v_conic),
                                        fptr_mut(v_colors), fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
-                                       (uint32_t)ctx->saved_data["flags"].toInt(), s),
+                                       g_listStats, (uint32_t)ctx->saved_data["flags"].toInt(), s),
                  "gs_rasterize_backward");
     Tensor v_dc = torch::empty({N, 3}, f32);
     Tensor v_rest = K > 1 ? torch::empty({N, K - 1, 3}, f32) : Tensor();

@@ -98,12 +98,15 @@ def simple_trainer_scene(N: int = 10_000, W: int = 256, H: int = 256, seed: int 
 def camera_scene(N: int, W: int, H: int, K: int = 16, seed: int = 1, sigma_px=(0.5, 4.0),
                  z_range=(2.0, 10.0), znear: float = 0.001, zfar: float = 1000.0,
                  degrees_to_use: int | None = None, yaw_deg: float = 0.0, name: str | None = None,
-                 with_cotangent: bool = True) -> Scene:
+                 with_cotangent: bool = True, hot=(0.0, 0)) -> Scene:
     """C2/C3-style scene: fovX = 90 deg, Gaussians spread over the image footprint
     at depth z, pixel-space sigma log-uniform in `sigma_px` with per-axis anisotropy U(0.3, 1).
 
     Depths lie on a jittered, shuffled grid so that no two Gaussians share a depth (the reference's
     CPU sort is unstable, gsplat_cpu.cpp:155-159): spacing (z1-z0)/N.
+
+    hot = (fraction, box_px): that fraction of the Gaussians is concentrated in a box_px x box_px
+    window at the image centre — a few tiles with very long lists, as real captures have.
     """
     rng = np.random.RandomState(seed)
     fx = fy = 0.5 * W
@@ -116,6 +119,10 @@ def camera_scene(N: int, W: int, H: int, K: int = 16, seed: int = 1, sigma_px=(0
     margin = 0.02
     px = (margin + (1 - 2 * margin) * rng.rand(N)) * W
     py = (margin + (1 - 2 * margin) * rng.rand(N)) * H
+    if hot[0] > 0:
+        nh = int(N * hot[0])
+        px[:nh] = cx + (rng.rand(nh) - 0.5) * hot[1]
+        py[:nh] = cy + (rng.rand(nh) - 0.5) * hot[1]
     x = (px - cx) * z / fx
     y = (py - cy) * z / fy
     means = np.stack([x, y, z], -1).astype(np.float32)
