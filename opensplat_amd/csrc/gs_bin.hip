@@ -176,8 +176,11 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
     // every iteration is taken by whole waves (for_each_tile uses wave-wide operations)
-    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
-        const int n = base + threadIdx.x;
+    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
+    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
+    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
+         chunk += (blockDim.x >> 6) * gridDim.x) {
+        const int n = chunk * 64 + (threadIdx.x & 63);
         const bool valid = n < N;
         TileRect r = {0, 0, 0, 0};
         if (valid) r = tile_rect(packed, n);
@@ -296,8 +299,11 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
     extern __shared__ int32_t h[];
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
-    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
-        const int n = base + threadIdx.x;
+    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
+    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
+    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
+         chunk += (blockDim.x >> 6) * gridDim.x) {
+        const int n = chunk * 64 + (threadIdx.x & 63);
         const bool valid = n < N;
         TileRect r = {0, 0, 0, 0};
         if (valid) r = tile_rect(packed, n);
@@ -310,8 +316,11 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
         if (c) h[t] = bins[t].x + atomicAdd(&fill[t], c);
     }
     __syncthreads();
-    for (int base = blockIdx.x * blockDim.x; base < N; base += gridDim.x * blockDim.x) {
-        const int n = base + threadIdx.x;
+    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
+    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
+    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
+         chunk += (blockDim.x >> 6) * gridDim.x) {
+        const int n = chunk * 64 + (threadIdx.x & 63);
         const bool valid = n < N;
         TileRect r = {0, 0, 0, 0};
         uint32_t db = 0;
@@ -642,7 +651,7 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // persistent workgroup per CU is enough to saturate the LDS atomic units; fewer for small N.
 constexpr size_t kMaxTileLds = 144 * 1024;
 static int persistent_blocks(int N) {
-    int b = (N + kPersistentThreads - 1) / kPersistentThreads;
+    int b = (N + 63) / 64;  // at least one 64-Gaussian chunk per workgroup
     return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 
