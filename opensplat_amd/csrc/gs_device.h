@@ -59,25 +59,6 @@ __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// Sum over the 16 lanes of each DPP row; every lane of the row ends up with the row sum.
-__device__ __forceinline__ float row_sum16(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror
-    return v;
-}
-
-// Sum over all 64 lanes; result is wave-uniform (lives in SGPRs after the readlanes).
-__device__ __forceinline__ float wave_sum(float v) {
-    v = row_sum16(v);
-    float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (s0 + s1) + (s2 + s3);
-}
-
 __device__ __forceinline__ int wave_max_i(int v) {
     v = max(v, dpp_i<0xB1>(v));
     v = max(v, dpp_i<0x4E>(v));

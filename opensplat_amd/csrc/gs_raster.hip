@@ -9,24 +9,29 @@
 // contributor decisions (same alpha >= 1/255 outcome as the forward, exactly) but is free to
 // re-associate the gradient arithmetic (fp32 atomics make the sum order undefined anyway).
 //
-// Both kernels are VALU-bound (rocprofv3: SQ_ACTIVE_INST_VALU ~ 85 % of busy cycles, LDS and HBM
-// far from their limits), so the design minimises wave-instructions per (tile, Gaussian) entry:
-//   * one 64-lane wavefront == one workgroup == one 16x16 tile; every lane owns FOUR pixels
-//     (column lane&15, rows (lane>>4) + 4k, k = 0..3), handled as TWO packed pairs so that the
-//     sigma quadratic form and the gradient body run on v_pk_{mul,add,fma}_f32 (2 pixels per
-//     instruction).  The per-Gaussian record is read from LDS once per wave (broadcast
-//     ds_read_b128) and amortised over 4 pixels per lane.
+// Both kernels are VALU-issue-bound in the bulk of a launch and latency-bound in its tail (rocprofv3
+// counters and the issue-cost model in DESIGN.md 4.1; LDS and HBM are far from their limits), so
+// the design minimises the cost-weighted instructions per (tile, Gaussian) entry:
+//   * one 64-lane wavefront == one workgroup == one 16x16 tile (two or four waves for tiles with
+//     very long lists and for the tail of the forward launch, see "work units" below); every lane
+//     owns FOUR pixels (column lane&15, rows (lane>>4) + 4k, k = 0..3), handled as TWO packed pairs
+//     so that the sigma quadratic form and the gradient body run on v_pk_{mul,add,fma}_f32.  The
+//     per-Gaussian record is read from LDS once per wave (broadcast reads of duplicated pairs, see
+//     Staged) and amortised over 4 pixels per lane.
 //   * no workgroup barriers between waves: the tile's sorted list is staged 64 entries at a time
 //     by the wave itself (next chunk's gather prefetched into registers while the current chunk
 //     is consumed), early termination is a 64-bit ballot.
-//   * per-pixel "is this Gaussian relevant" is two float compares, 0 <= sigma <= sigma_max, with
-//     sigma_max = ln(255*opacity) precomputed per Gaussian: the CPU oracle's pixel-rectangle test
-//     is implied by it whenever the rectangle encloses the sigma_max ellipse box (flag bit set by
+//   * per-pixel "is this Gaussian relevant" is ONE unsigned compare of sigma's bit pattern against
+//     sigma_max = ln(255*opacity) (precomputed per Gaussian): 0 <= sigma <= sigma_max, with
+//     negatives and NaNs failing by construction.  The CPU oracle's pixel-rectangle test is
+//     implied by it whenever the rectangle encloses the sigma_max ellipse box (flag bit set by
 //     gs_pack_splats); only for the rare Gaussians whose rectangle cuts the ellipse is the
-//     rectangle applied explicitly (scalar-branched slow path).  Finished / out-of-image pixels
-//     carry a NaN row coordinate in the forward, so they fail the same two compares for free.
+//     rectangle applied explicitly (scalar-branched path injecting NaN coordinates).  Finished /
+//     out-of-image pixels carry a NaN row coordinate in the forward, so they fail the compare too.
 //   * an 8-row half of the tile that the (tightened) rectangle does not touch is skipped with a
-//     scalar branch; the fp64 exponential is only issued when some lane of the pair passes.
+//     scalar branch; the fp64 exponential is only issued when some lane of the 4-row strip passes;
+//     a pixel that is skipped gets alpha = 0, which composites exactly nothing — no per-pixel
+//     branches; saturation (once per pixel and frame) is a scalar-branched rare path.
 //   * backward: the exponential is v_exp_f32, with the exact fp64 evaluation re-run only for
 //     lanes whose alpha lies within 2.5e-6 (relative) of the 1/255 threshold, so the decision
 //     equals the forward's; 1/(1-alpha) is v_rcp_f32 + one Newton step; the running colour
@@ -37,8 +42,9 @@
 //     v_permlane32_swap / v_permlane16_swap fold value PAIRS across the wave's halves / rows
 //     (2 instructions merge two registers into one), DPP row_mirror / half_mirror / quad_perm
 //     finish inside 8-lane groups, after which nine different lanes hold the nine totals and ONE
-//     global_atomic_add_f32 instruction (nine active lanes, per-lane addresses) scatters them —
-//     ~30 VALU + 1 VMEM per contributing (tile, Gaussian) instead of 9 x (11 VALU + 1 VMEM).
+//     global_atomic_add_f32 instruction (nine active lanes hitting one 64-byte gradient record)
+//     scatters them — ~30 VALU + 1 VMEM per contributing (tile, Gaussian) instead of
+//     9 x (11 VALU + 1 VMEM).
 //
 // Roofline: HBM traffic is one 48-byte gather per entry plus 20 B per pixel; DESIGN.md states the
 // algorithmic bytes used for roofline.achieved and the VALU accounting.
@@ -163,7 +169,7 @@ __device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int n
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool EXACT, bool PREFETCH>
+template <bool EXACT>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                     const int32_t *__restrict__ ids,
@@ -210,18 +216,15 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
 
     const int2 range = bins[tile];
     Rec nxt;
-    if (PREFETCH && range.x + lane < range.y) fetch_entry(nxt, range.x + lane, ids, packed);
+    if (range.x + lane < range.y) fetch_entry(nxt, range.x + lane, ids, packed);
     for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
         const bool alive = (py2[0].x == py2[0].x) || (py2[0].y == py2[0].y) ||
                            (py2[1].x == py2[1].x) || (py2[1].y == py2[1].y);
         if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
-        if (c0 + lane < range.y) {
-            if (!PREFETCH) fetch_entry(nxt, c0 + lane, ids, packed);
-            stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
-        }
+        if (c0 + lane < range.y) stage_entry(&stage[lane], nxt, tile_x0, tile_y0);
         __syncthreads();
-        if (PREFETCH && c0 + kChunk + lane < range.y) fetch_entry(nxt, c0 + kChunk + lane, ids, packed);
+        if (c0 + kChunk + lane < range.y) fetch_entry(nxt, c0 + kChunk + lane, ids, packed);
         const int n = min(kChunk, range.y - c0);
         for (int t = 0; t < n; t++) {
             const Staged &e = stage[t];
@@ -755,10 +758,10 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL((gs::k_rasterize_forward<false, true>), dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     else
-        hipLaunchKernelGGL((gs::k_rasterize_forward<true, true>), dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
