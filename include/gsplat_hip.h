@@ -181,8 +181,9 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
  * synchronised — e.g. after the forward kernel has been enqueued) with capacity and repeats
  * scan + sort + compositing with a larger buffer if it was exceeded. */
 int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
-                int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
-                size_t workspace_bytes, gs_stream_t stream);
+                int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                int32_t *tile_order /*[tiles], nullable: tiles by descending list length*/,
+                void *workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
  * rasterize_gaussians.cpp:6-37 together with its caller's cumsum/.item(), :62-63): for callers
@@ -193,7 +194,7 @@ int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, cons
  * reference blocks). */
 int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
                     const float *depths, int32_t *tile_bins, int32_t *gaussian_ids_sorted,
-                    int32_t *num_isects_host /*pinned host int32[2]*/, void *workspace,
+                    int32_t *tile_order /*[tiles], nullable*/, int32_t *num_isects_host /*pinned host int32[2]*/, void *workspace,
                     size_t workspace_bytes,
                     gs_stream_t stream);
 
@@ -211,7 +212,8 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            list_stats: {M, longest tile list} as gs_bin_scan stored them for this or an earlier
  *            frame (read on the host at call time; NULL or stale values are fine): when one tile's
  *            list is much longer than the average, that tile is composited by two or four waves
- *            (8 or 4 pixel rows each) instead of one — scheduling only, same results.
+ *            (8 or 4 pixel rows each) instead of one, and — if tile_order (from gs_bin_sort) is
+ *            given — the launch starts with the longest lists.  Scheduling only, same results.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
@@ -220,7 +222,8 @@ int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          const float *background /*host or device [3]*/, float *out_img, float *final_Ts,
                          int32_t *final_idx,
                          float *out_img_clamped /*[H,W,3], required with GS_FLAG_CLAMP_IMAGE*/,
-                         const int32_t *list_stats /*host int32[2], nullable*/, uint32_t flags,
+                         const int32_t *list_stats /*host int32[2], nullable*/,
+                         const int32_t *tile_order /*device [tiles], nullable*/, uint32_t flags,
                          gs_stream_t stream);
 
 size_t gs_rasterize_backward_workspace_bytes(int N);
@@ -233,7 +236,8 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const float *out_img /*raw image, required with GS_FLAG_CLAMP_IMAGE*/,
                           float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
                           void *workspace, size_t workspace_bytes,
-                          const int32_t *list_stats /*host int32[2], nullable*/, uint32_t flags,
+                          const int32_t *list_stats /*host int32[2], nullable*/,
+                          const int32_t *tile_order /*device [tiles], nullable*/, uint32_t flags,
                           gs_stream_t stream);
 
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact

@@ -199,6 +199,8 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
     tiles_hit = w.get("tiles_hit", (N,), torch.int32, dev)
     tiles = ((W + GS_TILE - 1) // GS_TILE) * ((H + GS_TILE - 1) // GS_TILE)
     tile_bins = w.get("tile_bins", (tiles, 2), torch.int32, dev)
+    # tiles by descending list length: the compositing launches start with the long lists
+    tile_order = w.get("tile_order", (tiles,), torch.int32, dev)
     _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
                             _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
                             C.c_uint32(flags), _stream()), "gs_pack_splats")
@@ -213,15 +215,16 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                                  C.c_void_p(m_host.data_ptr()), _p(ws), C.c_size_t(ws_bytes),
                                  _stream()), "gs_bin_scan")
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                                 _p(depths), _p(tile_bins), _p(ids), _p(ws), C.c_size_t(ws_bytes),
-                                 _stream()), "gs_bin_sort")
+                                 _p(depths), _p(tile_bins), _p(ids), _p(tile_order), _p(ws),
+                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
             b = Binned(packed, tiles_hit, -1, ids, tile_bins)
+            b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w
             b.list_stats = w.list_stats   # from the previous validated frame
             return b
         rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                               _p(depths), _p(tile_bins), _p(ids), C.c_void_p(m_host.data_ptr()),
-                               _p(ws), C.c_size_t(ws_bytes), _stream())
+                               _p(depths), _p(tile_bins), _p(ids), _p(tile_order),
+                               C.c_void_p(m_host.data_ptr()), _p(ws), C.c_size_t(ws_bytes), _stream())
         M = int(m_host[0])
         if rc == GS_ERR_CAPACITY:
             w.capacity = M + M // 8 + 1024
@@ -231,6 +234,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
     w.list_stats[0], w.list_stats[1] = int(m_host[0]), int(m_host[1])
     b = Binned(packed, tiles_hit, M, ids[:M], tile_bins)
     b.list_stats = w.list_stats
+    b.tile_order = tile_order
     return b
 
 
@@ -258,7 +262,8 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
                                       _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
                                       _p(out["final_Ts"]), _p(out["final_idx"]),
                                       _p(out.get("img_clamped")), getattr(binned, "list_stats", None),
-                                      C.c_uint32(flags), _stream()), "gs_rasterize_forward")
+                                      _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
+                                      _stream()), "gs_rasterize_forward")
     return out
 
 
@@ -278,7 +283,8 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
                                        _p(v_out_alpha), _p(img_raw), _p(out["v_xy"]), _p(out["v_conic"]),
                                        _p(out["v_colors"]), _p(out["v_opacity"]), _p(workspace),
                                        C.c_size_t(workspace.numel()),
-                                       getattr(binned, "list_stats", None), C.c_uint32(flags),
+                                       getattr(binned, "list_stats", None),
+                                       _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
                                        _stream()),
            "gs_rasterize_backward")
     return out

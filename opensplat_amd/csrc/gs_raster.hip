@@ -139,6 +139,7 @@ __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 // (rows ly + 4k) is owned iff bit 4k is set.
 struct Sched {
     int split_from, mult, t2, t4;
+    const int32_t *order;  // tiles by descending list length (mult > 1 only), or NULL
 };
 
 __device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int num_tiles,
@@ -151,7 +152,7 @@ __device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int n
             lin = sc.split_from + (r >> 1);
             rows = 0xFFu << (8 * (r & 1));
         }
-        tile = xcd_swizzle(lin, num_tiles);
+        tile = sc.order ? sc.order[lin] : xcd_swizzle(lin, num_tiles);
         return rows;
     }
     // blocks [0, (mult-1)*tiles): parts 1..mult-1 of every tile — almost all of them exit at once,
@@ -160,7 +161,9 @@ __device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int n
     // workgroup slots to blocks that exit, and the real ones latency-bound.)
     const int extra = (sc.mult - 1) * num_tiles;
     const int part = block < extra ? 1 + block / num_tiles : 0;
-    tile = xcd_swizzle(block < extra ? block % num_tiles : block - extra, num_tiles);
+    const int lin = block < extra ? block % num_tiles : block - extra;
+    // longest lists first when the order is known, else the XCD-banded raster order
+    tile = sc.order ? sc.order[lin] : xcd_swizzle(lin, num_tiles);
     const int2 range = bins[tile];
     const int n = range.y - range.x;
     const int split = (sc.mult >= 4 && n > sc.t4) ? 4 : (n > sc.t2 ? 2 : 1);
@@ -678,8 +681,9 @@ namespace gs {
 // Experimental overrides for A/B runs: flags bits 8..15 = tail percent + 1, bits 16..17 = mult.
 constexpr int kSplitPercentForward = 20, kSplitPercentBackward = 0;
 static inline Sched make_sched(int tiles, uint32_t flags, int tail_pct, const int32_t *list_stats,
-                               int &units) {
+                               const int32_t *tile_order, int &units) {
     Sched sc;
+    sc.order = tile_order;
     const int o = (int)((flags >> 8) & 0xFFu);
     if (o) tail_pct = o - 1;
     if (tail_pct > 100) tail_pct = 100;
@@ -737,8 +741,8 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
                                     const int32_t *tile_bins, const float *packed,
                                     const float *background, float *out_img, float *final_Ts,
                                     int32_t *final_idx, float *out_img_clamped,
-                                    const int32_t *list_stats, uint32_t flags,
-                                    gs_stream_t stream) {
+                                    const int32_t *list_stats, const int32_t *tile_order,
+                                    uint32_t flags, gs_stream_t stream) {
     if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
     float *clamped = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img_clamped : nullptr;
@@ -752,7 +756,7 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     int units;
-    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentForward, list_stats, units);
+    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentForward, list_stats, tile_order, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
@@ -779,8 +783,8 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                                      const float *v_out_alpha, const float *out_img, float *v_xy,
                                      float *v_conic, float *v_colors, float *v_opacity,
                                      void *workspace, size_t workspace_bytes,
-                                     const int32_t *list_stats, uint32_t flags,
-                                     gs_stream_t stream) {
+                                     const int32_t *list_stats, const int32_t *tile_order,
+                                     uint32_t flags, gs_stream_t stream) {
     if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
     const float *img_raw = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img : nullptr;
@@ -799,7 +803,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     float *gacc = static_cast<float *>(workspace);
     GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
     int units;
-    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentBackward, list_stats, units);
+    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentBackward, list_stats, tile_order, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];

@@ -45,13 +45,15 @@ public:
 
 // Packs the per-Gaussian 2-D records and ENQUEUES tile counting, scan, scatter and the per-tile sorts
 // with an id-list capacity guessed from the previous call (no host synchronisation).  Returns
-// { packed[N,12], gaussianIdsSorted[capacity] i32, tileBins[tiles,2] i32, count (pinned host i32) }.
+// { packed[N,12], gaussianIdsSorted[capacity] i32, tileBins[tiles,2] i32, count (pinned host i32[2]),
+//   tileOrder[tiles] i32 (tiles by descending list length) }.
 // After enqueuing the compositing kernel the caller runs validateBinning(count, ids): it drains the
 // stream and returns false if the guess was too small — repeat both steps then.
 // (The reference's binAndSortGaussians, rasterize_gaussians.hpp:11-20, blocks on cumsum().item()
 // before it can allocate, and takes radius-square tile counts; this one derives them from the
 // CPU pixel rectangle — DESIGN.md.)
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> binAndSortGaussians(
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+binAndSortGaussians(
     const torch::Tensor &xys, const torch::Tensor &depths, const torch::Tensor &radii,
     const torch::Tensor &conics, const torch::Tensor &colors, const torch::Tensor &opacity,
     const torch::Tensor &cov2d, int imgHeight, int imgWidth, bool opacityIsLogit = false);

@@ -178,7 +178,7 @@ static std::atomic<int64_t> g_capacityHint{0};
 // {M, longest tile list} of the last validated frame: scheduling hint for the compositing kernels
 static int32_t g_listStats[2] = {0, 0};
 
-std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
     const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth,
     bool opacityIsLogit) {
@@ -211,11 +211,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
                              mHost.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
                  "gs_bin_scan");
+    // tiles by descending list length: the compositing launches start with the long lists
+    Tensor tileOrder = torch::empty({tiles}, i32);
     check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
                              tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                             ws.data_ptr(), wsBytes, s),
+                             tileOrder.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
                  "gs_bin_sort");
-    return std::make_tuple(packed, idsSorted, tileBins, mHost);
+    return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
 }
 
 // Blocks until the stream has drained, then checks the intersection count of the binning against
@@ -264,15 +266,16 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     auto f32 = xys.options();
     Tensor outImg = torch::empty({H, W, 3}, f32), finalTs = torch::empty({H, W}, f32);
     Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
-    Tensor packed, idsSorted, tileBins;
+    Tensor packed, idsSorted, tileBins, tileOrder;
     for (;;) {
         auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
         packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
+        tileOrder = std::get<4>(b);
         check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
                                           tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                           fptr_mut(outImg), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), nullptr, g_listStats, flags,
-                                          current_stream()),
+                                          finalIdx.data_ptr<int32_t>(), nullptr, g_listStats,
+                                          tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr, flags, current_stream()),
                      "gs_rasterize_forward");
         if (validateBinning(std::get<3>(b), idsSorted)) break;
     }
@@ -281,7 +284,7 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["flags"] = (int64_t)flags;
     ctx->saved_data["numPoints"] = N;
-    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold});
+    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold, tileOrder});
     return outImg;
 }
 
@@ -290,7 +293,7 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     const int64_t N = ctx->saved_data["numPoints"].toInt();
     variable_list saved = ctx->get_saved_variables();
     Tensor idsSorted = saved[0], tileBins = saved[1], packed = saved[2];
-    Tensor finalTs = saved[3], finalIdx = saved[4], bgHold = saved[5];
+    Tensor finalTs = saved[3], finalIdx = saved[4], bgHold = saved[5], tileOrder = saved[6];
     c10::DeviceGuard guard(packed.device());
     Tensor v_outImg = grad_outputs[0].contiguous();
     GS_CHECK_F32(v_outImg);
@@ -306,6 +309,7 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
                                        nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
                                        nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
                                        fptr_mut(v_opacity), ws.data_ptr(), wsBytes, g_listStats,
+                                       tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
                                        (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
                  "gs_rasterize_backward");
     Tensor none;
@@ -417,14 +421,16 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
                      GS_FLAG_LOGIT_OPACITY;
     Tensor bgHold;
     const float *bg = vec3_arg(background, bgHold);
-    Tensor packed, idsSorted, tileBins;
+    Tensor packed, idsSorted, tileBins, tileOrder;
     for (;;) {
         auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacityLogits, cov2d, H, W, true);
         packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
+        tileOrder = std::get<4>(b);
         check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
                                           tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                           fptr_mut(imgRaw), fptr_mut(finalTs),
                                           finalIdx.data_ptr<int32_t>(), fptr_mut(img), g_listStats,
+                                          tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
                                           flags, s),
                      "gs_rasterize_forward");
         if (validateBinning(std::get<3>(b), idsSorted)) break;
@@ -442,7 +448,8 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     }
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
-                            gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold});
+                            gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold,
+                            tileOrder});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};
@@ -452,7 +459,7 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     variable_list sv = ctx->get_saved_variables();
     Tensor means = sv[0], logScales = sv[1], quats = sv[2], viewMat = sv[3], projMat = sv[4];
     Tensor radii = sv[5], rgbRaw = sv[6], idsSorted = sv[7], tileBins = sv[8], packed = sv[9];
-    Tensor finalTs = sv[10], finalIdx = sv[11], imgRaw = sv[12], gradOut = sv[13], bgHold = sv[14], cpHold = sv[15];
+    Tensor finalTs = sv[10], finalIdx = sv[11], imgRaw = sv[12], gradOut = sv[13], bgHold = sv[14], cpHold = sv[15], tileOrder = sv[16];
     const int64_t N = means.size(0), K = ctx->saved_data["K"].toInt();
     const int W = (int)ctx->saved_data["imgWidth"].toInt(), H = (int)ctx->saved_data["imgHeight"].toInt();
     c10::DeviceGuard guard(means.device());
@@ -472,7 +479,9 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
                                        finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
                                        fptr(imgRaw), fptr_mut(v_xy), fptr_mut(v_conic),
                                        fptr_mut(v_colors), fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
-                                       g_listStats, (uint32_t)ctx->saved_data["flags"].toInt(), s),
+                                       g_listStats,
+                                       tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
+                                       (uint32_t)ctx->saved_data["flags"].toInt(), s),
                  "gs_rasterize_backward");
     Tensor v_dc = torch::empty({N, 3}, f32);
     Tensor v_rest = K > 1 ? torch::empty({N, K - 1, 3}, f32) : Tensor();
