@@ -167,6 +167,7 @@ size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
  * the same place, rasterize_gaussians.cpp:63) — or does not read it at all and passes a
  * sufficient capacity to gs_bin_sort. */
 int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
+                int32_t *tile_order /*[tiles], nullable: tiles by descending list length*/,
                 int32_t *num_isects_host /*pinned host int32[2], nullable*/, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
@@ -181,9 +182,8 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
  * synchronised — e.g. after the forward kernel has been enqueued) with capacity and repeats
  * scan + sort + compositing with a larger buffer if it was exceeded. */
 int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
-                int32_t *tile_bins, int32_t *gaussian_ids_sorted,
-                int32_t *tile_order /*[tiles], nullable: tiles by descending list length*/,
-                void *workspace, size_t workspace_bytes, gs_stream_t stream);
+                int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
+                size_t workspace_bytes, gs_stream_t stream);
 
 /* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
  * rasterize_gaussians.cpp:6-37 together with its caller's cumsum/.item(), :62-63): for callers
@@ -212,8 +212,8 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            list_stats: {M, longest tile list} as gs_bin_scan stored them for this or an earlier
  *            frame (read on the host at call time; NULL or stale values are fine): when one tile's
  *            list is much longer than the average, that tile is composited by two or four waves
- *            (8 or 4 pixel rows each) instead of one, and — if tile_order (from gs_bin_sort) is
- *            given — the launch starts with the longest lists.  Scheduling only, same results.
+ *            (8 or 4 pixel rows each) instead of one; tile_order (from gs_bin_scan): the launch
+ *            starts with the longest lists.  Scheduling only, same results.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */

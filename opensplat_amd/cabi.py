@@ -212,11 +212,11 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         ids = w.get("ids_sorted", (cap,), torch.int32, dev)
         if speculative:
             _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
-                                 C.c_void_p(m_host.data_ptr()), _p(ws), C.c_size_t(ws_bytes),
-                                 _stream()), "gs_bin_scan")
+                                 _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
+                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                                 _p(depths), _p(tile_bins), _p(ids), _p(tile_order), _p(ws),
-                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
+                                 _p(depths), _p(tile_bins), _p(ids), _p(ws), C.c_size_t(ws_bytes),
+                                 _stream()), "gs_bin_sort")
             b = Binned(packed, tiles_hit, -1, ids, tile_bins)
             b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w

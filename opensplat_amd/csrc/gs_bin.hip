@@ -204,7 +204,8 @@ __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
-             int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host) {
+             int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
+             int32_t *__restrict__ order) {
     extern __shared__ int32_t c_lds[];
     __shared__ int32_t part[1024];
     const int t = threadIdx.x;
@@ -233,6 +234,7 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
         part[t] += v;
         __syncthreads();
     }
+    const int32_t total_keep = part[1023];
     int32_t run = part[t] - sum;  // exclusive prefix of this thread's slice
     if (use_lds) {
         for (int i = lo; i < hi; i++) {  // counts -> exclusive starts, in place
@@ -241,7 +243,7 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
             run += c;
         }
         __syncthreads();
-        const int32_t total = part[1023];
+        const int32_t total = total_keep;
         for (int i = t; i < tiles; i += 1024) {
             const int32_t st = c_lds[skew(i)];
             const int32_t en = (i + 1 < tiles) ? c_lds[skew(i + 1)] : total;
@@ -254,11 +256,44 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
             run += c;
         }
     }
+    // tiles by descending list length (counting sort on min(n >> shift, 1023)): the compositing
+    // kernels start the long lists first ("longest processing time first"), which evens out the end
+    // of their launches and lets a few heavy tiles overlap with the rest instead of trailing it
+    if (order) {
+        __syncthreads();
+        const int32_t longest_all = s_longest;
+        int shift = 0;
+        while ((longest_all >> shift) >= 1024) shift++;
+        part[t] = 0;
+        __syncthreads();
+        for (int i = t; i < tiles; i += 1024) {
+            const int32_t c = use_lds ? (bins[i].y - bins[i].x) : counts[i];
+            atomicAdd(&part[1023 - (c >> shift)], 1);  // bucket 0 = longest lists
+        }
+        __syncthreads();
+        const int32_t own = part[t];
+        for (int d = 1; d < 1024; d <<= 1) {
+            int32_t v = (t >= d) ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        const int32_t total_all = part[1023];
+        const int32_t first = part[t] - own;
+        __syncthreads();
+        part[t] = first;
+        __syncthreads();
+        for (int i = t; i < tiles; i += 1024) {
+            const int32_t c = use_lds ? (bins[i].y - bins[i].x) : counts[i];
+            order[atomicAdd(&part[1023 - (c >> shift)], 1)] = i;
+        }
+        (void)total_all;
+    }
     if (t == 1023) {
-        *total_dev = part[1023];
+        *total_dev = total_keep;
         // pinned (device-mapped) host memory: the stores land there without a copy kernel
         if (total_host) {
-            total_host[0] = part[1023];
+            total_host[0] = total_keep;
             total_host[1] = s_longest;
         }
     }
@@ -645,48 +680,6 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int2 *_
     }
 }
 
-// ---- 5. tile order ------------------------------------------------------------------------------
-// Tiles by descending list length (approximately: a counting sort on min(n >> shift, 1023)) — the
-// compositing kernels start the long lists first ("longest processing time first"), so that a few
-// heavy tiles overlap with the rest of the launch instead of trailing it.  One workgroup.
-__global__ void __launch_bounds__(1024)
-k_tile_order(int tiles, int32_t capacity, const int2 *__restrict__ bins, int32_t *__restrict__ order) {
-    __shared__ int32_t cnt[1024];
-    __shared__ int32_t s_max;
-    const int t = threadIdx.x;
-    cnt[t] = 0;
-    if (t == 0) s_max = 0;
-    __syncthreads();
-    int32_t mx = 0;
-    for (int i = t; i < tiles; i += 1024) mx = max(mx, min(bins[i].y, capacity) - min(bins[i].x, capacity));
-    atomicMax(&s_max, mx);
-    __syncthreads();
-    int shift = 0;
-    while ((s_max >> shift) >= 1024) shift++;
-    // bucket 0 = longest lists
-    for (int i = t; i < tiles; i += 1024) {
-        const int n = min(bins[i].y, capacity) - min(bins[i].x, capacity);
-        atomicAdd(&cnt[1023 - (n >> shift)], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the 1024 buckets (Hillis-Steele)
-    const int32_t own = cnt[t];
-    for (int d = 1; d < 1024; d <<= 1) {
-        int32_t v = (t >= d) ? cnt[t - d] : 0;
-        __syncthreads();
-        cnt[t] += v;
-        __syncthreads();
-    }
-    const int32_t start = cnt[t] - own;
-    __syncthreads();
-    cnt[t] = start;
-    __syncthreads();
-    for (int i = t; i < tiles; i += 1024) {
-        const int n = min(bins[i].y, capacity) - min(bins[i].x, capacity);
-        order[atomicAdd(&cnt[1023 - (n >> shift)], 1)] = i;
-    }
-}
-
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // LDS budget of the privatised count / scatter kernels (the CU has 160 KiB) and their grid: one
@@ -738,8 +731,8 @@ extern "C" size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H
 }
 
 extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
-                           int32_t *num_isects_host, void *workspace, size_t workspace_bytes,
-                           gs_stream_t stream) {
+                           int32_t *tile_order, int32_t *num_isects_host, void *workspace,
+                           size_t workspace_bytes, gs_stream_t stream) {
     if (N < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (!tile_bins || !workspace) return GS_ERR_INVALID_ARGUMENT;
@@ -777,7 +770,8 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
         hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
-                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host);
+                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host,
+                           tile_order);
     }
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -785,17 +779,10 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
 
 extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed,
                            const float *depths, int32_t *tile_bins,
-                           int32_t *gaussian_ids_sorted, int32_t *tile_order, void *workspace,
-                           size_t workspace_bytes, gs_stream_t stream) {
+                           int32_t *gaussian_ids_sorted, void *workspace, size_t workspace_bytes,
+                           gs_stream_t stream) {
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
-    if (tile_order && tile_bins && W > 0 && H > 0 && W <= 65535 && H <= 65535) {
-        const int tl = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-        hipLaunchKernelGGL(gs::k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, tl,
-                           capacity > 0 ? capacity : 0, reinterpret_cast<const int2 *>(tile_bins),
-                           tile_order);
-        GS_LAUNCH_CHECK();
-    }
     if (N == 0 || capacity == 0) return GS_OK;
     if (!packed || !depths || !tile_bins || !gaussian_ids_sorted || !workspace)
         return GS_ERR_INVALID_ARGUMENT;
@@ -855,12 +842,12 @@ extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const floa
                                int32_t *num_isects_host, void *workspace, size_t workspace_bytes,
                                gs_stream_t stream) {
     if (!num_isects_host) return GS_ERR_INVALID_ARGUMENT;
-    int rc = gs_bin_scan(W, H, N, packed, tile_bins, num_isects_host, workspace, workspace_bytes,
-                         stream);
+    int rc = gs_bin_scan(W, H, N, packed, tile_bins, tile_order, num_isects_host, workspace,
+                         workspace_bytes, stream);
     if (rc != GS_OK) return rc;
     GS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const int32_t M = *num_isects_host;
     if (M > capacity) return GS_ERR_CAPACITY;
-    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, tile_order,
-                       workspace, workspace_bytes, stream);
+    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, workspace,
+                       workspace_bytes, stream);
 }

@@ -208,14 +208,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     Tensor idsSorted = torch::empty({cap}, i32);
     size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
     Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
-    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
-                             mHost.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
-                 "gs_bin_scan");
     // tiles by descending list length: the compositing launches start with the long lists
     Tensor tileOrder = torch::empty({tiles}, i32);
+    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
+                             tileOrder.data_ptr<int32_t>(), mHost.data_ptr<int32_t>(),
+                             ws.data_ptr(), wsBytes, s),
+                 "gs_bin_scan");
     check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
                              tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                             tileOrder.data_ptr<int32_t>(), ws.data_ptr(), wsBytes, s),
+                             ws.data_ptr(), wsBytes, s),
                  "gs_bin_sort");
     return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
 }
