@@ -9,9 +9,9 @@ producing the image and the gradients of OpenSplat's six parameter tensors (mean
 opacities, featuresDc, featuresRest).  The element-wise glue between the three operators
 (model.cpp:114,176-177,192: cat, view directions, +0.5 / clamp_min) runs inside the SH kernels
 (row f1 variants gs_sh_forward_fused / gs_sh_backward_fused) — same arithmetic, no extra passes.
-The intersection count that sizes the id list is taken from the previous step and validated once
-per step after everything has been enqueued (see gs_bin_sort in include/gsplat_hip.h); a step
-whose guess was too small is repeated inside the timed region.  Every stage goes through the C ABI of
+The intersection count that sizes the id list is taken from the previous step and validated
+while the forward kernel runs (an event wait on the scan kernel, see gs_bin_sort in
+include/gsplat_hip.h); a forward whose guess was too small is repeated inside the timed region.  Every stage goes through the C ABI of
 libgsplat_hip.so (include/gsplat_hip.h); torch only provides device memory, the stream and, for
 N > 1, torch.distributed (nccl == RCCL).
 
@@ -146,17 +146,16 @@ class Pipeline:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
             f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
             mark()
+            # was the id list large enough?  Waits for the scan kernel only (long finished while the
+            # forward kernel runs): the stream never drains, the host keeps enqueuing.
+            if not cabi.validate_binning(b):
+                continue
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             g = cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"],
                                         f["final_idx"], self.v_out, self.flags, out=self.rgrads,
                                         workspace=self.bwd_ws)
             mark()
-            # the one host<->device rendezvous of the step: was the id list large enough?  With
-            # several ranks it has to happen before the first collective (a rank repeating its step
-            # alone would leave the others waiting), otherwise after everything has been enqueued.
-            if self.multi and not cabi.validate_binning(b):
-                continue
             cabi.sh_backward_fused(s.degrees_to_use, s.K, self.means, self.cam_pos, rgb_raw,
                                    g["v_colors"], out=(self.grads.v_dc, self.grads.v_rest))
             w1 = self.dist.allreduce_sh_async(self.grads)  # overlaps the projection backward
@@ -164,8 +163,7 @@ class Pipeline:
             cabi.project_backward(self.cam, self.means, self.scales, self.quats, p["radii"], g["v_xy"],
                                   g["v_conic"], None, self.vm_dev, self.pm_dev, out=self.pb_out)
             mark()
-            if self.multi or cabi.validate_binning(b):
-                break
+            break
         self.num_isects = b.num_isects
         if events is not None:
             events.extend(ev_local)

@@ -164,6 +164,7 @@ class BinWorkspace:
     def __init__(self):
         self.ws = None
         self.capacity = 0   # entries the id buffer / sort workspace currently hold
+        self.scan_done = None
         # pinned {M, longest tile list}: written by the scan kernel, read by the host
         self.m_host = torch.zeros(2, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else None
         self.list_stats = (C.c_int32 * 2)(0, 0)   # last validated values: scheduling hint
@@ -214,6 +215,9 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
             _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
                                  _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
                                  C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
+            if w.scan_done is None:
+                w.scan_done = torch.cuda.Event()
+            w.scan_done.record()   # validate_binning waits for THIS, not for the whole stream
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
                                  _p(depths), _p(tile_bins), _p(ids), _p(ws), C.c_size_t(ws_bytes),
                                  _stream()), "gs_bin_sort")
@@ -239,8 +243,10 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
 
 
 def validate_binning(b: Binned) -> bool:
-    """After a speculative bin_and_sort + the forward kernel: drain the stream, read M."""
-    torch.cuda.current_stream().synchronize()
+    """After a speculative bin_and_sort (typically once the forward kernel has been enqueued behind
+    it): wait until the scan kernel has stored the intersection count — an event wait, the stream
+    keeps running — and compare it with the capacity the id list was given."""
+    b.workspace.scan_done.synchronize()
     M = int(b.m_host[0])
     b.num_isects = M
     b.workspace.list_stats[0], b.workspace.list_stats[1] = M, int(b.m_host[1])

@@ -47,8 +47,9 @@ public:
 // with an id-list capacity guessed from the previous call (no host synchronisation).  Returns
 // { packed[N,12], gaussianIdsSorted[capacity] i32, tileBins[tiles,2] i32, count (pinned host i32[2]),
 //   tileOrder[tiles] i32 (tiles by descending list length) }.
-// After enqueuing the compositing kernel the caller runs validateBinning(count, ids): it drains the
-// stream and returns false if the guess was too small — repeat both steps then.
+// After enqueuing the compositing kernel the caller runs validateBinning(count, ids): it waits for
+// the scan kernel's event (not for the stream) and returns false if the guess was too small —
+// repeat both steps then.
 // (The reference's binAndSortGaussians, rasterize_gaussians.hpp:11-20, blocks on cumsum().item()
 // before it can allocate, and takes radius-square tile counts; this one derives them from the
 // CPU pixel rectangle — DESIGN.md.)

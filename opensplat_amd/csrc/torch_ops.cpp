@@ -10,6 +10,7 @@
 // GPU, and the package fails to import if libgsplat_hip.so is missing.
 #include "gsplat_ops.hpp"
 
+#include <ATen/hip/HIPEvent.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
@@ -175,6 +176,8 @@ tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_ou
 
 // ---- binning ------------------------------------------------------------------------------------
 static std::atomic<int64_t> g_capacityHint{0};
+// event recorded right after the scan kernel of the binning in flight on this thread
+static thread_local std::shared_ptr<at::cuda::CUDAEvent> g_scanDone;
 // {M, longest tile list} of the last validated frame: scheduling hint for the compositing kernels
 static int32_t g_listStats[2] = {0, 0};
 
@@ -214,6 +217,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
                              tileOrder.data_ptr<int32_t>(), mHost.data_ptr<int32_t>(),
                              ws.data_ptr(), wsBytes, s),
                  "gs_bin_scan");
+    // validateBinning waits for this event (the scan kernel has stored the count), not for the stream
+    auto scanDone = std::make_shared<at::cuda::CUDAEvent>();
+    scanDone->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    g_scanDone = scanDone;
     check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
                              tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
                              ws.data_ptr(), wsBytes, s),
@@ -221,10 +228,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
 }
 
-// Blocks until the stream has drained, then checks the intersection count of the binning against
-// the capacity it ran with.  false -> the lists were truncated: repeat binning + compositing.
+// Waits until the scan kernel of the preceding binAndSortGaussians has stored its intersection
+// count in pinned memory (an event wait: kernels enqueued behind it keep running, the host goes on
+// enqueuing afterwards) and checks it against the capacity the id list was given.
+// false -> the lists were truncated: repeat binning + compositing.
 bool validateBinning(const Tensor &mHost, const Tensor &idsSorted) {
-    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
+    if (g_scanDone) g_scanDone->synchronize();
+    else c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
     const int64_t M = mHost.data_ptr<int32_t>()[0];
     g_listStats[0] = (int32_t)M;
     g_listStats[1] = mHost.data_ptr<int32_t>()[1];
