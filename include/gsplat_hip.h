@@ -182,8 +182,10 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
  * synchronised — e.g. after the forward kernel has been enqueued) with capacity and repeats
  * scan + sort + compositing with a larger buffer if it was exceeded. */
 int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
-                int32_t *tile_bins, int32_t *gaussian_ids_sorted, void *workspace,
-                size_t workspace_bytes, gs_stream_t stream);
+                int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                const int32_t *list_stats /*host int32[2] {M, longest list} of an earlier frame,
+                                            nullable: lets the launch skip empty size classes*/,
+                void *workspace, size_t workspace_bytes, gs_stream_t stream);
 
 /* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
  * rasterize_gaussians.cpp:6-37 together with its caller's cumsum/.item(), :62-63): for callers

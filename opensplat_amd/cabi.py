@@ -219,8 +219,8 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                 w.scan_done = torch.cuda.Event()
             w.scan_done.record()   # validate_binning waits for THIS, not for the whole stream
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                                 _p(depths), _p(tile_bins), _p(ids), _p(ws), C.c_size_t(ws_bytes),
-                                 _stream()), "gs_bin_sort")
+                                 _p(depths), _p(tile_bins), _p(ids), w.list_stats, _p(ws),
+                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
             b = Binned(packed, tiles_hit, -1, ids, tile_bins)
             b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w

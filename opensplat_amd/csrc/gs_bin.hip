@@ -586,8 +586,9 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
 
 template <int PL, int B>
 __global__ void __launch_bounds__(64)
-k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int2 *__restrict__ bins,
-                   const uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
+                   int2 *__restrict__ bins, uint64_t *__restrict__ keys,
+                   int32_t *__restrict__ ids_sorted) {
     constexpr int CAP = 64 * PL, PER = B / 64;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
@@ -599,8 +600,20 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int2 *_
     // from the true total and repeats the call
     if (clamp_bins && range.y > capacity && threadIdx.x == 0)
         bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
-    if (n <= lo_n || n > hi_n) return;
+    if (n <= lo_n) return;
     const int lane = threadIdx.x;
+    if (n > hi_n) {
+        // a longer segment: normally another launch's job.  When the host skipped those launches
+        // (the previous frame had no long list) this wave sorts it in place in global memory —
+        // slow, but only ever hit on the frame where a list first outgrows this class.
+        if (!take_longer) return;
+        int P = 2;
+        while (P < n) P <<= 1;
+        GlobalKeys m{keys + start, n};
+        bitonic_sort(m, P, lane, 64);
+        for (int i = lane; i < n; i += 64) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+        return;
+    }
     const uint64_t *src = keys + start;
     uint64_t kk[PL];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
@@ -779,8 +792,8 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
 
 extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed,
                            const float *depths, int32_t *tile_bins,
-                           int32_t *gaussian_ids_sorted, void *workspace, size_t workspace_bytes,
-                           gs_stream_t stream) {
+                           int32_t *gaussian_ids_sorted, const int32_t *list_stats,
+                           void *workspace, size_t workspace_bytes, gs_stream_t stream) {
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0 || capacity == 0) return GS_OK;
@@ -816,10 +829,15 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory
     int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
-    hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                       capacity, 0, bins_rw, keys, gaussian_ids_sorted);
-    GS_LAUNCH_CHECK();
-    {
+    // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
+    // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
+    // longer: in place in global memory.  The launches for the longer classes are skipped when the
+    // previous frame's longest list (list_stats[1]) was comfortably inside the first class.
+    const bool only_short = list_stats && list_stats[0] > 0 && list_stats[1] <= 400;
+    if (!only_short) {
+        hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+                           capacity, 0, 0, bins_rw, keys, gaussian_ids_sorted);
+        GS_LAUNCH_CHECK();
         constexpr int CAP = 8192, B = 4096, NT = 256;
         const size_t lds = 8 * CAP + 4 * B + 64;
         GS_HIP_CHECK(hipFuncSetAttribute(
@@ -831,7 +849,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
     hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                       1, bins_rw, keys, gaussian_ids_sorted);
+                       1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
@@ -848,6 +866,6 @@ extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const floa
     GS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const int32_t M = *num_isects_host;
     if (M > capacity) return GS_ERR_CAPACITY;
-    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, workspace,
-                       workspace_bytes, stream);
+    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, num_isects_host,
+                       workspace, workspace_bytes, stream);
 }

@@ -273,6 +273,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                 GS_STAT(2, 1);
                 GS_STAT(3, (m0 != 0ull) + (m1 != 0ull));
                 GS_STAT(4, __builtin_popcountll(m0) + __builtin_popcountll(m1));
+                GS_STAT(5, (m0 != 0ull) && (m1 != 0ull) && ((m0 & m1) == 0ull));
+                GS_STAT(6, __builtin_popcountll(m0 & m1));
                 // exp(-sigma) only where needed; other lanes keep 0 => alpha 0 => no contribution
                 f2 vis = (f2)(0.0f);
                 if (m0 != 0ull) {

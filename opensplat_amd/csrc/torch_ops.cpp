@@ -223,7 +223,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     g_scanDone = scanDone;
     check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
                              tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                             ws.data_ptr(), wsBytes, s),
+                             g_listStats, ws.data_ptr(), wsBytes, s),
                  "gs_bin_sort");
     return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
 }

@@ -29,8 +29,8 @@ l.gs_debug_stats(buf, 1)
 pipe.step()
 l.gs_debug_stats(buf, 1)
 v = list(buf)
-names = ["entries", "halves", "halves_need", "exp_passes", "need_lane_pixels"]
+names = ["entries", "halves", "halves_need", "exp_passes", "need_lane_pixels", "both_strips_disjoint", "lanes_needing_both"]
 out = {"M": pipe.num_isects,
-       "forward": dict(zip(names, v[0:5])),
+       "forward": dict(zip(names, v[0:7])),
        "backward": dict(zip(["entries", "halves", "halves_need", "entries_any", "need_lane_pixels"], v[8:13]))}
 print(json.dumps(out))
