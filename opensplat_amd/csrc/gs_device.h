@@ -123,6 +123,30 @@ __device__ __forceinline__ float expf_glibc(float x, const uint64_t *tab) {
     return (float)y;
 }
 
+// Same result from the table in constant memory (per-lane global loads): for the backward's rare
+// near-threshold re-evaluation, which is not worth 2 KiB of LDS per wave.
+__device__ __forceinline__ float expf_glibc_cmem(float x) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    const uint32_t ki = (uint32_t)__double_as_longlong(kd);
+    kd -= Shift;
+    double r = z - kd;
+    const uint64_t t = kExp2fTab[ki & 31u];
+    const uint32_t hi = (uint32_t)(t >> 32) + (ki << 15);
+    const double s = __hiloint2double((int)hi, (int)(uint32_t)t);
+    double p = fma(C0, r, C1);
+    double r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(p, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
 template <bool EXACT>
 __device__ __forceinline__ float gs_exp(float x, const uint64_t *tab) {
     if constexpr (EXACT) {

@@ -38,13 +38,11 @@
 //     buffer is tracked as its dot product with the pixel's cotangent (one register per pixel
 //     instead of three); sigma moments are accumulated per pixel and converted to the nine
 //     gradient components once per entry and lane.
-//   * the nine partial gradients x 64 lanes are reduced with a transposing network:
-//     v_permlane32_swap / v_permlane16_swap fold value PAIRS across the wave's halves / rows
-//     (2 instructions merge two registers into one), DPP row_mirror / half_mirror / quad_perm
-//     finish inside 8-lane groups, after which nine different lanes hold the nine totals and ONE
-//     global_atomic_add_f32 instruction (nine active lanes hitting one 64-byte gradient record)
-//     scatters them — ~30 VALU + 1 VMEM per contributing (tile, Gaussian) instead of
-//     9 x (11 VALU + 1 VMEM).
+//   * the nine partial gradients x 64 lanes are summed through LDS (reduce9: nine conflict-free
+//     stores, four 16-byte reads and 15 adds per lane, one DPP quad reduction), after which nine
+//     lanes hold the nine totals and ONE global_atomic_add_f32 instruction (nine active lanes
+//     hitting one 64-byte gradient record) scatters them — against 9 x (4 DPP + 4 v_readlane +
+//     3 add + 1 atomic) in the first version of this kernel.
 //
 // Roofline: HBM traffic is one 48-byte gather per entry plus 20 B per pixel; DESIGN.md states the
 // algorithmic bytes used for roofline.achieved and the VALU accounting.
@@ -53,7 +51,6 @@
 namespace gs {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int kChunk = 64;  // entries staged per pass == wave width
 constexpr int kGradRec = 16;  // floats per Gaussian in the backward's gradient records (64 B)
@@ -338,47 +335,36 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Transposing wave reduction of nine per-lane values.  On return the totals sit in nine lanes:
-//   lane 0: v0   lane 32: v1   lane 16: v2   lane 48: v3   lane 8: v4   lane 40: v5
-//   lane 24: v6  lane 56: v7   lane 1: v8
-// (kReduceLane[i] below; checked on the device by tests via gs_debug_reduce9).
-__device__ __forceinline__ float swap_add32(float a, float b) {
-    // a.hi <-> b.lo, then add: lanes 0-31 get a.lo+a.hi, lanes 32-63 get b.lo+b.hi
-    u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float swap_add16(float a, float b) {
-    // odd rows of a <-> even rows of b, then add: rows 0,2 get a's row pairs, rows 1,3 get b's
-    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
+// Wave reduction of nine per-lane values through LDS.  Every lane stores its nine values (rows of
+// 64 + 4 floats: conflict-free stores), lane 4c + j then adds the 16 values [16j, 16j+16) of row c
+// (four 16-byte reads) and a DPP quad reduction leaves the total of component c in lane 4c:
+// 15 adds + 2 DPP per lane and 13 LDS instructions per entry.  Measured against the register-only
+// alternative (v_permlane32/16_swap folding value pairs across halves / rows + DPP inside rows:
+// 8 swaps at ~8 cycles each + ~25 VALU): 632 vs 673 us for the backward kernel at C2.
+constexpr int kRedStride = 68;
 __device__ __forceinline__ float reduce9(float v0, float v1, float v2, float v3, float v4,
-                                         float v5, float v6, float v7, float v8, int lane) {
-    const float p01 = swap_add32(v0, v1), p23 = swap_add32(v2, v3);
-    const float p45 = swap_add32(v4, v5), p67 = swap_add32(v6, v7);
-    const float p8 = swap_add32(v8, v8);
-    const float qa = swap_add16(p01, p23);  // rows: v0, v2, v1, v3
-    const float qb = swap_add16(p45, p67);  // rows: v4, v6, v5, v7
-    float q8 = swap_add16(p8, p8);          // every row: 16 partials of v8
-    const float ra = qa + dpp_f<0x140>(qa);  // row_mirror: lanes 0-7 hold 8 partials
-    const float rb = qb + dpp_f<0x140>(qb);
-    q8 = q8 + dpp_f<0x140>(q8);
-    float r = (lane & 8) ? rb : ra;
-    r += dpp_f<0x141>(r);   // row_half_mirror
-    q8 += dpp_f<0x141>(q8);
-    r += dpp_f<0x4E>(r);    // quad_perm [2,3,0,1]
-    q8 += dpp_f<0x4E>(q8);
-    r += dpp_f<0xB1>(r);    // quad_perm [1,0,3,2]
-    q8 += dpp_f<0xB1>(q8);
-    return (lane == 1) ? q8 : r;
+                                             float v5, float v6, float v7, float v8, int lane,
+                                             float *red) {
+    red[0 * kRedStride + lane] = v0; red[1 * kRedStride + lane] = v1;
+    red[2 * kRedStride + lane] = v2; red[3 * kRedStride + lane] = v3;
+    red[4 * kRedStride + lane] = v4; red[5 * kRedStride + lane] = v5;
+    red[6 * kRedStride + lane] = v6; red[7 * kRedStride + lane] = v7;
+    red[8 * kRedStride + lane] = v8;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int c = min(lane >> 2, 8), j = lane & 3;
+    const float4 *src = reinterpret_cast<const float4 *>(red + c * kRedStride + 16 * j);
+    const float4 a = src[0], b = src[1], d = src[2], e = src[3];
+    float r = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) +
+              (((d.x + d.y) + (d.z + d.w)) + ((e.x + e.y) + (e.z + e.w)));
+    r += dpp_f<0xB1>(r);  // quad_perm [1,0,3,2]
+    r += dpp_f<0x4E>(r);  // quad_perm [2,3,0,1]
+    __builtin_amdgcn_wave_barrier();  // the next entry's stores come after these loads
+    return r;
 }
-
-// role of a lane after reduce9: index of the value it holds, -1 if none.  Lanes 0,8,...,56 hold
-// value bitreverse3(lane >> 3) (the two swap stages deal values out by halves, then by rows).
 __device__ __forceinline__ int reduce9_role(int lane) {
-    if (lane == 1) return 8;
-    if (lane & 7) return -1;
-    return (int)((0x73516240u >> (4 * (lane >> 3))) & 0xFu);
+    return ((lane & 3) == 0 && lane < 36) ? (lane >> 2) : -1;
 }
 
 __global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ in,
@@ -388,7 +374,8 @@ __global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ 
     float v[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) v[i] = p[i * 64 + lane];
-    const float r = reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lane);
+    __shared__ __attribute__((aligned(16))) float red[9 * kRedStride];
+    const float r = reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], lane, red);
     const int role = reduce9_role(lane);
     if (role >= 0) out[(size_t)blockIdx.x * 9 + role] = r;
 }
@@ -405,7 +392,6 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                      const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                      float *__restrict__ gacc) {
     __shared__ Staged stage[kChunk];
-    __shared__ uint64_t exp_tab[kExpTabLds];
     const int lane = threadIdx.x;
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
@@ -415,7 +401,6 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
     if (rows == 0u) return;
     const uint32_t keep = 0xFFFFu | (rows << 16);
     const int tile_x0 = (tile % tiles_x) * GS_TILE, tile_y0 = (tile / tiles_x) * GS_TILE;
-    if (EXACT) load_exp_table(exp_tab, lane, 64);
 
     const int lx = lane & 15, ly = lane >> 4;
     const int px = tile_x0 + lx;
@@ -463,6 +448,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
     // gacc[g][0..8] = {v_x, v_y, v_A, v_B, v_C, v_r, v_g, v_b, v_opacity}: the nine lanes of the one
     // atomic instruction hit ONE cache line, which the L2 serves ~4x faster than nine lines
     // (measured, scripts/ubench/atomics.hip); k_unpack_grads splits the records afterwards.
+    __shared__ __attribute__((aligned(16))) float red[9 * kRedStride];
     const int role = reduce9_role(lane);
     float *wbase = gacc + (role >= 0 ? role : 0);
     const uint32_t colbit = 1u << lx;
@@ -547,8 +533,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                         (m0 & __builtin_amdgcn_ballot_w64(fabsf(alpha.x - thr) < 1.0e-8f)) |
                         (m1 & __builtin_amdgcn_ballot_w64(fabsf(alpha.y - thr) < 1.0e-8f));
                     if (ma != 0ull) {
-                        if (amb0) { vis.x = expf_glibc(-sg.x, exp_tab); alpha.x = oo.x * vis.x; }
-                        if (amb1) { vis.y = expf_glibc(-sg.y, exp_tab); alpha.y = oo.x * vis.y; }
+                        if (amb0) { vis.x = expf_glibc_cmem(-sg.x); alpha.x = oo.x * vis.x; }
+                        if (amb1) { vis.y = expf_glibc_cmem(-sg.y); alpha.y = oo.x * vis.y; }
                     }
                 }
                 const bool ok0 = alpha.x >= (1.0f / 255.0f);
@@ -598,7 +584,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
             const float g_B = hdx * vs1;       // 0.5 * v_sigma * dx * dy   (gsplat_cpu.cpp:361-363)
             const float g_C = 0.5f * vs2;      // 0.5 * v_sigma * dy^2
             const float r = reduce9(g_x, g_y, g_A, g_B, g_C, gr.x + gr.y, gg.x + gg.y,
-                                    gb.x + gb.y, S0, lane);
+                                    gb.x + gb.y, S0, lane, red);
             if (role >= 0) {
                 atomicAdd(wbase + (size_t)en.id * kGradRec, r);
             }

@@ -353,8 +353,8 @@ def test_c2_crop_matches_oracle(c2_run, restated):
 
 
 def test_reduce9_network():
-    """The backward kernel's transposing wave reduction (permlane32/16 swap + DPP) sums each of the
-    nine values over the 64 lanes and delivers total i at the lane that scatters component i."""
+    """The backward kernel's wave reduction (through LDS + a DPP quad step) sums each of the nine
+    values over the 64 lanes and delivers total i at the lane that scatters component i."""
     from opensplat_amd import cabi
 
     rs = np.random.RandomState(5)
