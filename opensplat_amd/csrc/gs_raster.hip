@@ -46,6 +46,8 @@
 //
 // Roofline: HBM traffic is one 48-byte gather per entry plus 20 B per pixel; DESIGN.md states the
 // algorithmic bytes used for roofline.achieved and the VALU accounting.
+#include <type_traits>
+
 #include "gs_device.h"
 
 namespace gs {
@@ -466,19 +468,17 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
         __syncthreads();
         if (hi - kChunk - lane >= range.x) fetch_entry(nxt, hi - kChunk - lane, ids, packed);
         const int n = min(kChunk, hi - range.x + 1);
-        for (int t = 0; t < n; t++) {
+        // One entry; BINDS (compile-time) as in the forward kernel.
+        auto entry = [&](int t, uint32_t mask, uint32_t sbits, auto binds_tag) {
+            constexpr bool rect_binds = decltype(binds_tag)::value;
             const Staged &en = stage[t];
-            const uint32_t mask = __builtin_amdgcn_readfirstlane(en.mask) & keep;
-            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(en.smax));
-            const bool rect_binds = (sbits & 1u) != 0u;  // wave-uniform
             const int e = hi - t;  // index of this entry in the sorted list
             const f2 dx2 = en.xx - pxf2;
             const float dx = dx2.x;
             // sigma is evaluated from copies of dx / dy that are NaN outside the rectangle when
             // the rectangle binds (a NaN sigma fails both compares); the moments use the real ones
             f2 dxs = dx2;
-            if (rect_binds) {  // rare: keep it a scalar branch
-                asm volatile("; rectangle binds");
+            if (rect_binds) {
                 if ((mask & colbit) == 0u) dxs = (f2)(qnan());
             }
             const f2 Adx = en.AA * dxs, Adxdx = Adx * dxs, Bdx = en.BB * dxs;
@@ -493,7 +493,6 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                 GS_STAT(9, 1);
                 f2 pys = py2[h];
                 if (rect_binds) {
-                    asm volatile("; rectangle binds");
                     if ((mask & (1u << (16 + ly + 8 * h))) == 0u) pys.x = qnan();
                     if ((mask & (1u << (16 + ly + 8 * h + 4))) == 0u) pys.y = qnan();
                 }
@@ -568,7 +567,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
                 s1 = s1 + ud;
                 s2 = __builtin_elementwise_fma(ud, dy, s2);
             }
-            if (!any) continue;
+            if (!any) return;
             GS_STAT(11, 1);
             // per-lane conversion of the moments to the nine gradient components
             const float S0 = s0.x + s0.y, S1 = s1.x + s1.y, S2 = s2.x + s2.y;
@@ -588,6 +587,12 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
             if (role >= 0) {
                 atomicAdd(wbase + (size_t)en.id * kGradRec, r);
             }
+        };
+        for (int t = 0; t < n; t++) {
+            const uint32_t mask = __builtin_amdgcn_readfirstlane(stage[t].mask) & keep;
+            const uint32_t sbits = __builtin_amdgcn_readfirstlane(__float_as_uint(stage[t].smax));
+            if (sbits & 1u) entry(t, mask, sbits, std::true_type{});   // wave-uniform, rare
+            else entry(t, mask, sbits, std::false_type{});
         }
     }
 }
