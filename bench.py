@@ -336,7 +336,10 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # the PMC passes are collected on the default command (C2 / C4 per-rank workload, parity exp)
+        default_workload = (scene.N == 1_000_000 and scene.W == 1920 and scene.H == 1080
+                            and not args.fast_exp and not args.hot)
+        if os.path.exists(tpath) and default_workload:
             try:
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
