@@ -17,8 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
-HIP_SOURCES = ["gs_api.hip", "gs_project.hip", "gs_sh.hip", "gs_bin.hip", "gs_raster.hip"]
-HIP_HEADERS = ["gs_device.h", os.path.join(INCLUDE, "gsplat_hip.h")]
+HIP_SOURCES = ["gs_api.hip", "gs_project.hip", "gs_sh.hip", "gs_bin.hip", "gs_raster.hip",
+               "gs_loss.hip", "gs_adam.hip"]
+HIP_HEADERS = ["gs_device.h", os.path.join(INCLUDE, "gsplat_hip.h"),
+               os.path.join(INCLUDE, "gsplat_train.h")]
 HIP_LIB = os.path.join(CSRC, "libgsplat_hip.so")
 TORCH_LIB = os.path.join(CSRC, "libgsplat_torch.so")
 

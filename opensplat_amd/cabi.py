@@ -29,6 +29,9 @@ SYMBOLS = [
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
     "gs_debug_reduce9", "gs_debug_time_next_kernel",
 ]
+# every symbol include/gsplat_train.h declares
+TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
+                 "gs_sched_lr"]
 
 
 class GsCamera(C.Structure):
@@ -56,6 +59,10 @@ def lib() -> C.CDLL:
         l.gs_bin_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
         l.gs_rasterize_backward_workspace_bytes.restype = C.c_size_t
         l.gs_rasterize_backward_workspace_bytes.argtypes = [C.c_int]
+        l.gs_loss_workspace_bytes.restype = C.c_size_t
+        l.gs_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        l.gs_sched_lr.restype = C.c_float
+        l.gs_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
         _lib = l
     return _lib
 
@@ -352,3 +359,58 @@ def sh_backward_fused(degrees_to_use, K, means, cam_pos, rgb_raw, v_colors, out=
                                       _p(rgb_raw), _p(v_colors), _p(v_dc), _p(v_rest), _stream()),
            "gs_sh_backward_fused")
     return v_dc, v_rest
+
+
+# ---------------------------------------------------------------------------------------------
+# loss + optimiser (include/gsplat_train.h)
+
+class GsAdamGroup(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p),
+                ("exp_avg_sq", C.c_void_p), ("n", C.c_int64), ("lr", C.c_double)]
+
+
+def ssim_window():
+    """The reference's 1-D SSIM window (ssim.cpp:39-45) as a list of 11 floats."""
+    g = (C.c_float * 11)()
+    _check(lib().gs_ssim_window(g), "gs_ssim_window")
+    return list(g)
+
+
+def main_loss(rendered, gt, ssim_weight=0.2, grad_scale=1.0, want_grad=True, out=None,
+              workspace=None):
+    """Model::mainLoss + backward.  rendered, gt: [H, W, 3] GPU tensors.
+    -> (loss[3] = {mainLoss, l1, ssim} device tensor, v_rendered [H, W, 3] or None)."""
+    H, W = rendered.shape[0], rendered.shape[1]
+    assert rendered.shape == (H, W, 3) and gt.shape == (H, W, 3)
+    need = lib().gs_loss_workspace_bytes(W, H)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=rendered.device, dtype=torch.uint8)
+    if out is None:
+        out = (torch.empty(3, device=rendered.device, dtype=torch.float32),
+               torch.empty_like(rendered) if want_grad else None)
+    loss, v = out
+    _check(lib().gs_main_loss(C.c_int(W), C.c_int(H), _p(rendered), _p(gt), C.c_float(ssim_weight),
+                              C.c_float(grad_scale), _p(loss), _p(v) if want_grad else C.c_void_p(0),
+                              _p(workspace), C.c_size_t(workspace.numel()), _stream()),
+           "gs_main_loss")
+    return loss, (v if want_grad else None)
+
+
+def adam_step(groups, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """groups: list of (param, grad, exp_avg, exp_avg_sq, lr) flat GPU tensors, updated in place
+    (Model::optimizersStep, model.cpp:236-243; lr per group as in model.cpp:61-66)."""
+    arr = (GsAdamGroup * len(groups))()
+    for i, (p, g, m, v, lr) in enumerate(groups):
+        n = p.numel()
+        assert g.numel() == n and m.numel() == n and v.numel() == n
+        arr[i].param, arr[i].grad = p.data_ptr(), g.data_ptr()
+        arr[i].exp_avg, arr[i].exp_avg_sq = m.data_ptr(), v.data_ptr()
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        arr[i].n, arr[i].lr = n, float(lr)
+    _check(lib().gs_adam_step(C.c_int(len(groups)), arr, C.c_int64(step), C.c_double(beta1),
+                              C.c_double(beta2), C.c_double(eps), _stream()), "gs_adam_step")
+
+
+def sched_lr(lr_init, lr_final, max_steps, step):
+    return float(lib().gs_sched_lr(lr_init, lr_final, max_steps, step))

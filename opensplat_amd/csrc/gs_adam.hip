@@ -1,0 +1,130 @@
+// gs_adam.hip — Model::optimizersStep (model.cpp:236-243): the six torch::optim::Adam instances of
+// model.cpp:61-66 as ONE launch over all parameter groups.  C ABI: include/gsplat_train.h.
+//
+// libtorch's Adam::step is ~10 element-wise kernels per optimiser (mul_, add_, mul_, addcmul_,
+// sqrt, div, add_, addcdiv_ + temporaries), 60 launches and ~13 passes over each tensor per
+// training step.  This is one pass: 16 B read + 12 B written per parameter (p, g, m, v -> p, m, v),
+// 128-bit accesses, pure HBM streaming (59 parameters per Gaussian at SH degree 3: 1.65 GB at
+// N = 1 M -> 0.26 ms at 6.3 TB/s).
+//
+// The arithmetic is ATen's, operation for operation (pinned against libtorch 2.10's CPU kernels by
+// oracle/train_oracle.c, which this kernel is tested against):
+//   m = fma(1 - b1, g, m * b1)            exp_avg.mul_(b1).add_(g, 1 - b1)
+//   v = fma((1 - b2) * g, g, v * b2)      exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+//   denom = sqrt(v) / sqrt(1 - b2^t) + eps
+//   p = p + (-(lr / (1 - b1^t)) * m) / denom      p.addcdiv_(m, denom, -step_size)
+#include <math.h>
+
+#include "gs_device.h"
+#include "../../include/gsplat_train.h"
+
+namespace gs {
+
+struct AdamArgs {
+    float *p[GS_ADAM_MAX_GROUPS];
+    const float *g[GS_ADAM_MAX_GROUPS];
+    float *m[GS_ADAM_MAX_GROUPS];
+    float *v[GS_ADAM_MAX_GROUPS];
+    int64_t n[GS_ADAM_MAX_GROUPS];
+    int64_t chunk_start[GS_ADAM_MAX_GROUPS + 1];  // in units of 4 floats
+    float neg_step_size[GS_ADAM_MAX_GROUPS];
+    uint32_t aligned;  // bit i: all four pointers of group i are 16-byte aligned
+    int num;
+    float beta1, beta2, omb1, omb2, bc2_sqrt, eps;
+};
+
+static __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float nss,
+                                             const AdamArgs &a) {
+    m = fmaf(a.omb1, g, m * a.beta1);
+    v = fmaf(a.omb2 * g, g, v * a.beta2);
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + (nss * m) / denom;
+}
+
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
+    const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= a.chunk_start[a.num]) return;
+    int grp = 0;
+#pragma unroll
+    for (int i = 1; i < GS_ADAM_MAX_GROUPS; i++)
+        if (i < a.num && chunk >= a.chunk_start[i]) grp = i;
+    const int64_t i0 = 4 * (chunk - a.chunk_start[grp]);
+    const int64_t n = a.n[grp];
+    float *p = a.p[grp] + i0, *m = a.m[grp] + i0, *v = a.v[grp] + i0;
+    const float *g = a.g[grp] + i0;
+    const float nss = a.neg_step_size[grp];
+    if (i0 + 4 <= n && ((a.aligned >> grp) & 1u)) {
+        float4 P = *reinterpret_cast<const float4 *>(p);
+        const float4 G = *reinterpret_cast<const float4 *>(g);
+        float4 M = *reinterpret_cast<const float4 *>(m);
+        float4 V = *reinterpret_cast<const float4 *>(v);
+        adam1(P.x, G.x, M.x, V.x, nss, a);
+        adam1(P.y, G.y, M.y, V.y, nss, a);
+        adam1(P.z, G.z, M.z, V.z, nss, a);
+        adam1(P.w, G.w, M.w, V.w, nss, a);
+        *reinterpret_cast<float4 *>(p) = P;
+        *reinterpret_cast<float4 *>(m) = M;
+        *reinterpret_cast<float4 *>(v) = V;
+    } else {
+        for (int k = 0; k < 4 && i0 + k < n; k++) {
+            float P = p[k], M = m[k], V = v[k];
+            adam1(P, g[k], M, V, nss, a);
+            p[k] = P;
+            m[k] = M;
+            v[k] = V;
+        }
+    }
+}
+
+}  // namespace gs
+
+extern "C" int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t step, double beta1,
+                            double beta2, double eps, gs_stream_t stream) {
+    using namespace gs;
+    if (num_groups < 0 || num_groups > GS_ADAM_MAX_GROUPS || step < 1) return GS_ERR_INVALID_ARGUMENT;
+    if (num_groups == 0) return GS_OK;
+    if (!groups) return GS_ERR_INVALID_ARGUMENT;
+    AdamArgs a = {};
+    // libtorch computes the bias corrections in double and casts scalars to the tensors' float
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    a.num = num_groups;
+    a.beta1 = (float)beta1;
+    a.beta2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1);
+    a.omb2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = (float)eps;
+    int64_t chunks = 0;
+    for (int i = 0; i < num_groups; i++) {
+        const GsAdamGroup &gr = groups[i];
+        if (gr.n < 0) return GS_ERR_INVALID_ARGUMENT;
+        if (gr.n > 0 && (!gr.param || !gr.grad || !gr.exp_avg || !gr.exp_avg_sq))
+            return GS_ERR_INVALID_ARGUMENT;
+        a.p[i] = gr.param;
+        a.g[i] = gr.grad;
+        a.m[i] = gr.exp_avg;
+        a.v[i] = gr.exp_avg_sq;
+        a.n[i] = gr.n;
+        a.neg_step_size[i] = (float)(-(gr.lr / bc1));
+        const uintptr_t bits = (uintptr_t)gr.param | (uintptr_t)gr.grad | (uintptr_t)gr.exp_avg |
+                               (uintptr_t)gr.exp_avg_sq;
+        if ((bits & 15u) == 0) a.aligned |= 1u << i;
+        a.chunk_start[i] = chunks;
+        chunks += (gr.n + 3) / 4;
+    }
+    for (int i = num_groups; i <= GS_ADAM_MAX_GROUPS; i++) a.chunk_start[i] = chunks;
+    if (chunks == 0) return GS_OK;
+    const int64_t blocks = (chunks + 255) / 256;
+    if (blocks > 0x7fffffffLL) return GS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" float gs_sched_lr(float lr_init, float lr_final, int max_steps, int step) {
+    float t = (float)step / (float)max_steps;  // optim_scheduler.cpp:5
+    t = t < 1.0f ? t : 1.0f;
+    t = t > 0.0f ? t : 0.0f;
+    return expf(logf(lr_init) * (1.0f - t) + logf(lr_final) * t);
+}

@@ -178,3 +178,45 @@ def config_c4(rank: int, N: int = 1_000_000) -> Scene:
     s = camera_scene(N, 1920, 1080, K=16, seed=3, sigma_px=(0.5, 4.0), yaw_deg=yaws[rank % 8],
                      name=f"C4_cam{rank}")
     return s
+
+
+# ---------------------------------------------------------------------------------------------
+# inputs of the loss / optimiser tests and measurements
+
+def loss_images(W: int, H: int, seed: int = 0, noise: float = 0.1):
+    """(rendered, gt) as float32 [H, W, 3]: a smooth random "photo" in [0, 1] (what
+    Camera::getImage hands to Model::mainLoss) and a rendering of it that is off by low-frequency
+    error + noise, clamped to <= 1 like Model::forward's output (model.cpp:222), with a patch of
+    exactly equal pixels (sign(0) in the L1 gradient) and a saturated patch."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32),
+                         indexing="ij")
+    gt = np.zeros((H, W, 3), np.float32)
+    for _ in range(6):
+        fx, fy = rng.uniform(0.005, 0.12, 2)
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        amp = rng.uniform(0.05, 0.25, 3)
+        for c in range(3):
+            gt[..., c] += amp[c] * np.sin(fx * xx + fy * yy + ph[c]).astype(np.float32)
+    gt = np.clip(gt + 0.5, 0.0, 1.0).astype(np.float32)
+    err = 0.15 * np.sin(0.03 * xx[..., None] + rng.uniform(0, 6, 3)).astype(np.float32)
+    rendered = gt + err + noise * rng.standard_normal((H, W, 3)).astype(np.float32)
+    rendered = np.minimum(np.maximum(rendered, 0.0), 1.0).astype(np.float32)
+    h4, w4 = max(H // 4, 1), max(W // 4, 1)
+    rendered[:h4, :w4] = gt[:h4, :w4]          # exactly equal
+    rendered[-h4:, -w4:] = 1.0                 # saturated
+    return np.ascontiguousarray(rendered), np.ascontiguousarray(gt)
+
+
+def adam_problem(n: int, steps: int, seed: int = 0):
+    """(param0, [grad_1 .. grad_steps]) float32: gradients spanning 1e-12 .. 1e3 in magnitude,
+    with exact zeros (Gaussians outside the frustum get zero gradients every step)."""
+    rng = np.random.RandomState(seed)
+    p = rng.standard_normal(n).astype(np.float32)
+    mag = (10.0 ** rng.uniform(-12, 3, n)).astype(np.float32)
+    grads = []
+    for _ in range(steps):
+        g = (mag * rng.standard_normal(n)).astype(np.float32)
+        g[rng.rand(n) < 0.1] = 0.0
+        grads.append(g)
+    return p, grads

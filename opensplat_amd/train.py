@@ -1,0 +1,158 @@
+"""One optimiser step of OpenSplat's training loop on the MI355X kernels.
+
+Host-side mirror of the reference's iteration (opensplat.cpp:151-170):
+
+    model.optimizersZeroGrad()                      -> nothing to do: every gradient is overwritten
+    rgb = model.forward(cam, step)                  -> projection + SH + binning + compositing with the
+                                                       Model::forward glue fused in (row f1)
+    mainLoss = model.mainLoss(rgb, gt, ssimWeight)  -> gs_main_loss: value AND d loss / d rgb in one call
+    mainLoss.backward()                             -> compositing / SH / projection backward
+    [multi-camera batch: one camera per rank]       -> sum all-reduce of the flat gradient buffer (RCCL)
+    model.optimizersStep()                          -> gs_adam_step: the six groups in one launch
+    model.schedulersStep(step)                      -> gs_sched_lr for the means (model.cpp:68,245-247)
+
+Everything goes through the C ABI (opensplat_amd/cabi.py); torch only owns the device buffers and
+the process group.  Parameters, gradients and both Adam moments live in four flat buffers with the
+same layout (dist.GradBuffer: [features_rest | features_dc | means | scales | quats | opacities]),
+so the Adam groups are plain slices and the all-reduce needs no gather copy.
+
+A batch of B cameras = B ranks; the step's loss is the mean of the per-camera losses (each rank
+scales its cotangent by 1/B, the all-reduce sums).  Model::afterTrain (densification, model.cpp:
+311-494) is row f4 and not part of this step.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import cabi, dist
+
+
+class Trainer:
+    # model.cpp:61-66, 68 (means decay to lr / 100 over max_steps)
+    LR = dict(means=0.00016, scales=0.005, quats=0.001, features_dc=0.0025,
+              features_rest=0.000125, opacities=0.05)
+    MEANS_LR_FINAL = 0.0000016
+
+    def __init__(self, means, log_scales, quats, opacity_logits, features_dc, features_rest,
+                 device, max_steps: int = 30000, ssim_weight: float = 0.2):
+        """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
+        [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
+                                      dtype=torch.float32).to(device)
+        N = means.shape[0]
+        K = 1 + (int(features_rest.shape[1]) if features_rest is not None else 0)
+        self.N, self.K, self.dev = N, K, device
+        self.max_steps, self.ssim_weight = max_steps, ssim_weight
+        self.params = dist.GradBuffer(N, K, device)   # same layout, holds the parameters
+        self.grads = dist.GradBuffer(N, K, device)
+        self.exp_avg = dist.GradBuffer(N, K, device)
+        self.exp_avg_sq = dist.GradBuffer(N, K, device)
+        P = self.params
+        P.v_means.copy_(t(means)); P.v_scales.copy_(t(log_scales)); P.v_quats.copy_(t(quats))
+        P.v_opacity.copy_(t(opacity_logits).reshape(-1)); P.v_dc.copy_(t(features_dc))
+        if K > 1:
+            P.v_rest.copy_(t(features_rest))
+        self.step_count = 0
+        self.means_lr = self.LR["means"]
+        self._shape = None
+        self.world = torch.distributed.get_world_size() if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+
+    # the six tensors, as views of the flat parameter buffer
+    means = property(lambda s: s.params.v_means)
+    log_scales = property(lambda s: s.params.v_scales)
+    quats = property(lambda s: s.params.v_quats)
+    opacity_logits = property(lambda s: s.params.v_opacity)
+    features_dc = property(lambda s: s.params.v_dc)
+    features_rest = property(lambda s: s.params.v_rest)
+
+    def _buffers(self, W, H):
+        if self._shape == (W, H):
+            return
+        N, dev = self.N, self.dev
+        f = dict(device=dev, dtype=torch.float32)
+        i = dict(device=dev, dtype=torch.int32)
+        self.proj = dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
+                         radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
+                         num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
+                         cov2d=torch.empty((N, 3), **f))
+        self.sh_out = (torch.empty((N, 3), **f), torch.empty((N, 3), **f))
+        self.bin_ws = cabi.BinWorkspace()
+        self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
+                        final_idx=torch.empty((H, W), **i), img_clamped=torch.empty((H, W, 3), **f))
+        self.bwd_ws = torch.empty((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
+                                  device=dev, dtype=torch.uint8)
+        self.g2d = torch.zeros(N * 8, **f)
+        self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
+                           v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.grads.v_opacity)
+        self.loss_ws = torch.empty(cabi.lib().gs_loss_workspace_bytes(W, H), device=dev,
+                                   dtype=torch.uint8)
+        self.loss_out = (torch.empty(3, **f), torch.empty((H, W, 3), **f))
+        self._shape = (W, H)
+
+    def render(self, cam: dict, background, degrees_to_use: int):
+        """Model::forward (model.cpp:83-225) for one camera -> (clamped rgb [H,W,3], binned, raw)."""
+        W, H = cam["W"], cam["H"]
+        self._buffers(W, H)
+        gcam = cabi.make_camera(cam["viewmat"], cam["projmat"], cam["fx"], cam["fy"], cam["cx"],
+                                cam["cy"], W, H, flags=cabi.GS_CAM_LOG_SCALES)
+        vm = np.asarray(cam["viewmat"], dtype=np.float32)
+        cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)   # model.cpp:95
+        flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
+        while True:
+            p = cabi.project_forward(gcam, self.means, self.log_scales, self.quats, out=self.proj)
+            colors, rgb_raw = cabi.sh_forward_fused(degrees_to_use, self.means, cam_pos,
+                                                    self.features_dc,
+                                                    self.features_rest if self.K > 1 else None,
+                                                    out=self.sh_out)
+            b = cabi.bin_and_sort(W, H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
+                                  self.opacity_logits, p["cov2d"], self.bin_ws, flags=flags,
+                                  speculative=True)
+            f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
+            if cabi.validate_binning(b):   # id-list capacity guess was large enough
+                break
+        self._ctx = (gcam, cam_pos, p, rgb_raw, b, f, flags, degrees_to_use, background, W, H)
+        return f["img_clamped"]
+
+    def backward(self, v_rgb):
+        """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
+        gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
+        g = cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"],
+                                    v_rgb, flags, out=self.rgrads, workspace=self.bwd_ws,
+                                    img_raw=f["img"])
+        cabi.sh_backward_fused(deg, self.K, self.means, cam_pos, rgb_raw, g["v_colors"],
+                               out=(self.grads.v_dc, self.grads.v_rest if self.K > 1 else None))
+        w1 = dist.allreduce_sh_async(self.grads)      # overlaps the projection backward
+        cabi.project_backward(gcam, self.means, self.log_scales, self.quats, p["radii"], g["v_xy"],
+                              g["v_conic"], None,
+                              out=dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
+                                       v_quats=self.grads.v_quats))
+        w2 = dist.allreduce_rest_async(self.grads)
+        dist.wait_all(w1, w2)
+
+    def adam_groups(self):
+        P, G, M, V = self.params, self.grads, self.exp_avg, self.exp_avg_sq
+        lr = dict(self.LR, means=self.means_lr)
+        names = [("v_means", "means"), ("v_scales", "scales"), ("v_quats", "quats"),
+                 ("v_dc", "features_dc"), ("v_rest", "features_rest"), ("v_opacity", "opacities")]
+        return [(P.views[v], G.views[v], M.views[v], V.views[v], lr[n]) for v, n in names
+                if P.views[v].numel() > 0]
+
+    def optimizer_step(self):
+        """Model::optimizersStep + schedulersStep (model.cpp:236-247)."""
+        self.step_count += 1
+        cabi.adam_step(self.adam_groups(), self.step_count)
+        # OptimScheduler::step(step) sets the lr the NEXT optimiser step uses (opensplat.cpp:168-169)
+        self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps,
+                                      self.step_count)
+
+    def train_step(self, cam: dict, gt, background, degrees_to_use: int):
+        """One iteration of opensplat.cpp:151-170 for this rank's camera of the batch.
+        Returns the device tensor {mainLoss, l1, ssim} of THIS camera (no host sync)."""
+        rgb = self.render(cam, background, degrees_to_use)
+        loss, v_rgb = cabi.main_loss(rgb, gt, self.ssim_weight, 1.0 / self.world, True,
+                                     out=self.loss_out, workspace=self.loss_ws)
+        self.backward(v_rgb)
+        self.optimizer_step()
+        return loss

@@ -160,6 +160,37 @@ class Restated(_Base):
         return y
 
 
+    # ---- SURVEY.md §8 row f2 (oracle/train_oracle.c) ------------------------------------------
+    def ssim_window(self):
+        g, gp = _fo((11,)); w2, wp = _fo((11, 11))
+        self.lib.orc_ssim_gaussian(C.c_float(1.5), gp)
+        self.lib.orc_ssim_window(wp)
+        return g, w2
+
+    def main_loss(self, rendered, gt, ssim_weight, want_grad=True):
+        H, W = rendered.shape[:2]
+        r, rp = _f(rendered); g, gp = _f(gt)
+        loss, lp = _fo((3,)); v, vp = _fo((H, W, 3))
+        rc = self.lib.orc_main_loss(C.c_int(W), C.c_int(H), rp, gp, C.c_float(ssim_weight), lp,
+                                    vp if want_grad else None)
+        assert rc == 0
+        return loss, (v if want_grad else None)
+
+    def adam_step(self, p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+        """In place on float32 numpy arrays p, m, v."""
+        self.lib.orc_adam_step.argtypes = [C.c_int64, _f32p, _f32p, _f32p, _f32p, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, C.c_int64]
+        for a in (p, m, v):
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        gg, ggp = _f(g)
+        self.lib.orc_adam_step(p.size, p.ctypes.data_as(_f32p), ggp, m.ctypes.data_as(_f32p),
+                               v.ctypes.data_as(_f32p), lr, beta1, beta2, eps, step)
+
+    def sched_lr(self, lr_init, lr_final, max_steps, step):
+        self.lib.orc_sched_lr.restype = C.c_float
+        self.lib.orc_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
+        return float(self.lib.orc_sched_lr(lr_init, lr_final, max_steps, step))
+
 class Reference(_Base):
     name = "reference"
 
@@ -281,6 +312,43 @@ class Reference(_Base):
             bgp, voutp, ip, vmnp, vsp, vqp, vcp, vop_, times))
         return dict(img=img, v_means=vmn, v_scales=vs, v_quats=vq, v_coeffs=vc, v_opacities=vo_,
                     fwd_ms=times[0], bwd_ms=times[1])
+
+
+    # ---- SURVEY.md §8 row f2 (oracle/ref_train_shim.cpp) --------------------------------------
+    def _tchk(self, rc):
+        if rc != 0:
+            self.lib.ref_train_last_error.restype = C.c_char_p
+            raise RuntimeError("reference threw: " + self.lib.ref_train_last_error().decode())
+
+    def ssim_window(self):
+        g, gp = _fo((11,)); w2, wp = _fo((11, 11))
+        self._tchk(self.lib.ref_ssim_window(wp, gp))
+        return g, w2
+
+    def main_loss(self, rendered, gt, ssim_weight, want_grad=True):
+        H, W = rendered.shape[:2]
+        r, rp = _f(rendered); g, gp = _f(gt)
+        loss, lp = _fo((3,)); v, vp = _fo((H, W, 3))
+        ms = C.c_double()
+        self._tchk(self.lib.ref_main_loss(C.c_int(W), C.c_int(H), rp, gp, C.c_float(ssim_weight), lp,
+                                          vp if want_grad else None, C.byref(ms)))
+        self.last_ms = ms.value
+        return loss, (v if want_grad else None)
+
+    def adam_steps(self, p, grads, lr):
+        """`len(grads)` libtorch Adam steps; returns (param, exp_avg, exp_avg_sq)."""
+        p = np.ascontiguousarray(p, np.float32).copy()
+        gr, grp = _f(np.stack(grads))
+        n = p.size
+        m, mp = _fo((n,)); v, vp = _fo((n,))
+        self._tchk(self.lib.ref_adam_steps(C.c_int64(n), p.ctypes.data_as(_f32p), grp,
+                                           C.c_int(len(grads)), C.c_double(lr), mp, vp))
+        return p, m, v
+
+    def sched_lr(self, lr_init, lr_final, max_steps, step):
+        self.lib.ref_sched_lr.restype = C.c_float
+        self.lib.ref_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
+        return float(self.lib.ref_sched_lr(lr_init, lr_final, max_steps, step))
 
 
 _restated = None

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""SURVEY.md §8 row f2 measurement: the fused loss (L1 + SSIM forward+backward) at 1920x1080 and
+the six-group Adam step at N = 1 M Gaussians / SH degree 3 (59 M parameters), HIP-event timed on
+one MI355X, with
+  * the same ops as the reference issues them, run by torch on the SAME GPU (grouped conv2d SSIM +
+    autograd; torch::optim::Adam's op sequence per group) — what OpenSplat's GPU build executes;
+  * the reference's own code on the host CPU (oracle/_ref: ssim.cpp + libtorch Adam), bounded
+    sample — the `cpu_baseline`.
+Prints one JSON object.  python scripts/bench_train_step.py [--no-cpu]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from opensplat_amd import cabi, scenes  # noqa: E402
+
+DEV = torch.device("cuda:0")
+W, H, N, K = 1920, 1080, 1_000_000, 16
+HBM_PEAK = 8000.0  # GB/s
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def torch_ssim_loss(window):
+    """ssim.cpp:7-33 + model.cpp:54-56,780-784 as torch ops (what the reference's GPU build runs)."""
+    w2 = torch.outer(window, window)[None, None].expand(3, 1, 11, 11).contiguous()
+
+    def f(rendered, gt, ssim_weight):
+        img1 = gt.permute(2, 0, 1)[None]
+        img2 = rendered.permute(2, 0, 1)[None]
+        mu1 = F.conv2d(img1, w2, padding=5, groups=3)
+        mu2 = F.conv2d(img2, w2, padding=5, groups=3)
+        mu1Sq, mu2Sq, mu1mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+        s1 = F.conv2d(img1 * img1, w2, padding=5, groups=3) - mu1Sq
+        s2 = F.conv2d(img2 * img2, w2, padding=5, groups=3) - mu2Sq
+        s12 = F.conv2d(img1 * img2, w2, padding=5, groups=3) - mu1mu2
+        C1, C2 = 0.01 ** 2, 0.03 ** 2
+        m = ((2.0 * mu1mu2 + C1) * (2.0 * s12 + C2)) / ((mu1Sq + mu2Sq + C1) * (s1 + s2 + C2))
+        return (1.0 - ssim_weight) * torch.abs(gt - rendered).mean() + ssim_weight * (1.0 - m.mean())
+    return f
+
+
+def torch_adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    """torch::optim::Adam::step's op sequence (libtorch C++ frontend, one parameter)."""
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def main():
+    out = {"workload": f"loss at {W}x{H}; Adam over N={N} Gaussians, SH degree 3 (K={K}): "
+                       f"{N * (3 * K + 11)} parameters in six groups"}
+    rendered_np, gt_np = scenes.loss_images(W, H, seed=1)
+    rendered, gt = torch.from_numpy(rendered_np).to(DEV), torch.from_numpy(gt_np).to(DEV)
+    ws = torch.empty(cabi.lib().gs_loss_workspace_bytes(W, H), device=DEV, dtype=torch.uint8)
+    buf = (torch.empty(3, device=DEV), torch.empty_like(rendered))
+    ms = timeit(lambda: cabi.main_loss(rendered, gt, 0.2, 1.0, True, out=buf, workspace=ws))
+    P = W * H
+    loss_bytes = P * (24 + 108) + P * (108 + 24 + 12)   # k_ssim_maps + k_ssim_grad, DESIGN.md §11
+    out["loss"] = {"ms": ms, "algorithmic_bytes": loss_bytes,
+                   "achieved_GBs": loss_bytes / ms / 1e6, "frac_of_hbm_peak": loss_bytes / ms / 1e6 / HBM_PEAK,
+                   "value": [float(x) for x in buf[0].cpu()]}
+    buf0 = (torch.empty(3, device=DEV), torch.empty_like(rendered))
+    ms0 = timeit(lambda: cabi.main_loss(rendered, gt, 0.0, 1.0, True, out=buf0, workspace=ws))
+    out["loss_l1_only"] = {"ms": ms0}
+    ours_only = "--ours-only" in sys.argv   # profiling runs: skip the torch-op comparisons
+    if not ours_only:
+        # the reference's op sequence on this GPU
+        window = torch.tensor(cabi.ssim_window(), device=DEV)
+        f = torch_ssim_loss(window)
+
+        def torch_loss():
+            r = rendered.detach().requires_grad_(True)
+            f(r, gt, 0.2).backward()
+            return r.grad
+        out["loss_torch_ops_same_gpu"] = {"ms": timeit(torch_loss, reps=5, warm=2)}
+        g_t = torch_loss()
+        out["loss"]["max_abs_grad_diff_vs_torch_ops"] = float((g_t - buf[1]).abs().max())
+        out["loss"]["max_abs_grad"] = float(g_t.abs().max())
+
+    # Adam: Model's six groups (model.cpp:61-66)
+    sizes = [N * 3, N * 3, N * 4, N * 3, N * (K - 1) * 3, N]
+    lrs = [0.00016, 0.005, 0.001, 0.0025, 0.000125, 0.05]
+    total = sum(sizes)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    flat = [torch.randn(total, device=DEV, generator=gen) for _ in range(2)] + \
+           [torch.zeros(total, device=DEV) for _ in range(2)]
+    groups, off = [], 0
+    for sz, lr in zip(sizes, lrs):
+        groups.append(tuple(t[off:off + sz] for t in flat) + (lr,))
+        off += sz
+    step = [0]
+
+    def ours():
+        step[0] += 1
+        cabi.adam_step(groups, step[0])
+    ms = timeit(ours)
+    adam_bytes = total * 28
+    out["adam"] = {"ms": ms, "parameters": total, "algorithmic_bytes": adam_bytes,
+                   "achieved_GBs": adam_bytes / ms / 1e6, "frac_of_hbm_peak": adam_bytes / ms / 1e6 / HBM_PEAK}
+    tstep = [0]
+
+    def theirs():
+        tstep[0] += 1
+        for p, g, m, v, lr in groups:
+            torch_adam_step(p, g, m, v, lr, tstep[0])
+    if not ours_only:
+        out["adam_torch_ops_same_gpu"] = {"ms": timeit(theirs, reps=5, warm=2)}
+
+    if "--no-cpu" not in sys.argv:
+        import oracle
+        if oracle.have_reference():
+            R = oracle.reference()
+            R.main_loss(rendered_np[:270], gt_np[:270], 0.2)           # warm-up, quarter frame
+            t0 = time.time()
+            R.main_loss(rendered_np, gt_np, 0.2)
+            out["cpu_baseline_loss"] = {"ms": R.last_ms, "wall_s": time.time() - t0, "kind": "reference",
+                                        "threads_torch": torch.get_num_threads(),
+                                        "sample": f"1 mainLoss forward+backward at {W}x{H}"}
+            n = 4_000_000
+            p0, grads = scenes.adam_problem(n, 3, 1)
+            t0 = time.time()
+            R.adam_steps(p0, grads, 0.005)
+            dt = (time.time() - t0) / 3
+            out["cpu_baseline_adam"] = {"ms_per_59M_params": dt * 1e3 * total / n, "kind": "reference",
+                                        "sample": f"3 libtorch Adam steps over {n} parameters, scaled"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -80,3 +80,21 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def torch_main_loss(window_1d, rendered, gt, ssim_weight):
+    """Model::mainLoss as the torch ops the reference issues (ssim.cpp:7-33, model.cpp:54-56,
+    780-784), differentiable: what OpenSplat's GPU build executes on the device."""
+    import torch
+    import torch.nn.functional as F
+
+    w2 = torch.outer(window_1d, window_1d)[None, None].expand(3, 1, 11, 11).contiguous()
+    img1 = gt.permute(2, 0, 1)[None]
+    img2 = rendered.permute(2, 0, 1)[None]
+    conv = lambda a: F.conv2d(a, w2, padding=5, groups=3)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1Sq, mu2Sq, mu1mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = conv(img1 * img1) - mu1Sq, conv(img2 * img2) - mu2Sq, conv(img1 * img2) - mu1mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2.0 * mu1mu2 + C1) * (2.0 * s12 + C2)) / ((mu1Sq + mu2Sq + C1) * (s1 + s2 + C2))
+    return (1.0 - ssim_weight) * torch.abs(gt - rendered).mean() + ssim_weight * (1.0 - m.mean())
