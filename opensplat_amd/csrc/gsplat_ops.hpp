@@ -101,6 +101,44 @@ public:
                                                  torch::autograd::tensor_list grad_outputs);
 };
 
+// SURVEY.md §8 row f2 — Model::mainLoss (model.cpp:780-784): (1 - w) * l1(rgb, gt) + w * (1 - ssim)
+// as ONE autograd node (fused L1 + SSIM kernels, include/gsplat_train.h).  The gradient w.r.t. rgb
+// is computed together with the value; backward only scales it by the incoming gradient.
+// `mainLoss(rgb, gt, ssimWeight)` is the drop-in for the member function (returns a 0-dim tensor).
+class MainLoss : public torch::autograd::Function<MainLoss> {
+public:
+    static torch::Tensor forward(torch::autograd::AutogradContext *ctx, torch::Tensor rgb,
+                                 torch::Tensor gt, double ssimWeight);
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext *ctx,
+                                                 torch::autograd::tensor_list grad_outputs);
+};
+torch::Tensor mainLoss(const torch::Tensor &rgb, const torch::Tensor &gt, float ssimWeight);
+
+// Model's six torch::optim::Adam instances (model.cpp:61-66) and Model::optimizersStep /
+// optimizersZeroGrad (model.cpp:227-243) as one object: every group steps in ONE kernel launch.
+// Parameters keep their identity (updated in place, like torch::optim::Adam does); gradients are
+// read from param.grad().  Betas (0.9, 0.999), eps 1e-8 = libtorch's AdamOptions defaults.
+class FusedAdam {
+public:
+    FusedAdam(std::vector<torch::Tensor> params, std::vector<double> lrs);
+    void step();                      // all groups; groups without a gradient are skipped
+    void zeroGrad();                  // optimizersZeroGrad
+    void setLr(size_t group, double lr) { lrs_.at(group) = lr; }   // OptimScheduler::step
+    double getLr(size_t group) const { return lrs_.at(group); }
+    int64_t stepCount() const { return step_; }
+    // optimiser-state access for densification surgery (model.cpp:253-309)
+    torch::Tensor &expAvg(size_t group) { return expAvg_.at(group); }
+    torch::Tensor &expAvgSq(size_t group) { return expAvgSq_.at(group); }
+    void replaceParam(size_t group, torch::Tensor param, torch::Tensor expAvg, torch::Tensor expAvgSq);
+
+private:
+    std::vector<torch::Tensor> params_, expAvg_, expAvgSq_;
+    std::vector<double> lrs_;
+    int64_t step_ = 0;
+};
+// OptimScheduler::getLearningRate (optim_scheduler.cpp:4-7)
+float schedulerLearningRate(float lrInit, float lrFinal, int maxSteps, int step);
+
 // Process-wide switch for the compositing kernels' exponential: false (default) = glibc-bit-exact
 // expf (contributor sets identical to gsplat-cpu); true = hardware v_exp_f32 (GS_FLAG_FAST_EXP).
 void gsplatSetFastExp(bool enabled);

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "../../include/gsplat_hip.h"
+#include "../../include/gsplat_train.h"
 
 using torch::Tensor;
 using torch::autograd::AutogradContext;
@@ -518,6 +519,87 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
             none, none, none, none, none, none};
 }
 
+// ---- row f2: loss + optimiser (include/gsplat_train.h) -------------------------------------------
+Tensor MainLoss::forward(AutogradContext *ctx, Tensor rgb, Tensor gt, double ssimWeight) {
+    GS_CHECK_DEV(rgb); GS_CHECK_DEV(gt); GS_CHECK_F32(rgb); GS_CHECK_F32(gt);
+    TORCH_CHECK(rgb.dim() == 3 && rgb.size(2) == 3, "rgb must be [H, W, 3]");
+    TORCH_CHECK(gt.sizes() == rgb.sizes(), "gt must have rgb's shape");
+    c10::DeviceGuard guard(rgb.device());
+    Tensor r = rgb.contiguous(), g = gt.contiguous();
+    const int H = (int)r.size(0), W = (int)r.size(1);
+    Tensor loss = torch::empty({3}, r.options());
+    Tensor vRgb = torch::empty_like(r);
+    Tensor ws = torch::empty({(int64_t)gs_loss_workspace_bytes(W, H)}, r.options().dtype(torch::kUInt8));
+    check_status(gs_main_loss(W, H, fptr(r), fptr(g), (float)ssimWeight, 1.0f, fptr_mut(loss),
+                              fptr_mut(vRgb), ws.data_ptr(), (size_t)ws.numel(), current_stream()),
+                 "gs_main_loss");
+    ctx->save_for_backward({vRgb});
+    return loss[0];
+}
+
+tensor_list MainLoss::backward(AutogradContext *ctx, tensor_list grad_outputs) {
+    Tensor vRgb = ctx->get_saved_variables()[0];
+    c10::DeviceGuard guard(vRgb.device());
+    return {vRgb * grad_outputs[0], Tensor(), Tensor()};
+}
+
+Tensor mainLoss(const Tensor &rgb, const Tensor &gt, float ssimWeight) {
+    return MainLoss::apply(rgb, gt, (double)ssimWeight);
+}
+
+FusedAdam::FusedAdam(std::vector<Tensor> params, std::vector<double> lrs)
+    : params_(std::move(params)), lrs_(std::move(lrs)) {
+    TORCH_CHECK(params_.size() == lrs_.size(), "one learning rate per parameter group");
+    TORCH_CHECK(params_.size() <= GS_ADAM_MAX_GROUPS, "at most ", GS_ADAM_MAX_GROUPS, " groups");
+    for (auto &p : params_) {
+        GS_CHECK_DEV(p); GS_CHECK_F32(p);
+        TORCH_CHECK(p.is_contiguous(), "parameters must be contiguous");
+        expAvg_.push_back(torch::zeros_like(p));     // AdamParamState::exp_avg / exp_avg_sq
+        expAvgSq_.push_back(torch::zeros_like(p));
+    }
+}
+
+void FusedAdam::step() {
+    if (params_.empty()) return;
+    c10::DeviceGuard guard(params_[0].device());
+    GsAdamGroup groups[GS_ADAM_MAX_GROUPS];
+    std::vector<Tensor> keep;  // contiguous gradient copies, alive until the launch is enqueued
+    int n = 0;
+    for (size_t i = 0; i < params_.size(); i++) {
+        const Tensor &g = params_[i].grad();
+        if (!g.defined()) continue;  // torch::optim::Adam skips parameters without a gradient
+        Tensor gc = g.contiguous();
+        keep.push_back(gc);
+        groups[n].param = params_[i].data_ptr<float>();
+        groups[n].grad = gc.data_ptr<float>();
+        groups[n].exp_avg = expAvg_[i].data_ptr<float>();
+        groups[n].exp_avg_sq = expAvgSq_[i].data_ptr<float>();
+        groups[n].n = params_[i].numel();
+        groups[n].lr = lrs_[i];
+        n++;
+    }
+    step_++;
+    check_status(gs_adam_step(n, groups, step_, 0.9, 0.999, 1e-8, current_stream()), "gs_adam_step");
+}
+
+void FusedAdam::zeroGrad() {
+    for (auto &p : params_)
+        if (p.grad().defined()) p.mutable_grad().reset();  // set_to_none, Optimizer::zero_grad's default
+}
+
+void FusedAdam::replaceParam(size_t group, Tensor param, Tensor expAvg, Tensor expAvgSq) {
+    GS_CHECK_DEV(param); GS_CHECK_F32(param);
+    TORCH_CHECK(expAvg.sizes() == param.sizes() && expAvgSq.sizes() == param.sizes(),
+                "optimiser state must have the parameter's shape");
+    params_.at(group) = std::move(param);
+    expAvg_.at(group) = expAvg.contiguous();
+    expAvgSq_.at(group) = expAvgSq.contiguous();
+}
+
+float schedulerLearningRate(float lrInit, float lrFinal, int maxSteps, int step) {
+    return gs_sched_lr(lrInit, lrFinal, maxSteps, step);
+}
+
 // ---- Python-visible registration (torch.ops.opensplat_amd.*) -------------------------------------
 namespace {
 
@@ -558,6 +640,34 @@ std::vector<Tensor> op_splat_render(const Tensor &means, const Tensor &logScales
 
 void op_set_fast_exp(bool enabled) { gsplatSetFastExp(enabled); }
 
+Tensor op_main_loss(const Tensor &rgb, const Tensor &gt, double ssimWeight) {
+    return MainLoss::apply(rgb, gt, ssimWeight);
+}
+
+// One optimizersStep over parallel lists (params updated in place; state tensors owned by the
+// caller so that Python can hold them): the FusedAdam class is the C++ face of the same call.
+void op_adam_step(std::vector<Tensor> params, std::vector<Tensor> grads, std::vector<Tensor> expAvg,
+                  std::vector<Tensor> expAvgSq, std::vector<double> lrs, int64_t step) {
+    const size_t n = params.size();
+    TORCH_CHECK(grads.size() == n && expAvg.size() == n && expAvgSq.size() == n && lrs.size() == n,
+                "parallel lists of equal length expected");
+    TORCH_CHECK(n <= GS_ADAM_MAX_GROUPS, "at most ", GS_ADAM_MAX_GROUPS, " groups");
+    if (n == 0) return;
+    c10::DeviceGuard guard(params[0].device());
+    GsAdamGroup groups[GS_ADAM_MAX_GROUPS];
+    for (size_t i = 0; i < n; i++) {
+        for (const Tensor *t : {&params[i], &grads[i], &expAvg[i], &expAvgSq[i]}) {
+            TORCH_CHECK(t->is_cuda() && t->scalar_type() == torch::kFloat32 && t->is_contiguous(),
+                        "contiguous float32 GPU tensors expected");
+            TORCH_CHECK(t->numel() == params[i].numel(), "group ", i, ": size mismatch");
+        }
+        groups[i] = GsAdamGroup{params[i].data_ptr<float>(), grads[i].data_ptr<float>(),
+                                expAvg[i].data_ptr<float>(), expAvgSq[i].data_ptr<float>(),
+                                params[i].numel(), lrs[i]};
+    }
+    check_status(gs_adam_step((int)n, groups, step, 0.9, 0.999, 1e-8, current_stream()), "gs_adam_step");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(opensplat_amd, m) {
@@ -577,4 +687,8 @@ TORCH_LIBRARY(opensplat_amd, m) {
           "Tensor background, Tensor? xys_grad_out=None) -> Tensor[]",
           &op_splat_render);
     m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
+    m.def("main_loss(Tensor rgb, Tensor gt, float ssim_weight) -> Tensor", &op_main_loss);
+    m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, "
+          "float[] lrs, int step) -> ()",
+          &op_adam_step);
 }

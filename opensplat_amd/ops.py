@@ -75,3 +75,16 @@ def splat_render(means, log_scales, quats, opacity_logits, features_dc, features
     return _ops.splat_render(means, log_scales, quats, opacity_logits, features_dc, features_rest,
                              viewmat, projmat, cam_pos, fx, fy, cx, cy, img_height, img_width,
                              degrees_to_use, background, xys_grad_out)
+
+
+def main_loss(rgb, gt, ssim_weight=0.2):
+    """Model::mainLoss (model.cpp:780-784) as one autograd node: (1 - w) * L1 + w * (1 - SSIM) with the
+    reference's 11x11 window; returns a 0-dim tensor, differentiable w.r.t. rgb (row f2)."""
+    return _ops.main_loss(rgb, gt, float(ssim_weight))
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lrs, step):
+    """Model::optimizersStep (model.cpp:236-243) for up to eight parameter groups in ONE launch;
+    params / exp_avg / exp_avg_sq are updated in place; `step` is 1-based."""
+    _ops.adam_step(list(params), list(grads), list(exp_avg), list(exp_avg_sq),
+                   [float(x) for x in lrs], int(step))

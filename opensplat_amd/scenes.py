@@ -220,3 +220,13 @@ def adam_problem(n: int, steps: int, seed: int = 0):
         g[rng.rand(n) < 0.1] = 0.0
         grads.append(g)
     return p, grads
+
+
+def raw_parameters(s: Scene):
+    """The optimiser's view of scene `s` (model.hpp): (means, log-scales, raw quats, opacity logits
+    [N,1], featuresDc [N,3], featuresRest [N,K-1,3]) such that Model::forward's glue (exp,
+    normalise, sigmoid, cat; model.cpp:114-215) reproduces the scene's tensors."""
+    o = np.clip(s.opacities.reshape(-1, 1), 1e-6, 1 - 1e-6)
+    logits = np.log(o / (1 - o)).astype(np.float32)
+    return (s.means, np.log(s.scales).astype(np.float32), s.quats.astype(np.float32), logits,
+            np.ascontiguousarray(s.sh_coeffs[:, 0, :]), np.ascontiguousarray(s.sh_coeffs[:, 1:, :]))

@@ -125,6 +125,27 @@ def main():
     if not ours_only:
         out["adam_torch_ops_same_gpu"] = {"ms": timeit(theirs, reps=5, warm=2)}
 
+    # ---- the whole iteration (opensplat.cpp:151-170) at C2: render + loss + backward + Adam ------
+    from opensplat_amd import train
+    s_ = scenes.config_c2()
+    raw = scenes.raw_parameters(s_)
+    T = train.Trainer(*raw, DEV, max_steps=30000, ssim_weight=0.2)
+    cam = dict(viewmat=s_.viewmat, projmat=s_.projmat, fx=s_.fx, fy=s_.fy, cx=s_.cx, cy=s_.cy,
+               W=s_.W, H=s_.H)
+    it_ms = timeit(lambda: T.train_step(cam, gt, s_.background, s_.degrees_to_use), reps=30, warm=5)
+    stages = {}
+    T.render(cam, s_.background, s_.degrees_to_use)
+    stages["render"] = timeit(lambda: T.render(cam, s_.background, s_.degrees_to_use), reps=10)
+    lo = lambda: cabi.main_loss(T.fwd["img_clamped"], gt, 0.2, 1.0, True, out=T.loss_out,
+                                workspace=T.loss_ws)
+    stages["loss"] = timeit(lo, reps=10)
+    stages["backward"] = timeit(lambda: T.backward(T.loss_out[1]), reps=10)
+    stages["adam"] = timeit(T.optimizer_step, reps=10)
+    out["iteration"] = {"workload": "C2 scene (1 M Gaussians, 1920x1080, SH degree 3), one camera: "
+                                    "Model::forward + mainLoss + backward + optimizersStep",
+                        "ms": it_ms, "iterations_per_s": 1e3 / it_ms, "stage_ms": stages,
+                        "loss_after": [float(x) for x in T.loss_out[0].cpu()]}
+
     if "--no-cpu" not in sys.argv:
         import oracle
         if oracle.have_reference():

@@ -281,3 +281,53 @@ def test_trainer_loss_decreases_on_a_fixed_view():
     losses = [float(T.train_step(cam, gt, s.background, s.degrees_to_use)[0]) for _ in range(30)]
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     assert all(np.isfinite(losses))
+
+
+# ---- the libtorch operator surface (torch_ops.cpp: MainLoss, adam_step) -------------------------
+
+def test_main_loss_operator_autograd():
+    from opensplat_amd import ops
+    from tests.util import torch_main_loss
+
+    rendered_np, gt_np = scenes.loss_images(150, 90, seed=13)
+    gt = torch.from_numpy(gt_np).to(DEV)
+    window = torch.tensor(cabi.ssim_window(), device=DEV)
+    a = torch.from_numpy(rendered_np).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rendered_np).to(DEV).requires_grad_(True)
+    # loss composed with further torch ops on both sides: backward must honour the incoming grad
+    la = 3.0 * ops.main_loss(torch.clamp_max(a * 1.1, 1.0), gt, 0.2)
+    lb = 3.0 * torch_main_loss(window, torch.clamp_max(b * 1.1, 1.0), gt, 0.2)
+    la.backward()
+    lb.backward()
+    assert la.dim() == 0 and abs(float(la) - float(lb)) < 3e-5
+    ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    assert np.abs(ga - gb).max() < GRAD_RTOL * np.abs(gb).max()
+    with pytest.raises(RuntimeError):
+        ops.main_loss(a.detach().cpu(), gt.cpu(), 0.2)   # no CPU path
+
+
+def test_adam_step_operator_against_torch_optim():
+    from opensplat_amd import ops
+
+    rng = np.random.RandomState(3)
+    shapes, lrs = [(1000, 3), (1000, 4), (1000, 15, 3), (1000, 1)], [0.00016, 0.001, 0.000125, 0.05]
+    P0 = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    mine = [torch.from_numpy(p.copy()).to(DEV) for p in P0]
+    m = [torch.zeros_like(p) for p in mine]
+    v = [torch.zeros_like(p) for p in mine]
+    theirs = [torch.from_numpy(p.copy()).to(DEV).requires_grad_(True) for p in P0]
+    opts = [torch.optim.Adam([p], lr=lr, eps=1e-8, foreach=False, fused=False)
+            for p, lr in zip(theirs, lrs)]
+    for step in (1, 2, 3, 4):
+        grads = [torch.from_numpy((rng.standard_normal(sh) * 10.0 ** rng.uniform(-6, 1)).astype(np.float32)).to(DEV)
+                 for sh in shapes]
+        ops.adam_step(mine, grads, m, v, lrs, step)
+        for p, g, o in zip(theirs, grads, opts):
+            p.grad = g.clone()
+            o.step()
+    torch.cuda.synchronize()
+    for a, b, lr in zip(mine, theirs, lrs):
+        a, b = a.cpu().numpy(), b.detach().cpu().numpy()
+        # torch's GPU kernels round a few operations differently (no fused multiply-adds where
+        # ATen's CPU kernels have them): a couple of ulps of max(|p|, update)
+        assert np.all(np.abs(a - b) <= 4 * np.spacing(np.maximum(np.abs(b), np.float32(4 * lr))))
