@@ -32,6 +32,9 @@ SYMBOLS = [
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
                  "gs_sched_lr"]
+# every symbol include/gsplat_densify.h declares
+DENSIFY_SYMBOLS = ["gs_densify_stats", "gs_densify_workspace_bytes", "gs_densify_plan",
+                   "gs_densify_apply", "gs_reset_opacity"]
 
 
 class GsCamera(C.Structure):
@@ -61,6 +64,8 @@ def lib() -> C.CDLL:
         l.gs_rasterize_backward_workspace_bytes.argtypes = [C.c_int]
         l.gs_loss_workspace_bytes.restype = C.c_size_t
         l.gs_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        l.gs_densify_workspace_bytes.restype = C.c_size_t
+        l.gs_densify_workspace_bytes.argtypes = [C.c_int]
         l.gs_sched_lr.restype = C.c_float
         l.gs_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
         _lib = l
@@ -414,3 +419,94 @@ def adam_step(groups, step, beta1=0.9, beta2=0.999, eps=1e-8):
 
 def sched_lr(lr_init, lr_final, max_steps, step):
     return float(lib().gs_sched_lr(lr_init, lr_final, max_steps, step))
+
+
+# ---------------------------------------------------------------------------------------------
+# densification / culling (include/gsplat_densify.h)
+
+class GsDensifyConfig(C.Structure):
+    _fields_ = [("half_max_side", C.c_float), ("densify_grad_thresh", C.c_float),
+                ("densify_size_thresh", C.c_float), ("split_screen_size", C.c_float),
+                ("check_screen_size", C.c_int32), ("cull_alpha_thresh", C.c_float),
+                ("cull_huge", C.c_int32), ("cull_scale_thresh", C.c_float),
+                ("cull_screen_size", C.c_float)]
+
+
+class GsGaussianSet(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("means", "log_scales", "quats", "opacity_logits",
+                                          "features_dc", "features_rest")]
+
+
+COUNT_NAMES = ["n_splits", "n_dups", "kept_orig", "kept_split", "kept_dup", "new_n", "added", "culled"]
+
+
+def densify_stats(xys_grad, radii, max_side, first, xys_grad_norm, vis_counts, max_2d_size):
+    """Model::afterTrain's per-iteration statistics (model.cpp:317-337), in place."""
+    N = radii.shape[0]
+    _check(lib().gs_densify_stats(C.c_int(N), _p(xys_grad), _p(radii), C.c_float(max_side),
+                                  C.c_int(int(first)), _p(xys_grad_norm), _p(vis_counts),
+                                  _p(max_2d_size), _stream()), "gs_densify_stats")
+
+
+def densify_config(width, height, grad_thresh=0.0002, size_thresh=0.01, check_screen=True,
+                   split_screen=0.05, cull_huge=True, cull_alpha=0.1, cull_scale=0.5,
+                   cull_screen=0.15) -> GsDensifyConfig:
+    return GsDensifyConfig(0.5 * float(max(width, height)), grad_thresh, size_thresh, split_screen,
+                           int(bool(check_screen)), cull_alpha, int(bool(cull_huge)), cull_scale,
+                           cull_screen)
+
+
+def _set(tensors):
+    s = GsGaussianSet()
+    for name, t in zip([f[0] for f in GsGaussianSet._fields_], tensors):
+        if t is not None and t.numel() > 0:
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+            setattr(s, name, t.data_ptr())
+    return s
+
+
+def densify(cfg: GsDensifyConfig, params, exp_avg, exp_avg_sq, xys_grad_norm, vis_counts,
+            max_2d_size, samples_fn=None):
+    """One refinement (model.cpp:345-458): params / exp_avg / exp_avg_sq are lists of the six
+    tensors [means, log_scales, quats, opacity_logits, features_dc, features_rest] (the moment
+    lists may be None).  samples_fn(n_splits) -> [2 n_splits, 3] normal samples (default
+    torch.randn on the device, like the reference).  Returns (new_params, new_exp_avg,
+    new_exp_avg_sq, counts dict); one host sync, to read the counts."""
+    means = params[0]
+    N, dev = means.shape[0], means.device
+    K = 1 + (params[5].shape[1] if params[5] is not None and params[5].numel() > 0 else 0)
+    need = lib().gs_densify_workspace_bytes(N)
+    ws = torch.empty(need, device=dev, dtype=torch.uint8)
+    counts = torch.zeros(8, dtype=torch.int32).pin_memory()
+    _check(lib().gs_densify_plan(C.c_int(N), C.byref(cfg), _p(xys_grad_norm), _p(vis_counts),
+                                 _p(max_2d_size), _p(params[1]), _p(params[3]),
+                                 C.c_void_p(counts.data_ptr()), _p(ws), C.c_size_t(need), _stream()),
+           "gs_densify_plan")
+    torch.cuda.current_stream().synchronize()
+    c = dict(zip(COUNT_NAMES, [int(x) for x in counts]))
+    n_splits, new_n = c["n_splits"], c["new_n"]
+    if samples_fn is None:
+        samples_fn = lambda n: torch.randn((2 * n, 3), device=dev)   # model.cpp:360
+    samples = samples_fn(n_splits) if n_splits > 0 else None
+    if samples is not None:
+        samples = samples.to(dev).contiguous()
+        assert samples.shape == (2 * n_splits, 3)
+
+    def alloc(like):
+        return [torch.empty((new_n,) + tuple(t.shape[1:]), device=dev, dtype=torch.float32)
+                if t is not None else None for t in like]
+    new_p = alloc(params)
+    new_m = alloc(params) if exp_avg is not None else None
+    new_v = alloc(params) if exp_avg_sq is not None else None
+    src = (GsGaussianSet * 3)(_set(params), _set(exp_avg or [None] * 6), _set(exp_avg_sq or [None] * 6))
+    dst = (GsGaussianSet * 3)(_set(new_p), _set(new_m or [None] * 6), _set(new_v or [None] * 6))
+    _check(lib().gs_densify_apply(C.c_int(N), C.c_int(K), C.c_int(new_n), _p(samples), src, dst,
+                                  _p(ws), C.c_size_t(need), _stream()), "gs_densify_apply")
+    return new_p, new_m, new_v, c
+
+
+def reset_opacity(opacity_logits, reset_value=0.2, exp_avg=None, exp_avg_sq=None):
+    """The alpha reset, model.cpp:464-479 (in place)."""
+    _check(lib().gs_reset_opacity(C.c_int(opacity_logits.numel()), C.c_float(reset_value),
+                                  _p(opacity_logits), _p(exp_avg), _p(exp_avg_sq), _stream()),
+           "gs_reset_opacity")

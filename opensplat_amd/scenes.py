@@ -230,3 +230,44 @@ def raw_parameters(s: Scene):
     logits = np.log(o / (1 - o)).astype(np.float32)
     return (s.means, np.log(s.scales).astype(np.float32), s.quats.astype(np.float32), logits,
             np.ascontiguousarray(s.sh_coeffs[:, 0, :]), np.ascontiguousarray(s.sh_coeffs[:, 1:, :]))
+
+
+def densify_problem(N: int, K: int = 4, seed: int = 0, width: int = 640, height: int = 480):
+    """Inputs of one refinement step: the six raw parameter tensors, Adam
+    moments, the accumulated statistics, with every branch of Model::afterTrain populated: high /
+    low gradients, small / large / huge Gaussians, large screen footprints (so that some Gaussians
+    are BOTH split and duplicated, as the reference allows), faint opacities.  Quantities compared
+    with thresholds are kept >= 1e-3 (relative) away from them, so that exp / sigmoid rounding
+    cannot flip a decision."""
+    rs = np.random.RandomState(seed)
+    f = np.float32
+
+    def away(x, thr):  # push values out of the +-0.1 % band around a threshold
+        x = x.copy()
+        near = np.abs(x / thr - 1.0) < 1e-3
+        x[near] = thr * 1.01
+        return x
+
+    size = away(10.0 ** rs.uniform(-3.2, 0.2, N), 0.01)              # densifySizeThresh, cullScaleThresh
+    size = away(size, 0.5)
+    size = away(size, 0.5 * 1.6)                                     # split samples vs cullScaleThresh
+    aniso = rs.uniform(0.2, 1.0, (N, 3))
+    aniso[np.arange(N), rs.randint(0, 3, N)] = 1.0
+    log_scales = np.log(size[:, None] * aniso).astype(f)
+    means = rs.uniform(-1, 1, (N, 3)).astype(f)
+    quats = (rs.standard_normal((N, 4)) * rs.uniform(0.3, 3.0, (N, 1))).astype(f)
+    alpha = away(rs.uniform(0.005, 0.995, N), 0.1)
+    logits = np.log(alpha / (1 - alpha)).astype(f).reshape(N, 1)
+    dc = rs.uniform(-1.5, 1.5, (N, 3)).astype(f)
+    rest = (0.1 * rs.standard_normal((N, K - 1, 3))).astype(f)
+    params = [means, log_scales, quats, logits, dc, rest]
+    exp_avg = [(1e-3 * rs.standard_normal(p.shape)).astype(f) for p in params]
+    exp_avg_sq = [(1e-6 * rs.uniform(0, 1, p.shape)).astype(f) for p in params]
+    vis = rs.randint(1, 100, N).astype(f)
+    side = float(max(width, height))
+    avg = away(10.0 ** rs.uniform(-5.5, -2.0, N), 0.0002)            # densifyGradThresh
+    gnorm = (avg * vis / (0.5 * side)).astype(f)
+    m2d = away(rs.uniform(0.0, 0.3, N) * (rs.rand(N) < 0.5), 0.05)   # splitScreenSize, cullScreenSize
+    m2d = away(m2d, 0.15).astype(f)
+    return dict(params=params, exp_avg=exp_avg, exp_avg_sq=exp_avg_sq, xys_grad_norm=gnorm,
+                vis_counts=vis, max_2d_size=m2d, width=width, height=height, K=K, N=N)

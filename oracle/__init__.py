@@ -191,6 +191,26 @@ class Restated(_Base):
         self.lib.orc_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
         return float(self.lib.orc_sched_lr(lr_init, lr_final, max_steps, step))
 
+    # ---- SURVEY.md §8 row f4 (oracle/densify_oracle.c) ----------------------------------------
+    def densify_stats(self, xys_grad, radii, height, width, first, gnorm, vis, m2d):
+        """In place on float32 arrays gnorm, vis, m2d."""
+        N = len(radii)
+        g, gp = _f(xys_grad)
+        r = np.ascontiguousarray(radii, np.int32)
+        self.lib.orc_densify_stats(C.c_int(N), gp, r.ctypes.data_as(_i32p), C.c_int(height),
+                                   C.c_int(width), C.c_int(int(first)), gnorm.ctypes.data_as(_f32p),
+                                   vis.ctypes.data_as(_f32p), m2d.ctypes.data_as(_f32p))
+
+    def densify_refine(self, prob, grad_thresh, size_thresh, check_screen, split_screen, cull_huge,
+                       samples_fn):
+        return _densify_refine(self.lib.orc_densify_refine, prob, grad_thresh, size_thresh,
+                               check_screen, split_screen, cull_huge, samples_fn)
+
+    def reset_opacity(self, logits, reset_value=0.2):
+        out = np.ascontiguousarray(logits, np.float32).copy()
+        self.lib.orc_reset_opacity(C.c_int(out.size), C.c_float(reset_value), out.ctypes.data_as(_f32p))
+        return out
+
 class Reference(_Base):
     name = "reference"
 
@@ -349,6 +369,60 @@ class Reference(_Base):
         self.lib.ref_sched_lr.restype = C.c_float
         self.lib.ref_sched_lr.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int]
         return float(self.lib.ref_sched_lr(lr_init, lr_final, max_steps, step))
+
+
+    # ---- SURVEY.md §8 row f4 (oracle/ref_train_shim.cpp: afterTrain restated under libtorch) ----
+    def densify_stats(self, xys_grad, radii, height, width, first, gnorm, vis, m2d):
+        N = len(radii)
+        g, gp = _f(xys_grad)
+        r = np.ascontiguousarray(radii, np.int32)
+        self._tchk(self.lib.ref_densify_stats(C.c_int(N), gp, r.ctypes.data_as(_i32p), C.c_int(height),
+                                              C.c_int(width), C.c_int(int(first)),
+                                              gnorm.ctypes.data_as(_f32p), vis.ctypes.data_as(_f32p),
+                                              m2d.ctypes.data_as(_f32p)))
+
+    def densify_refine(self, prob, grad_thresh, size_thresh, check_screen, split_screen, cull_huge,
+                       samples_fn):
+        def call(*a):
+            self._tchk(self.lib.ref_densify_refine(*a))
+            return 0
+        return _densify_refine(call, prob, grad_thresh, size_thresh, check_screen, split_screen,
+                               cull_huge, samples_fn)
+
+
+def _densify_refine(fn, prob, grad_thresh, size_thresh, check_screen, split_screen, cull_huge, samples_fn):
+    """Shared driver of orc_densify_refine / ref_densify_refine (same C signature).  samples_fn(n)
+    -> float32 [2 n, 3] normal samples.  Returns dict(params, exp_avg, exp_avg_sq, counts)."""
+    N, K = prob["N"], prob["K"]
+    PP = C.POINTER(_f32p)
+
+    def ptrs(arrs):
+        keep = [np.ascontiguousarray(a, np.float32) for a in arrs]
+        arr = (_f32p * 6)(*[a.ctypes.data_as(_f32p) for a in keep])
+        return keep, arr
+    kp, pp = ptrs(prob["params"]); ka, pa = ptrs(prob["exp_avg"]); ks, ps = ptrs(prob["exp_avg_sq"])
+    g, gp = _f(prob["xys_grad_norm"]); v, vp = _f(prob["vis_counts"]); m, mp = _f(prob["max_2d_size"])
+    lens = [3, 3, 4, 1, 3, (K - 1) * 3]
+    outs = [[np.zeros((4 * N, l), np.float32) for l in lens] for _ in range(3)]
+    optr = [(_f32p * 6)(*[a.ctypes.data_as(_f32p) for a in o]) for o in outs]
+    counts = (C.c_int32 * 4)()
+    args = lambda smp: (C.c_int(N), C.c_int(K), pp, pa, ps, gp, vp, mp, C.c_int(prob["width"]),
+                        C.c_int(prob["height"]), C.c_float(grad_thresh), C.c_float(size_thresh),
+                        C.c_int(int(check_screen)), C.c_float(split_screen), C.c_int(int(cull_huge)),
+                        smp, optr[0], optr[1], optr[2], counts)
+    rc = fn(*args(None))
+    assert rc == 0
+    n_splits = counts[0]
+    samples = np.ascontiguousarray(samples_fn(n_splits), np.float32)
+    assert samples.shape == (2 * n_splits, 3)
+    if n_splits > 0:
+        rc = fn(*args(samples.ctypes.data_as(_f32p)))
+        assert rc == 0
+    new_n = counts[1]
+    shapes = [(new_n, 3), (new_n, 3), (new_n, 4), (new_n, 1), (new_n, 3), (new_n, K - 1, 3)]
+    cut = lambda o: [a[:new_n].reshape(sh).copy() for a, sh in zip(o, shapes)]
+    return dict(params=cut(outs[0]), exp_avg=cut(outs[1]), exp_avg_sq=cut(outs[2]),
+                n_splits=n_splits, new_n=new_n, n_dups=counts[2], culled=counts[3], samples=samples)
 
 
 _restated = None

@@ -113,3 +113,189 @@ extern "C" float ref_sched_lr(float lr_init, float lr_final, int max_steps, int 
     OptimScheduler sched(&opt, lr_final, max_steps);
     return sched.getLearningRate(step);
 }
+
+// ---- Model::afterTrain (model.cpp:311-494) --------------------------------
+// model.cpp itself cannot be compiled here (OpenCV, nanoflann, json, ...), so the statements of
+// afterTrain that touch tensors are RESTATED below, in the reference's order and with the
+// reference's torch calls, as free functions over explicit tensors; quatToRotMat is the reference's
+// own (tensor_math.cpp, compiled in place).  The optimiser-state surgery follows addToOptimizer /
+// removeFromOptimizer (model.cpp:253-309).
+#include "tensor_math.hpp"
+
+using namespace torch::indexing;
+
+namespace {
+torch::Tensor tf(const float *p, std::initializer_list<int64_t> shape) {
+    return torch::from_blob(const_cast<float *>(p), shape, torch::kFloat32).clone();
+}
+void out_f(const torch::Tensor &t, float *dst) {
+    if (!dst) return;
+    torch::Tensor c = t.detach().to(torch::kFloat32).contiguous();
+    std::memcpy(dst, c.data_ptr<float>(), sizeof(float) * c.numel());
+}
+}  // namespace
+
+// model.cpp:317-337.  `first`: xysGradNorm.numel() == 0.  Accumulators [N] in/out.
+extern "C" int ref_densify_stats(int N, const float *xys_grad, const int32_t *radii_in, int lastHeight,
+                                 int lastWidth, int first, float *xysGradNorm_io, float *visCounts_io,
+                                 float *max2DSize_io) {
+    try {
+        torch::Tensor xysGrad = tf(xys_grad, {N, 2});
+        torch::Tensor radii = torch::from_blob(const_cast<int32_t *>(radii_in), {N}, torch::kInt32).clone();
+        torch::Tensor xysGradNorm = first ? torch::Tensor() : tf(xysGradNorm_io, {N});
+        torch::Tensor visCounts = first ? torch::Tensor() : tf(visCounts_io, {N});
+        torch::Tensor max2DSize = first ? torch::Tensor() : tf(max2DSize_io, {N});
+
+        torch::Tensor visibleMask = (radii > 0).flatten();
+        torch::Tensor grads = torch::linalg_vector_norm(xysGrad.detach(), 2, {-1}, false, torch::kFloat32);
+        if (!xysGradNorm.numel()) {
+            xysGradNorm = grads;
+            visCounts = torch::ones_like(xysGradNorm);
+        } else {
+            visCounts.index_put_({visibleMask}, visCounts.index({visibleMask}) + 1);
+            xysGradNorm.index_put_({visibleMask}, grads.index({visibleMask}) + xysGradNorm.index({visibleMask}));
+        }
+        if (!max2DSize.numel()) {
+            max2DSize = torch::zeros_like(radii, torch::kFloat32);
+        }
+        torch::Tensor newRadii = radii.detach().index({visibleMask});
+        max2DSize.index_put_({visibleMask}, torch::maximum(
+            max2DSize.index({visibleMask}), newRadii / static_cast<float>((std::max)(lastHeight, lastWidth))));
+        out_f(xysGradNorm, xysGradNorm_io);
+        out_f(visCounts, visCounts_io);
+        out_f(max2DSize, max2DSize_io);
+        return 0;
+    } catch (const std::exception &e) {
+        g_train_err = e.what();
+        return -1;
+    }
+}
+
+// model.cpp:345-458 (the doDensification branch: split, duplicate, cull) on parameter tensors and
+// the two Adam moment tensors of each.  Two-call protocol so that the caller can supply the normal
+// samples (torch::randn in the reference) that the product path is given too:
+//   call 1: samples == NULL -> returns n_splits in counts[0]
+//   call 2: samples [2 * n_splits, 3] -> fills the outputs (capacity 4N rows each), new N in counts[1]
+// params / moments order: means, scales, quats, opacities, featuresDc, featuresRest.
+extern "C" int ref_densify_refine(int N, int K, const float *const *params, const float *const *exp_avg_in,
+                                  const float *const *exp_avg_sq_in, const float *xysGradNorm_in,
+                                  const float *visCounts_in, const float *max2DSize_in, int lastWidth,
+                                  int lastHeight, float densifyGradThresh, float densifySizeThresh,
+                                  int checkScreenSize /* step < stopScreenSizeAt */, float splitScreenSize,
+                                  int cullHuge /* step > refineEvery * resetAlphaEvery */,
+                                  const float *samples, float *const *out_params, float *const *out_exp_avg,
+                                  float *const *out_exp_avg_sq, int32_t *counts) {
+    try {
+        torch::Tensor means = tf(params[0], {N, 3}), scales = tf(params[1], {N, 3}),
+                      quats = tf(params[2], {N, 4}), opacities = tf(params[3], {N, 1}),
+                      featuresDc = tf(params[4], {N, 3}),
+                      featuresRest = tf(params[5], {N, K - 1, 3});
+        std::vector<torch::Tensor> ea, es;
+        const std::vector<std::vector<int64_t>> shapes = {{N, 3}, {N, 3}, {N, 4}, {N, 1}, {N, 3}, {N, K - 1, 3}};
+        for (int i = 0; i < 6; i++) {
+            ea.push_back(torch::from_blob(const_cast<float *>(exp_avg_in[i]), shapes[i], torch::kFloat32).clone());
+            es.push_back(torch::from_blob(const_cast<float *>(exp_avg_sq_in[i]), shapes[i], torch::kFloat32).clone());
+        }
+        torch::Tensor xysGradNorm = tf(xysGradNorm_in, {N}), visCounts = tf(visCounts_in, {N}),
+                      max2DSize = tf(max2DSize_in, {N});
+        const float cullAlphaThresh = 0.1f;
+
+        torch::Tensor avgGradNorm = (xysGradNorm / visCounts) * 0.5f * static_cast<float>((std::max)(lastWidth, lastHeight));
+        torch::Tensor highGrads = (avgGradNorm > densifyGradThresh).squeeze();
+        torch::Tensor splits = (std::get<0>(scales.exp().max(-1)) > densifySizeThresh).squeeze();
+        if (checkScreenSize) {
+            splits |= (max2DSize > splitScreenSize).squeeze();
+        }
+        splits &= highGrads;
+        const int nSplitSamples = 2;
+        int nSplits = splits.sum().item<int>();
+        counts[0] = nSplits;
+        if (!samples && nSplits > 0) return 0;  // call 1
+
+        torch::Tensor centeredSamples = samples ? tf(samples, {nSplitSamples * nSplits, 3})
+                                                : torch::zeros({0, 3});
+        torch::Tensor scaledSamples = torch::exp(scales.index({splits}).repeat({nSplitSamples, 1})) * centeredSamples;
+        torch::Tensor qs = quats.index({splits}) / torch::linalg_vector_norm(quats.index({splits}), 2, {-1}, true, torch::kFloat32);
+        torch::Tensor rots = quatToRotMat(qs.repeat({nSplitSamples, 1}));
+        torch::Tensor rotatedSamples = torch::bmm(rots, scaledSamples.index({"...", None})).squeeze(-1);
+        torch::Tensor splitMeans = rotatedSamples + means.index({splits}).repeat({nSplitSamples, 1});
+        torch::Tensor splitFeaturesDc = featuresDc.index({splits}).repeat({nSplitSamples, 1});
+        torch::Tensor splitFeaturesRest = featuresRest.index({splits}).repeat({nSplitSamples, 1, 1});
+        torch::Tensor splitOpacities = opacities.index({splits}).repeat({nSplitSamples, 1});
+        const float sizeFac = 1.6f;
+        torch::Tensor splitScales = torch::log(torch::exp(scales.index({splits})) / sizeFac).repeat({nSplitSamples, 1});
+        scales.index({splits}) = torch::log(torch::exp(scales.index({splits})) / sizeFac);  // (no effect: index() copies)
+        torch::Tensor splitQuats = quats.index({splits}).repeat({nSplitSamples, 1});
+
+        torch::Tensor dups = (std::get<0>(scales.exp().max(-1)) <= densifySizeThresh).squeeze();
+        dups &= highGrads;
+        torch::Tensor dupMeans = means.index({dups});
+        torch::Tensor dupFeaturesDc = featuresDc.index({dups});
+        torch::Tensor dupFeaturesRest = featuresRest.index({dups});
+        torch::Tensor dupOpacities = opacities.index({dups});
+        torch::Tensor dupScales = scales.index({dups});
+        torch::Tensor dupQuats = quats.index({dups});
+
+        means = torch::cat({means.detach(), splitMeans, dupMeans}, 0);
+        featuresDc = torch::cat({featuresDc.detach(), splitFeaturesDc, dupFeaturesDc}, 0);
+        featuresRest = torch::cat({featuresRest.detach(), splitFeaturesRest, dupFeaturesRest}, 0);
+        opacities = torch::cat({opacities.detach(), splitOpacities, dupOpacities}, 0);
+        scales = torch::cat({scales.detach(), splitScales, dupScales}, 0);
+        quats = torch::cat({quats.detach(), splitQuats, dupQuats}, 0);
+        max2DSize = torch::cat({max2DSize, torch::zeros_like(splitScales.index({Slice(), 0})),
+                                torch::zeros_like(dupScales.index({Slice(), 0}))}, 0);
+
+        torch::Tensor splitIdcs = torch::where(splits)[0];
+        torch::Tensor dupIdcs = torch::where(dups)[0];
+        // addToOptimizer (model.cpp:253-287): exp_avg / exp_avg_sq grow by zeros
+        auto grow = [](torch::Tensor &state, const torch::Tensor &idcs, int nSamples) {
+            std::vector<int64_t> repeats;
+            repeats.push_back(nSamples);
+            for (long int i = 0; i < state.dim() - 1; i++) repeats.push_back(1);
+            state = torch::cat({state, torch::zeros_like(state.index({idcs.squeeze()})).repeat(repeats)}, 0);
+        };
+        for (int i = 0; i < 6; i++) { grow(ea[i], splitIdcs, nSplitSamples); grow(es[i], splitIdcs, nSplitSamples); }
+        for (int i = 0; i < 6; i++) { grow(ea[i], dupIdcs, 1); grow(es[i], dupIdcs, 1); }
+
+        torch::Tensor splitsMask = torch::cat({splits,
+            torch::full({nSplitSamples * splits.sum().item<int>() + dups.sum().item<int>()}, false,
+                        torch::TensorOptions().dtype(torch::kBool))}, 0);
+
+        // Cull (model.cpp:419-458)
+        torch::Tensor culls = (torch::sigmoid(opacities) < cullAlphaThresh).squeeze();
+        if (splitsMask.numel()) culls |= splitsMask;
+        if (cullHuge) {
+            const float cullScaleThresh = 0.5f;
+            const float cullScreenSize = 0.15f;
+            torch::Tensor huge = std::get<0>(torch::exp(scales).max(-1)) > cullScaleThresh;
+            if (checkScreenSize) huge |= max2DSize > cullScreenSize;
+            culls |= huge;
+        }
+        int cullCount = torch::sum(culls).item<int>();
+        if (cullCount > 0) {
+            means = means.index({~culls});
+            scales = scales.index({~culls});
+            quats = quats.index({~culls});
+            featuresDc = featuresDc.index({~culls});
+            featuresRest = featuresRest.index({~culls});
+            opacities = opacities.index({~culls});
+            for (int i = 0; i < 6; i++) {   // removeFromOptimizer (model.cpp:289-309)
+                ea[i] = ea[i].index({~culls});
+                es[i] = es[i].index({~culls});
+            }
+        }
+        counts[1] = (int32_t)means.size(0);
+        counts[2] = dups.sum().item<int>();
+        counts[3] = cullCount;
+        const torch::Tensor outs[6] = {means, scales, quats, opacities, featuresDc, featuresRest};
+        for (int i = 0; i < 6; i++) {
+            out_f(outs[i], out_params[i]);
+            out_f(ea[i], out_exp_avg[i]);
+            out_f(es[i], out_exp_avg_sq[i]);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_train_err = e.what();
+        return -1;
+    }
+}

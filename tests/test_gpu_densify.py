@@ -1,0 +1,163 @@
+"""GPU (MI355X): SURVEY.md §8 row f4 through the C ABI (include/gsplat_densify.h) — per-iteration
+statistics, the split / duplicate / cull refinement with its optimiser-state surgery, the alpha
+reset — against the CPU oracle (oracle/densify_oracle.c, pinned to the reference's statements under
+libtorch by tests/test_densify_oracle.py) and the stored reference vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from opensplat_amd import cabi, scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "densify.npz"))
+DEV = "cuda:0"
+CASES = [(4, True, True, 1), (1, False, True, 2), (16, True, False, 3), (4, False, False, 4)]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def run_gpu(prob, cfg, samples_np):
+    P = [dev(a) for a in prob["params"]]
+    M = [dev(a) for a in prob["exp_avg"]]
+    V = [dev(a) for a in prob["exp_avg_sq"]]
+    fn = lambda n: dev(samples_np(n))
+    p, m, v, c = cabi.densify(cfg, P, M, V, dev(prob["xys_grad_norm"]), dev(prob["vis_counts"]),
+                              dev(prob["max_2d_size"]), fn)
+    torch.cuda.synchronize()
+    np_ = lambda lst: [t.cpu().numpy() for t in lst]
+    return dict(params=np_(p), exp_avg=np_(m), exp_avg_sq=np_(v)), c
+
+
+def check_set(r, ref):
+    """Copied rows bit-equal; split samples' means / scales (exp, log, 3x3 product) 1e-6 relative."""
+    for key in ("params", "exp_avg", "exp_avg_sq"):
+        for i, (a, b) in enumerate(zip(r[key], ref[key])):
+            assert a.shape == b.shape, (key, i, a.shape, b.shape)
+            if a.size == 0:
+                continue
+            if key == "params" and i in (0, 1):
+                assert np.abs(a - b).max() <= 1e-6 * max(np.abs(b).max(), 1.0), (key, i)
+            else:
+                assert np.array_equal(a, b), (key, i)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"K{c[0]}_screen{int(c[1])}_huge{int(c[2])}" for c in CASES])
+def test_refine_matches_reference_vectors(case):
+    K, cs, ch, seed = case
+    prob = scenes.densify_problem(600, K, seed)
+    smp = lambda n: np.random.RandomState(seed + 100).standard_normal((2 * n, 3)).astype(np.float32)
+    cfg = cabi.densify_config(prob["width"], prob["height"], 0.0002, 0.01, cs, 0.05, ch)
+    r, c = run_gpu(prob, cfg, smp)
+    tag = f"c{seed}"
+    assert [c["n_splits"], c["n_dups"], c["new_n"], c["culled"]] == list(GOLD[f"{tag}_counts"])
+    assert c["added"] == 2 * c["n_splits"] + c["n_dups"]
+    assert c["new_n"] == c["kept_orig"] + 2 * c["kept_split"] + c["kept_dup"]
+    ref = {key: [GOLD[f"{tag}_{key}{i}"] for i in range(6)] for key in ("params", "exp_avg", "exp_avg_sq")}
+    check_set(r, ref)
+
+
+@pytest.mark.parametrize("N", [1, 63, 1024, 1025, 5000, 70001])
+def test_refine_matches_oracle_ragged_sizes(N, restated):
+    prob = scenes.densify_problem(N, 4, seed=N)
+    smp = lambda n: np.random.RandomState(N).standard_normal((2 * n, 3)).astype(np.float32)
+    cfg = cabi.densify_config(prob["width"], prob["height"], 0.0002, 0.01, True, 0.05, True)
+    r, c = run_gpu(prob, cfg, smp)
+    o = restated.densify_refine(prob, 0.0002, 0.01, True, 0.05, True, smp)
+    assert (c["n_splits"], c["n_dups"], c["new_n"], c["culled"]) == \
+           (o["n_splits"], o["n_dups"], o["new_n"], o["culled"])
+    check_set(r, o)
+
+
+def test_refine_degenerate_outcomes(restated):
+    smp = lambda n: np.zeros((2 * n, 3), np.float32)
+    # nothing to do: low gradients, healthy opacities -> identity
+    prob = scenes.densify_problem(3000, 4, seed=5)
+    prob["xys_grad_norm"][:] = 0.0
+    prob["params"][3][:] = 2.0
+    cfg = cabi.densify_config(prob["width"], prob["height"], cull_huge=False)
+    r, c = run_gpu(prob, cfg, smp)
+    assert c["n_splits"] == 0 and c["n_dups"] == 0 and c["new_n"] == 3000 and c["culled"] == 0
+    for i in range(6):
+        assert np.array_equal(r["params"][i], prob["params"][i])
+        assert np.array_equal(r["exp_avg"][i], prob["exp_avg"][i])
+    # everything faint: all culled, also the new ones (they inherit the opacity)
+    prob = scenes.densify_problem(2500, 4, seed=6)
+    prob["params"][3][:] = -5.0
+    r, c = run_gpu(prob, cabi.densify_config(prob["width"], prob["height"]), smp)
+    assert c["new_n"] == 0 and c["culled"] == 2500 + c["added"]
+    assert all(a.shape[0] == 0 for a in r["params"])
+    # no optimiser state given: moments of the new set are not produced
+    prob = scenes.densify_problem(1500, 4, seed=7)
+    P = [dev(a) for a in prob["params"]]
+    p, m, v, c = cabi.densify(cabi.densify_config(prob["width"], prob["height"]), P, None, None,
+                              dev(prob["xys_grad_norm"]), dev(prob["vis_counts"]),
+                              dev(prob["max_2d_size"]), lambda n: torch.zeros((2 * n, 3), device=DEV))
+    assert m is None and v is None and p[0].shape[0] == c["new_n"]
+
+
+def test_refine_one_million_properties():
+    """BASELINE size: structural properties instead of the (slow) serial oracle — counts are
+    consistent, survivors are an order-preserving subsequence of the originals with their moments,
+    new rows have zero moments, duplicates are exact copies."""
+    N, K = 1_000_000, 16
+    prob = scenes.densify_problem(N, K, seed=11)
+    # tag every Gaussian through featuresDc[:, 0] so that rows can be traced
+    prob["params"][4][:, 0] = np.arange(N, dtype=np.float32)
+    smp = lambda n: np.random.RandomState(1).standard_normal((2 * n, 3)).astype(np.float32)
+    cfg = cabi.densify_config(prob["width"], prob["height"])
+    r, c = run_gpu(prob, cfg, smp)
+    new_n, ko, ks, kd = c["new_n"], c["kept_orig"], c["kept_split"], c["kept_dup"]
+    assert new_n == ko + 2 * ks + kd and c["culled"] == N + c["added"] - new_n
+    tag = r["params"][4][:, 0].astype(np.int64)
+    assert np.all(np.diff(tag[:ko]) > 0)                                    # originals keep their order
+    assert np.array_equal(tag[ko:ko + ks], tag[ko + ks:ko + 2 * ks])         # sample-major pairs
+    assert np.all(np.diff(tag[ko:ko + ks]) > 0) and np.all(np.diff(tag[ko + 2 * ks:]) > 0)
+    assert not np.intersect1d(tag[:ko], tag[ko:ko + ks]).size               # split sources are culled
+    for i in range(6):
+        src_rows = prob["params"][i][tag]
+        if i not in (0, 1):
+            assert np.array_equal(r["params"][i], src_rows)
+        assert np.array_equal(r["exp_avg"][i][:ko], prob["exp_avg"][i][tag[:ko]])
+        assert not r["exp_avg"][i][ko:].any() and not r["exp_avg_sq"][i][ko:].any()
+    assert np.array_equal(r["params"][0][ko + 2 * ks:], prob["params"][0][tag[ko + 2 * ks:]])  # dups
+    # split samples: scale = log(exp(s) / 1.6), means within a few sigma of the source
+    s_src = prob["params"][1][tag[ko:ko + ks]]
+    assert np.abs(r["params"][1][ko:ko + ks] - (s_src - np.log(np.float32(1.6)))).max() < 1e-5
+    d = np.abs(r["params"][0][ko:ko + ks] - prob["params"][0][tag[ko:ko + ks]]).max(axis=1)
+    assert np.all(d <= 6.0 * np.exp(s_src).max(axis=1) + 1e-6)
+
+
+def test_stats_match_oracle_and_reference_vectors(restated):
+    N = 600
+    rs = np.random.RandomState(5)
+    g = torch.zeros(N, device=DEV); v = torch.zeros(N, device=DEV); m = torch.zeros(N, device=DEV)
+    go = np.zeros(N, np.float32); vo = np.zeros(N, np.float32); mo = np.zeros(N, np.float32)
+    for it in range(4):
+        grad = (rs.standard_normal((N, 2)) * 1e-4).astype(np.float32)
+        rad = (rs.randint(0, 40, N) * (rs.rand(N) < 0.7)).astype(np.int32)
+        grad[rad == 0] = 0
+        cabi.densify_stats(dev(grad), dev(rad), 640.0, it == 0, g, v, m)
+        restated.densify_stats(grad, rad, 480, 640, it == 0, go, vo, mo)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy(), go)      # same IEEE operations as the C oracle
+    assert np.array_equal(v.cpu().numpy(), vo) and np.array_equal(m.cpu().numpy(), mo)
+    assert np.array_equal(v.cpu().numpy(), GOLD["stats_vis"])
+    assert np.array_equal(m.cpu().numpy(), GOLD["stats_m2d"])
+    assert np.abs(g.cpu().numpy() - GOLD["stats_gnorm"]).max() <= 2e-7 * np.abs(go).max()
+
+
+def test_reset_opacity(restated):
+    x = np.linspace(-6, 6, 1001, dtype=np.float32)
+    t = dev(x)
+    m1, m2 = torch.ones_like(t), torch.ones_like(t)
+    cabi.reset_opacity(t, 0.2, m1, m2)
+    assert np.array_equal(t.cpu().numpy(), restated.reset_opacity(x, 0.2))
+    assert not m1.any() and not m2.any()
+    t2 = dev(x)
+    cabi.reset_opacity(t2, 0.2)          # the reference's actual behaviour: moments untouched
+    assert np.array_equal(t2.cpu().numpy(), t.cpu().numpy())
