@@ -466,12 +466,13 @@ def _set(tensors):
 
 
 def densify(cfg: GsDensifyConfig, params, exp_avg, exp_avg_sq, xys_grad_norm, vis_counts,
-            max_2d_size, samples_fn=None):
+            max_2d_size, samples_fn=None, alloc_fn=None):
     """One refinement (model.cpp:345-458): params / exp_avg / exp_avg_sq are lists of the six
     tensors [means, log_scales, quats, opacity_logits, features_dc, features_rest] (the moment
     lists may be None).  samples_fn(n_splits) -> [2 n_splits, 3] normal samples (default
     torch.randn on the device, like the reference).  Returns (new_params, new_exp_avg,
-    new_exp_avg_sq, counts dict); one host sync, to read the counts."""
+    new_exp_avg_sq, counts dict); one host sync, to read the counts.  alloc_fn(new_n) -> (params,
+    exp_avg, exp_avg_sq) lists lets the caller place the new set (e.g. views of flat buffers)."""
     means = params[0]
     N, dev = means.shape[0], means.device
     K = 1 + (params[5].shape[1] if params[5] is not None and params[5].numel() > 0 else 0)
@@ -495,9 +496,12 @@ def densify(cfg: GsDensifyConfig, params, exp_avg, exp_avg_sq, xys_grad_norm, vi
     def alloc(like):
         return [torch.empty((new_n,) + tuple(t.shape[1:]), device=dev, dtype=torch.float32)
                 if t is not None else None for t in like]
-    new_p = alloc(params)
-    new_m = alloc(params) if exp_avg is not None else None
-    new_v = alloc(params) if exp_avg_sq is not None else None
+    if alloc_fn is not None:
+        new_p, new_m, new_v = alloc_fn(new_n)
+    else:
+        new_p = alloc(params)
+        new_m = alloc(params) if exp_avg is not None else None
+        new_v = alloc(params) if exp_avg_sq is not None else None
     src = (GsGaussianSet * 3)(_set(params), _set(exp_avg or [None] * 6), _set(exp_avg_sq or [None] * 6))
     dst = (GsGaussianSet * 3)(_set(new_p), _set(new_m or [None] * 6), _set(new_v or [None] * 6))
     _check(lib().gs_densify_apply(C.c_int(N), C.c_int(K), C.c_int(new_n), _p(samples), src, dst,

@@ -17,8 +17,11 @@ same layout (dist.GradBuffer: [features_rest | features_dc | means | scales | qu
 so the Adam groups are plain slices and the all-reduce needs no gather copy.
 
 A batch of B cameras = B ranks; the step's loss is the mean of the per-camera losses (each rank
-scales its cotangent by 1/B, the all-reduce sums).  Model::afterTrain (densification, model.cpp:
-311-494) is row f4 and not part of this step.
+scales its cotangent by 1/B, the all-reduce sums).
+
+Trainer.after_train mirrors Model::afterTrain (model.cpp:311-494, row f4): per-iteration
+statistics, and every `refine_every` steps the split / duplicate / cull refinement with the
+optimiser-state surgery and the alpha reset, all on the device (include/gsplat_densify.h).
 """
 from __future__ import annotations
 
@@ -35,7 +38,11 @@ class Trainer:
     MEANS_LR_FINAL = 0.0000016
 
     def __init__(self, means, log_scales, quats, opacity_logits, features_dc, features_rest,
-                 device, max_steps: int = 30000, ssim_weight: float = 0.2):
+                 device, max_steps: int = 30000, ssim_weight: float = 0.2, refine_every: int = 100,
+                 warmup_length: int = 500, reset_alpha_every: int = 30,
+                 densify_grad_thresh: float = 0.0002, densify_size_thresh: float = 0.01,
+                 stop_screen_size_at: int = 4000, split_screen_size: float = 0.05,
+                 num_cameras: int = 1):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -53,6 +60,13 @@ class Trainer:
         P.v_opacity.copy_(t(opacity_logits).reshape(-1)); P.v_dc.copy_(t(features_dc))
         if K > 1:
             P.v_rest.copy_(t(features_rest))
+        # densification schedule: the CLI defaults of opensplat.cpp:37-43, model.hpp:30
+        self.refine_every, self.warmup_length = refine_every, warmup_length
+        self.reset_alpha_every, self.stop_split_at = reset_alpha_every, max_steps // 2
+        self.densify_grad_thresh, self.densify_size_thresh = densify_grad_thresh, densify_size_thresh
+        self.stop_screen_size_at, self.split_screen_size = stop_screen_size_at, split_screen_size
+        self.num_cameras = num_cameras
+        self._stats = None          # (xysGradNorm, visCounts, max2DSize); None = cleared
         self.step_count = 0
         self.means_lr = self.LR["means"]
         self._shape = None
@@ -156,3 +170,63 @@ class Trainer:
         self.backward(v_rgb)
         self.optimizer_step()
         return loss
+
+    # ---- Model::afterTrain (model.cpp:311-494) -------------------------------------------------
+    def _param_list(self, buf):
+        return [buf.v_means, buf.v_scales, buf.v_quats, buf.v_opacity.view(-1, 1), buf.v_dc,
+                buf.v_rest if self.K > 1 else None]
+
+    def after_train(self, step: int):
+        """Call after train_step(step's camera).  Returns the densification counts dict when this
+        step refined the Gaussian set, else None."""
+        gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
+        N, dev = self.N, self.dev
+        if step < self.stop_split_at:   # model.cpp:317-337
+            first = self._stats is None
+            if first:
+                self._stats = tuple(torch.empty(N, device=dev, dtype=torch.float32) for _ in range(3))
+            cabi.densify_stats(self.rgrads["v_xy"], p["radii"], float(max(H, W)), first, *self._stats)
+        counts = None
+        if step % self.refine_every == 0 and step > self.warmup_length and self._stats is not None:
+            reset_interval = self.reset_alpha_every * self.refine_every
+            do_densify = step < self.stop_split_at and \
+                step % reset_interval > self.num_cameras + self.refine_every
+            if do_densify:
+                counts = self._refine(step, W, H)
+            if step < self.stop_split_at and step % reset_interval == self.refine_every:
+                # the reference clamps but never installs the zeroed optimiser state (model.cpp:
+                # 475-477); the intended behaviour — reset the moments too — is what runs here
+                cabi.reset_opacity(self.params.v_opacity, 0.2, self.exp_avg.v_opacity,
+                                   self.exp_avg_sq.v_opacity)
+            self._stats = None           # model.cpp:482-484
+        return counts
+
+    def _refine(self, step, W, H):
+        gn, vc, m2 = self._stats
+        if self.world > 1:
+            # one camera per rank: merge the ranks' statistics so that every replica takes the
+            # same decisions (sum of norms, sum of counts minus the extra initial ones, max size)
+            torch.distributed.all_reduce(gn)
+            torch.distributed.all_reduce(vc)
+            vc -= float(self.world - 1)
+            torch.distributed.all_reduce(m2, op=torch.distributed.ReduceOp.MAX)
+        cfg = cabi.densify_config(W, H, self.densify_grad_thresh, self.densify_size_thresh,
+                                  step < self.stop_screen_size_at, self.split_screen_size,
+                                  step > self.refine_every * self.reset_alpha_every)
+        gen = torch.Generator(device=self.dev).manual_seed(1_000_003 * step)  # same on every rank
+        samples_fn = lambda n: torch.randn((2 * n, 3), device=self.dev, generator=gen)
+        new = {}
+
+        def alloc(new_n):
+            for name in ("params", "exp_avg", "exp_avg_sq"):
+                new[name] = dist.GradBuffer(new_n, self.K, self.dev)
+            return tuple(self._param_list(new[n]) for n in ("params", "exp_avg", "exp_avg_sq"))
+        _, _, _, counts = cabi.densify(cfg, self._param_list(self.params),
+                                       self._param_list(self.exp_avg),
+                                       self._param_list(self.exp_avg_sq), gn, vc, m2, samples_fn,
+                                       alloc)
+        self.params, self.exp_avg, self.exp_avg_sq = new["params"], new["exp_avg"], new["exp_avg_sq"]
+        self.N = counts["new_n"]
+        self.grads = dist.GradBuffer(self.N, self.K, self.dev)
+        self._shape = None               # per-N render buffers are rebuilt on the next render
+        return counts

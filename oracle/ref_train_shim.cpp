@@ -299,3 +299,105 @@ extern "C" int ref_densify_refine(int N, int K, const float *const *params, cons
         return -1;
     }
 }
+
+// ---- row f4, second half: Model::savePly / saveSplat (model.cpp:505-598) restated ----------------
+// Same statements, free functions over explicit tensors (model.cpp cannot be compiled here).
+#include <fstream>
+#include <numeric>
+
+#include "spherical_harmonics.hpp"
+
+extern "C" int ref_save_ply(const char *filename, int numPoints, int K, const float *means_, const float *scales_,
+                            const float *quats_, const float *opacities_, const float *featuresDc_,
+                            const float *featuresRest_, int step, int keepCrs, float scale,
+                            const float *translation_) {
+    try {
+        torch::Tensor means = tf(means_, {numPoints, 3}), scales = tf(scales_, {numPoints, 3}),
+                      quats = tf(quats_, {numPoints, 4}), opacities = tf(opacities_, {numPoints, 1}),
+                      featuresDc = tf(featuresDc_, {numPoints, 3}),
+                      featuresRest = tf(featuresRest_, {numPoints, K - 1, 3});
+        torch::Tensor translation = translation_ ? tf(translation_, {3}) : torch::zeros({3});
+        std::ofstream o(filename, std::ios::binary);
+        o << "ply" << std::endl;
+        o << "format binary_little_endian 1.0" << std::endl;
+        o << "comment Generated by opensplat at iteration " << step << std::endl;
+        o << "element vertex " << numPoints << std::endl;
+        o << "property float x" << std::endl;
+        o << "property float y" << std::endl;
+        o << "property float z" << std::endl;
+        o << "property float nx" << std::endl;
+        o << "property float ny" << std::endl;
+        o << "property float nz" << std::endl;
+        for (int i = 0; i < featuresDc.size(1); i++) o << "property float f_dc_" << i << std::endl;
+        torch::Tensor featuresRestCpu = featuresRest.cpu().transpose(1, 2).reshape({numPoints, -1});
+        for (int i = 0; i < featuresRestCpu.size(1); i++) o << "property float f_rest_" << i << std::endl;
+        o << "property float opacity" << std::endl;
+        o << "property float scale_0" << std::endl;
+        o << "property float scale_1" << std::endl;
+        o << "property float scale_2" << std::endl;
+        o << "property float rot_0" << std::endl;
+        o << "property float rot_1" << std::endl;
+        o << "property float rot_2" << std::endl;
+        o << "property float rot_3" << std::endl;
+        o << "end_header" << std::endl;
+        float zeros[] = {0.0f, 0.0f, 0.0f};
+        torch::Tensor meansCpu = keepCrs ? (means.cpu() / scale) + translation : means.cpu();
+        torch::Tensor featuresDcCpu = featuresDc.cpu();
+        torch::Tensor opacitiesCpu = opacities.cpu();
+        torch::Tensor scalesCpu = keepCrs ? torch::log((torch::exp(scales.cpu()) / scale)) : scales.cpu();
+        torch::Tensor quatsCpu = quats.cpu();
+        for (size_t i = 0; i < (size_t)numPoints; i++) {
+            o.write(reinterpret_cast<const char *>(meansCpu[i].data_ptr()), sizeof(float) * 3);
+            o.write(reinterpret_cast<const char *>(zeros), sizeof(float) * 3);
+            o.write(reinterpret_cast<const char *>(featuresDcCpu[i].data_ptr()), sizeof(float) * featuresDcCpu.size(1));
+            o.write(reinterpret_cast<const char *>(featuresRestCpu[i].contiguous().data_ptr()), sizeof(float) * featuresRestCpu.size(1));
+            o.write(reinterpret_cast<const char *>(opacitiesCpu[i].data_ptr()), sizeof(float) * 1);
+            o.write(reinterpret_cast<const char *>(scalesCpu[i].data_ptr()), sizeof(float) * 3);
+            o.write(reinterpret_cast<const char *>(quatsCpu[i].data_ptr()), sizeof(float) * 4);
+        }
+        o.close();
+        return 0;
+    } catch (const std::exception &e) {
+        g_train_err = e.what();
+        return -1;
+    }
+}
+
+extern "C" int ref_save_splat(const char *filename, int numPoints, const float *means_, const float *scales_,
+                              const float *quats_, const float *opacities_, const float *featuresDc_,
+                              int keepCrs, float scale, const float *translation_) {
+    try {
+        torch::Tensor means = tf(means_, {numPoints, 3}), scales = tf(scales_, {numPoints, 3}),
+                      quats = tf(quats_, {numPoints, 4}), opacities = tf(opacities_, {numPoints, 1}),
+                      featuresDc = tf(featuresDc_, {numPoints, 3});
+        torch::Tensor translation = translation_ ? tf(translation_, {3}) : torch::zeros({3});
+        std::ofstream o(filename, std::ios::binary);
+        torch::Tensor meansCpu = keepCrs ? (means.cpu() / scale) + translation : means.cpu();
+        torch::Tensor scalesCpu = keepCrs ? (torch::exp(scales.cpu()) / scale) : torch::exp(scales.cpu());
+        torch::Tensor rgbsCpu = (sh2rgb(featuresDc.cpu()) * 255.0f).toType(torch::kUInt8);
+        torch::Tensor opac = (1.0f + torch::exp(-opacities.cpu()));
+        torch::Tensor opacitiesCpu = torch::clamp(((1.0f / opac) * 255.0f), 0.0f, 255.0f).toType(torch::kUInt8);
+        torch::Tensor quatsCpu = torch::clamp(quats.cpu() * 128.0f + 128.0f, 0.0f, 255.0f).toType(torch::kUInt8);
+        std::vector<size_t> splatIndices(numPoints);
+        std::iota(splatIndices.begin(), splatIndices.end(), 0);
+        torch::Tensor order = (scalesCpu.index({"...", 0}) + scalesCpu.index({"...", 1}) + scalesCpu.index({"...", 2})) /
+                              opac.index({"...", 0});
+        order = order.contiguous();
+        float *orderPtr = reinterpret_cast<float *>(order.data_ptr());
+        std::sort(splatIndices.begin(), splatIndices.end(),
+                  [&orderPtr](size_t const &a, size_t const &b) { return orderPtr[a] > orderPtr[b]; });
+        for (int i = 0; i < numPoints; i++) {
+            size_t idx = splatIndices[i];
+            o.write(reinterpret_cast<const char *>(meansCpu[idx].data_ptr()), sizeof(float) * 3);
+            o.write(reinterpret_cast<const char *>(scalesCpu[idx].data_ptr()), sizeof(float) * 3);
+            o.write(reinterpret_cast<const char *>(rgbsCpu[idx].data_ptr()), sizeof(uint8_t) * 3);
+            o.write(reinterpret_cast<const char *>(opacitiesCpu[idx].data_ptr()), sizeof(uint8_t) * 1);
+            o.write(reinterpret_cast<const char *>(quatsCpu[idx].data_ptr()), sizeof(uint8_t) * 4);
+        }
+        o.close();
+        return 0;
+    } catch (const std::exception &e) {
+        g_train_err = e.what();
+        return -1;
+    }
+}

@@ -65,6 +65,59 @@ def torch_adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+def torch_refine_ms(P, M, V, gnorm, vis, m2d, W, H):
+    """Model::afterTrain's densification branch (model.cpp:345-458 + addToOptimizer /
+    removeFromOptimizer) as the torch ops the reference issues, on the GPU; wall time incl. syncs."""
+    import time
+
+    def run():
+        means, scales, quats, opac, dc, rest = P
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        avg = (gnorm / vis) * 0.5 * float(max(W, H))
+        high = avg > 0.0002
+        splits = scales.exp().max(-1)[0] > 0.01
+        splits = (splits | (m2d > 0.05)) & high
+        n_splits = int(splits.sum().item())
+        smp = torch.randn((2 * n_splits, 3), device=means.device)
+        scaled = torch.exp(scales[splits].repeat(2, 1)) * smp
+        qs = quats[splits] / quats[splits].norm(dim=-1, keepdim=True)
+        u = F.normalize(qs.repeat(2, 1), dim=-1)
+        w, x, y, z = u.unbind(-1)
+        rots = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                            torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                            torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+        split_means = torch.bmm(rots, scaled[..., None]).squeeze(-1) + means[splits].repeat(2, 1)
+        split_scales = torch.log(torch.exp(scales[splits]) / 1.6).repeat(2, 1)
+        dups = (scales.exp().max(-1)[0] <= 0.01) & high
+        new = [torch.cat([means, split_means, means[dups]]), torch.cat([scales, split_scales, scales[dups]]),
+               torch.cat([quats, quats[splits].repeat(2, 1), quats[dups]]),
+               torch.cat([opac, opac[splits].repeat(2, 1), opac[dups]]),
+               torch.cat([dc, dc[splits].repeat(2, 1), dc[dups]]),
+               torch.cat([rest, rest[splits].repeat(2, 1, 1), rest[dups]])]
+        m2 = torch.cat([m2d, torch.zeros(2 * n_splits + int(dups.sum().item()), device=means.device)])
+        si, di = torch.where(splits)[0], torch.where(dups)[0]
+        states = []
+        for st in (M, V):
+            grown = []
+            for t in st:
+                t = torch.cat([t, torch.zeros_like(t[si]).repeat(2, *([1] * (t.dim() - 1)))])
+                t = torch.cat([t, torch.zeros_like(t[di])])
+                grown.append(t)
+            states.append(grown)
+        splits_mask = torch.cat([splits, torch.zeros(2 * n_splits + int(dups.sum().item()), dtype=torch.bool,
+                                                     device=means.device)])
+        culls = (torch.sigmoid(new[3]) < 0.1).squeeze() | splits_mask
+        culls |= (torch.exp(new[1]).max(-1)[0] > 0.5) | (m2 > 0.15)
+        if int(culls.sum().item()) > 0:
+            new = [t[~culls] for t in new]
+            states = [[t[~culls] for t in st] for st in states]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+    run()
+    return min(run() for _ in range(3))
+
+
 def main():
     out = {"workload": f"loss at {W}x{H}; Adam over N={N} Gaussians, SH degree 3 (K={K}): "
                        f"{N * (3 * K + 11)} parameters in six groups"}
@@ -145,6 +198,37 @@ def main():
                                     "Model::forward + mainLoss + backward + optimizersStep",
                         "ms": it_ms, "iterations_per_s": 1e3 / it_ms, "stage_ms": stages,
                         "loss_after": [float(x) for x in T.loss_out[0].cpu()]}
+
+    # ---- row f4: Model::afterTrain on the device ------------------------------------------------
+    N_ = s_.N
+    stats = [torch.zeros(N_, device=DEV) for _ in range(3)]
+    cabi.densify_stats(T.rgrads["v_xy"], T.proj["radii"], float(max(s_.W, s_.H)), True, *stats)
+    st_ms = timeit(lambda: cabi.densify_stats(T.rgrads["v_xy"], T.proj["radii"],
+                                              float(max(s_.W, s_.H)), False, *stats))
+    prob = scenes.densify_problem(N, K, seed=11)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    P_, M_, V_ = ([d(a) for a in prob[k]] for k in ("params", "exp_avg", "exp_avg_sq"))
+    gs_, vc_, m2_ = d(prob["xys_grad_norm"]), d(prob["vis_counts"]), d(prob["max_2d_size"])
+    cfg = cabi.densify_config(prob["width"], prob["height"])
+    import time as _t
+
+    def refine():
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        r = cabi.densify(cfg, P_, M_, V_, gs_, vc_, m2_)
+        torch.cuda.synchronize()
+        return (_t.perf_counter() - t0) * 1e3, r[3]
+    refine()
+    times = [refine() for _ in range(5)]
+    out["densify"] = {"stats_ms_per_iteration": st_ms,
+                      "stats_algorithmic_bytes": N_ * (8 + 4 + 6 * 4),
+                      "refine_wall_ms": min(t for t, _ in times), "refine_counts": times[0][1],
+                      "refine_workload": f"{N} Gaussians, K={K}: parameters + 2 Adam moments "
+                                         f"({3 * N * (3 * K + 11) * 4 / 1e6:.0f} MB in), incl. the "
+                                         "count read-back and torch.randn"}
+    if not ours_only:
+        out["densify"]["refine_torch_ops_same_gpu_wall_ms"] = torch_refine_ms(P_, M_, V_, gs_, vc_, m2_,
+                                                                              prob["width"], prob["height"])
 
     if "--no-cpu" not in sys.argv:
         import oracle

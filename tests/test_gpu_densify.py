@@ -161,3 +161,53 @@ def test_reset_opacity(restated):
     t2 = dev(x)
     cabi.reset_opacity(t2, 0.2)          # the reference's actual behaviour: moments untouched
     assert np.array_equal(t2.cpu().numpy(), t.cpu().numpy())
+
+
+def test_trainer_after_train_schedule_and_refinement(restated):
+    """Model::afterTrain's schedule driven by Trainer on a small scene with a fast schedule: the
+    statistics accumulate, step 12 refines (checked against the oracle on the captured state, same
+    normal samples), the alpha reset fires at step % reset_interval == refine_every, training
+    continues on the grown set."""
+    from opensplat_amd import train
+
+    s = scenes.camera_scene(4000, 256, 192, K=4, seed=81, znear=1.0, zfar=100.0, degrees_to_use=1)
+    raw = scenes.raw_parameters(s)
+    cam = dict(viewmat=s.viewmat, projmat=s.projmat, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, W=s.W, H=s.H)
+    _, gt_np = scenes.loss_images(s.W, s.H, seed=3)
+    gt = dev(gt_np)
+    T = train.Trainer(*raw, torch.device(DEV), max_steps=200, refine_every=4, warmup_length=5,
+                      reset_alpha_every=5, densify_grad_thresh=2e-6, densify_size_thresh=0.01,
+                      stop_screen_size_at=100, num_cameras=1)
+    # reset_interval = 20; densify when step % 20 > 5: steps 8, 12, 16; alpha reset at step 24
+    events = {}
+    for step in range(1, 26):
+        T.train_step(cam, gt, s.background, s.degrees_to_use)
+        if step == 8:   # capture the state the refinement will see
+            torch.cuda.synchronize()
+            np_ = lambda lst: [t.detach().cpu().numpy().copy() if t is not None else None for t in lst]
+            snap = dict(params=np_(T._param_list(T.params)), exp_avg=np_(T._param_list(T.exp_avg)),
+                        exp_avg_sq=np_(T._param_list(T.exp_avg_sq)),
+                        stats=[t.cpu().numpy().copy() for t in T._stats],
+                        v_xy=T.rgrads["v_xy"].cpu().numpy().copy(),
+                        radii=T.proj["radii"].cpu().numpy().copy())
+        c = T.after_train(step)
+        if c is not None:
+            events[step] = (c, T.N)
+    torch.cuda.synchronize()
+    assert sorted(events) == [8, 12, 16], sorted(events)   # 20 % 20 = 0 and 24 % 20 = 4 are not > 5
+    c8, n8 = events[8]
+    assert c8["added"] > 0 and n8 == c8["new_n"]
+    # oracle on the captured state
+    gn, vc, m2 = [a.copy() for a in snap["stats"]]
+    restated.densify_stats(snap["v_xy"], snap["radii"], s.H, s.W, False, gn, vc, m2)
+    prob = dict(params=snap["params"], exp_avg=snap["exp_avg"], exp_avg_sq=snap["exp_avg_sq"],
+                xys_grad_norm=gn, vis_counts=vc, max_2d_size=m2, width=s.W, height=s.H, K=4, N=4000)
+    gen = torch.Generator(device=DEV).manual_seed(1_000_003 * 8)
+    smp = lambda n: torch.randn((2 * n, 3), device=DEV, generator=gen).cpu().numpy()
+    o = restated.densify_refine(prob, 2e-6, 0.01, True, 0.05, False, smp)
+    assert (o["n_splits"], o["n_dups"], o["new_n"]) == (c8["n_splits"], c8["n_dups"], c8["new_n"])
+    # ... and the run continued on the refined set with finite losses and consistent buffers
+    assert T.N == events[16][1]
+    for buf in (T.params, T.grads, T.exp_avg, T.exp_avg_sq):
+        assert buf.flat.numel() == T.N * (3 * 4 + 11) and torch.isfinite(buf.flat).all()
+    assert T.opacity_logits.max().item() <= np.log(0.2 / 0.8) + 1.0   # reset at step 24, one Adam step since
