@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""End-to-end training on a synthetic multi-view capture — the stand-in for BASELINE config 5
+(banana COLMAP to 7 k iterations: the dataset is not available offline).
+
+A ground-truth Gaussian set is rendered from a ring of cameras with this repo's renderer; training
+starts, like OpenSplat does from SfM points (model.hpp:33-60), from a noisy subsample of positions
+and colours with kNN-derived scales, and runs the reference's loop (opensplat.cpp:151-170) through
+`opensplat_amd.train.Trainer`: Model::forward -> mainLoss (L1 + SSIM) -> backward -> Adam ->
+scheduler -> afterTrain (densification schedule of the CLI defaults).  Reports PSNR on held-out
+cameras, Gaussian count, iterations/s, a PLY save / load round trip, and the reference's CPU path
+timed on the same scene for the wall-clock comparison.
+
+  python scripts/train_synthetic.py [--iters 3000] [--no-cpu]   -> one JSON object on stdout
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from opensplat_amd import io, scenes, train  # noqa: E402
+
+DEV = torch.device("cuda:0")
+C0 = 0.28209479177387814
+
+
+def look_at(pos, target=(0.0, 0.0, 0.0)):
+    """World -> camera (x right, y down, z forward: the convention of scenes.py / model.cpp:93-104)."""
+    pos, target = np.asarray(pos, np.float64), np.asarray(target, np.float64)
+    f = target - pos
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.array([0.0, -1.0, 0.0]))
+    r /= np.linalg.norm(r)
+    d = np.cross(f, r)
+    R = np.stack([r, d, f])
+    vm = np.eye(4, dtype=np.float32)
+    vm[:3, :3] = R
+    vm[:3, 3] = -R @ pos
+    return vm
+
+
+def make_camera(pos, W, H, fov_deg=50.0):
+    fx = fy = 0.5 * W / math.tan(0.5 * math.radians(fov_deg))
+    fovx, fovy = 2.0 * math.atan(W / (2.0 * fx)), 2.0 * math.atan(H / (2.0 * fy))
+    vm = look_at(pos)
+    pm = (scenes.projection_matrix(0.001, 1000.0, fovx, fovy) @ vm).astype(np.float32)
+    return dict(viewmat=vm, projmat=pm, fx=fx, fy=fy, cx=W / 2.0, cy=H / 2.0, W=W, H=H)
+
+
+def ground_truth(n, K, rs):
+    """A few blobs and a shell of small anisotropic Gaussians with position-dependent colour."""
+    centres = rs.uniform(-0.6, 0.6, (6, 3))
+    which = rs.randint(0, 6, n)
+    means = centres[which] + 0.22 * rs.standard_normal((n, 3))
+    shell = rs.rand(n) < 0.3
+    d = rs.standard_normal((n, 3))
+    means[shell] = 0.95 * d[shell] / np.linalg.norm(d[shell], axis=1, keepdims=True)
+    log_scales = np.log(rs.uniform(0.012, 0.05, (n, 1)) * rs.uniform(0.3, 1.0, (n, 3)))
+    quats = scenes.random_quats(rs.rand(n), rs.rand(n), rs.rand(n))
+    logits = rs.normal(1.5, 1.0, (n, 1))
+    rgb = 0.5 + 0.45 * np.sin(3.0 * means + np.array([0.0, 2.0, 4.0]))
+    dc = (rgb - 0.5) / C0
+    rest = 0.03 * rs.standard_normal((n, K - 1, 3))
+    f = np.float32
+    return [means.astype(f), log_scales.astype(f), quats.astype(f), logits.astype(f), dc.astype(f),
+            rest.astype(f)]
+
+
+def sfm_like_init(gt, n, K, rs):
+    """Model's initialisation from points (model.hpp:36-60): means = points, scales = log of the mean
+    distance to the 3 nearest neighbours, random quats, opacity logit(0.1), featuresDc = rgb2sh."""
+    from scipy.spatial import cKDTree
+
+    idx = rs.choice(gt[0].shape[0], n, replace=False)
+    pts = gt[0][idx] + 0.01 * rs.standard_normal((n, 3)).astype(np.float32)
+    rgb = np.clip(gt[4][idx] * C0 + 0.5 + 0.05 * rs.standard_normal((n, 3)), 0.0, 1.0)
+    dist, _ = cKDTree(pts).query(pts, k=4)
+    scale = np.log(np.maximum(dist[:, 1:].mean(1), 1e-4))[:, None].repeat(3, 1)
+    f = np.float32
+    return [pts.astype(f), scale.astype(f),
+            scenes.random_quats(rs.rand(n), rs.rand(n), rs.rand(n)),
+            np.full((n, 1), math.log(0.1 / 0.9), f), ((rgb - 0.5) / C0).astype(f),
+            np.zeros((n, K - 1, 3), f)]
+
+
+def psnr(a, b):
+    mse = float(((a - b) ** 2).mean())
+    return 10.0 * math.log10(1.0 / max(mse, 1e-12))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=3000)
+    ap.add_argument("--gt-gaussians", type=int, default=20000)
+    ap.add_argument("--init-points", type=int, default=6000)
+    ap.add_argument("--width", type=int, default=384)
+    ap.add_argument("--height", type=int, default=288)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    rs = np.random.RandomState(0)
+    K, W, H = 16, a.width, a.height
+    bg = np.array([0.0, 0.0, 0.0], np.float32)
+
+    n_train, n_test = 24, 4
+    cams = []
+    for i in range(n_train + n_test):
+        ang = 2.0 * math.pi * (i + (0.5 if i >= n_train else 0.0)) / (n_train if i < n_train else n_test)
+        h = 0.8 * math.sin(3.0 * ang) if i < n_train else 0.3
+        cams.append(make_camera((3.5 * math.cos(ang), h, 3.5 * math.sin(ang)), W, H))
+    gt_params = ground_truth(a.gt_gaussians, K, rs)
+    G = train.Trainer(*gt_params, DEV)
+    images = [G.render(c, bg, 3).clone() for c in cams]
+    torch.cuda.synchronize()
+
+    init = sfm_like_init(gt_params, a.init_points, K, rs)
+    T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train)
+    sh_interval = max(a.iters // 4, 1)          # --sh-degree-interval 1000 at 3000+ iterations
+
+    def evaluate():
+        vals = []
+        for c, img in zip(cams[n_train:], images[n_train:]):
+            deg = min(T.step_count // sh_interval, 3)
+            vals.append(psnr(T.render(c, bg, deg).clamp(0, 1), img))
+        return float(np.mean(vals))
+
+    curve = [{"step": 0, "psnr": evaluate(), "gaussians": T.N}]
+    order = np.random.RandomState(1)
+    refinements = []
+    torch.cuda.synchronize()
+    t0 = time.time()
+    train_time = 0.0
+    for step in range(1, a.iters + 1):
+        ci = int(order.randint(0, n_train))
+        deg = min(step // sh_interval, 3)        # model.cpp:85 degreesToUse
+        loss = T.train_step(cams[ci], images[ci], bg, deg)
+        if step % max(a.iters // 6, 1) == 0:
+            last_loss = [float(x) for x in loss.cpu()]   # before a refinement reallocates buffers
+        c = T.after_train(step)
+        if c is not None:
+            refinements.append({"step": step, "added": c["added"], "culled": c["culled"], "gaussians": T.N})
+        if step % max(a.iters // 6, 1) == 0:
+            torch.cuda.synchronize()
+            train_time += time.time() - t0
+            curve.append({"step": step, "psnr": evaluate(), "gaussians": T.N,
+                          "loss": last_loss})
+            torch.cuda.synchronize()
+            t0 = time.time()
+    torch.cuda.synchronize()
+    train_time += time.time() - t0
+
+    # save / load round trip through the Inria-compatible PLY (model.cpp:505-562, 640-767)
+    params = dict(means=T.means, log_scales=T.log_scales, quats=T.quats,
+                  opacity_logits=T.opacity_logits.view(-1, 1), features_dc=T.features_dc,
+                  features_rest=T.features_rest)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "splat.ply")
+        io.save(path, params, a.iters)
+        loaded, step_loaded = io.load_ply(path)
+        size = os.path.getsize(path)
+        io.save(os.path.join(d, "scene.splat"), params, a.iters)
+        splat_size = os.path.getsize(os.path.join(d, "scene.splat"))
+    T2 = train.Trainer(loaded["means"], loaded["log_scales"], loaded["quats"], loaded["opacity_logits"],
+                       loaded["features_dc"], loaded["features_rest"], DEV)
+    same = bool(torch.equal(T2.render(cams[-1], bg, 3), T.render(cams[-1], bg, 3)))
+
+    out = {"workload": f"synthetic capture: {a.gt_gaussians} ground-truth Gaussians, {n_train} training + "
+                       f"{n_test} held-out cameras at {W}x{H}, SH degree 3; {a.init_points} initial points; "
+                       f"{a.iters} iterations with the reference's densification defaults",
+           "psnr_curve": curve, "refinements": refinements, "final_gaussians": T.N,
+           "train_seconds": train_time, "iterations_per_s": a.iters / train_time,
+           "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,
+           "ply_round_trip_renders_identically": same}
+
+    if not a.no_cpu:
+        import oracle
+        if oracle.have_reference():
+            R = oracle.reference()
+            # the reference's CPU operators on the INITIAL Gaussian set, one camera
+            c = cams[0]
+            means, ls, q, lo, dc, rest = init
+            vm = c["viewmat"]
+            cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)
+            dirs = means - cam_pos
+            dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+            coeffs = np.concatenate([dc[:, None, :], rest], 1)
+            v = np.random.RandomState(2).uniform(-1e-4, 1e-4, (H, W, 3)).astype(np.float32)
+            t1 = time.time()
+            r = R.chain_fwd_bwd(means, np.exp(ls), q / np.linalg.norm(q, axis=1, keepdims=True), dirs, coeffs,
+                                (1 / (1 + np.exp(-lo))).astype(np.float32), vm, c["projmat"],
+                                c["fx"], c["fy"], c["cx"], c["cy"], H, W, bg, v, degrees_to_use=3)
+            render_s = (r["fwd_ms"] + r["bwd_ms"]) / 1e3
+            R.main_loss(images[0].cpu().numpy(), images[1].cpu().numpy(), 0.2)
+            loss_s = R.last_ms / 1e3
+            out["cpu_baseline"] = {"kind": "reference", "threads_torch": torch.get_num_threads(),
+                                   "render_fwd_bwd_s": render_s, "main_loss_s": loss_s,
+                                   "sample": f"1 iteration's render + loss on the {a.init_points}-point initial set "
+                                             f"(no optimiser, no growth): {render_s + loss_s:.3f} s -> "
+                                             f">= {(render_s + loss_s) * a.iters:.0f} s for {a.iters} iterations",
+                                   "wall_s": time.time() - t1}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
