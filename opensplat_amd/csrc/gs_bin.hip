@@ -202,6 +202,32 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
 // different banks
 __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 
+// Inclusive scan of one int per thread over a 1024-thread workgroup: shuffles inside the waves,
+// the sixteen wave totals through LDS (three barriers instead of the twenty of a Hillis-Steele
+// scan in LDS).  `ws` holds 17 ints; ws[16] receives the grand total.
+static __device__ __forceinline__ int32_t block_scan_1024(int32_t v, int32_t *ws) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    __syncthreads();  // ws may still be read from a previous call
+    if (lane == 63) ws[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int w = 0; w < 16; w++) {
+            const int32_t x = ws[w];
+            ws[w] = run;
+            run += x;
+        }
+        ws[16] = run;
+    }
+    __syncthreads();
+    return v + ws[wave];
+}
+
 __global__ void __launch_bounds__(1024)
 k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
              int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
@@ -225,17 +251,10 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
     if (t == 0) s_longest = 0;
     __syncthreads();
     atomicMax(&s_longest, longest);
-    part[t] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        int32_t v = (t >= d) ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    const int32_t total_keep = part[1023];
-    int32_t run = part[t] - sum;  // exclusive prefix of this thread's slice
+    __shared__ int32_t ws[17];
+    const int32_t incl = block_scan_1024(sum, ws);
+    const int32_t total_keep = ws[16];
+    int32_t run = incl - sum;  // exclusive prefix of this thread's slice
     if (use_lds) {
         for (int i = lo; i < hi; i++) {  // counts -> exclusive starts, in place
             const int32_t c = c_lds[skew(i)];
@@ -266,28 +285,21 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
         while ((longest_all >> shift) >= 1024) shift++;
         part[t] = 0;
         __syncthreads();
-        for (int i = t; i < tiles; i += 1024) {
-            const int32_t c = use_lds ? (bins[i].y - bins[i].x) : counts[i];
-            atomicAdd(&part[1023 - (c >> shift)], 1);  // bucket 0 = longest lists
-        }
+        // list length of tile i: from the exclusive starts still in LDS (no global read-back)
+        auto length = [&](int i) -> int32_t {
+            if (!use_lds) return counts[i];
+            const int32_t st = c_lds[skew(i)];
+            return ((i + 1 < tiles) ? c_lds[skew(i + 1)] : total_keep) - st;
+        };
+        for (int i = t; i < tiles; i += 1024)
+            atomicAdd(&part[1023 - (length(i) >> shift)], 1);  // bucket 0 = longest lists
         __syncthreads();
         const int32_t own = part[t];
-        for (int d = 1; d < 1024; d <<= 1) {
-            int32_t v = (t >= d) ? part[t - d] : 0;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
-        }
-        const int32_t total_all = part[1023];
-        const int32_t first = part[t] - own;
-        __syncthreads();
+        const int32_t first = block_scan_1024(own, ws) - own;
         part[t] = first;
         __syncthreads();
-        for (int i = t; i < tiles; i += 1024) {
-            const int32_t c = use_lds ? (bins[i].y - bins[i].x) : counts[i];
-            order[atomicAdd(&part[1023 - (c >> shift)], 1)] = i;
-        }
-        (void)total_all;
+        for (int i = t; i < tiles; i += 1024)
+            order[atomicAdd(&part[1023 - (length(i) >> shift)], 1)] = i;
     }
     if (t == 1023) {
         *total_dev = total_keep;
