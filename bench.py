@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--fast-exp", action="store_true",
                     help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-kernels", action="store_true",
+                    help="run projection / SH / pack and their backwards as separate kernels "
+                         "(operator granularity) instead of the fused per-Gaussian kernels")
     ap.add_argument("--hot", type=float, default=0.0,
                     help="experiment: fraction of the Gaussians concentrated in a 48x48 px window")
     ap.add_argument("--cpu-gaussians", type=int, default=0,
@@ -63,7 +66,7 @@ def parse_args():
 class Pipeline:
     """The hot path on one GPU with every buffer preallocated."""
 
-    def __init__(self, scene, device, flags):
+    def __init__(self, scene, device, flags, stage_kernels=False):
         import torch
 
         from opensplat_amd import cabi, dist
@@ -107,13 +110,28 @@ class Pipeline:
         self.num_isects = 0
         self.multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size() > 1
-        self.stage_names = ["project_fwd", "sh_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
-                            "sh_bwd", "project_bwd", "allreduce"]
+        # default: the per-Gaussian stages fused into one kernel per direction (gs_gaussian_*);
+        # --stage-kernels runs them as the separate operator-granular kernels instead
+        self.stage_kernels = stage_kernels
+        if stage_kernels:
+            self.stage_names = ["project_fwd", "sh_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
+                                "sh_bwd", "project_bwd", "allreduce"]
+        else:
+            self.stage_names = ["gaussian_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
+                                "gaussian_bwd", "allreduce"]
+            self.gfwd = dict(packed=torch.empty((N, 12), **f), depths=self.proj["depths"],
+                             radii=self.proj["radii"], rgb_raw=self.sh_out[1], xys=None)
+            self.bwd_ws.zero_()   # the fused backward leaves the records zeroed (no memset per step)
+            self.gout = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
+                             v_quats=self.grads.v_quats, v_opacity=self.grads.v_opacity,
+                             v_dc=self.grads.v_dc, v_rest=self.grads.v_rest)
 
     def step(self, events=None, kernel_events=None):
         """One forward+backward.  events: list that receives the stage-boundary events;
         kernel_events: dict name -> (start, stop) event pairs armed around the two compositing
         kernels alone (gs_debug_time_next_kernel)."""
+        if not self.stage_kernels:
+            return self.step_fused(events, kernel_events)
         torch, cabi, s = self.torch, self.cabi, self.s
 
         def mark():
@@ -177,6 +195,57 @@ class Pipeline:
         w2 = self.dist.allreduce_rest_async(self.grads)
         self.dist.wait_all(w1, w2)
         mark()
+
+
+    def step_fused(self, events=None, kernel_events=None):
+        """Same work with gs_gaussian_forward / gs_gaussian_backward around binning + compositing."""
+        torch, cabi, s = self.torch, self.cabi, self.s
+        KEEP = cabi.GS_FLAG_KEEP_RECORDS | cabi.GS_FLAG_RECORDS_ZEROED
+        while True:
+            ev_local = []
+
+            def mark():
+                if events is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    ev_local.append(e)
+
+            mark()
+            g = cabi.gaussian_forward(self.cam, self.means, self.scales, self.quats, self.opac,
+                                      self.features_dc, self.features_rest, self.cam_pos,
+                                      s.degrees_to_use, 0, out=self.gfwd, viewmat_dev=self.vm_dev,
+                                      projmat_dev=self.pm_dev)
+            mark()
+            b = cabi.bin_and_sort(s.W, s.H, None, g["depths"], None, None, None, None, None, self.ws,
+                                  speculative=True, packed=g["packed"])
+            mark()
+            if kernel_events is not None:
+                cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
+            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
+            mark()
+            if not cabi.validate_binning(b):
+                continue
+            if kernel_events is not None:
+                cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
+            cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"], f["final_idx"],
+                                    self.v_out, self.flags | KEEP, workspace=self.bwd_ws)
+            mark()
+            cabi.gaussian_backward(self.cam, self.means, self.scales, self.quats, self.opac,
+                                   self.cam_pos, s.K, s.degrees_to_use, g["radii"], g["rgb_raw"],
+                                   self.bwd_ws, self.gout, 0, viewmat_dev=self.vm_dev,
+                                   projmat_dev=self.pm_dev)
+            mark()
+            break
+        self.num_isects = b.num_isects
+        if events is not None:
+            events.extend(ev_local)
+        w1 = self.dist.allreduce_sh_async(self.grads)
+        w2 = self.dist.allreduce_rest_async(self.grads)
+        self.dist.wait_all(w1, w2)
+        if events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            events.append(e)
 
 
 def algorithmic_bytes(N, K, M, P):
@@ -269,7 +338,7 @@ def main():
                     "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians, world))
 
     flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
-    pipe = Pipeline(scene, dev, flags)
+    pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels)
 
     def barrier():
         if world > 1:
@@ -361,6 +430,8 @@ def main():
             "config": {"workload": workload, "gaussians": N, "width": scene.W, "height": scene.H,
                        "sh_bases": K, "tile": 16, "intersections_M": M,
                        "exp": "hardware v_exp_f32" if args.fast_exp else "glibc-bit-exact expf (parity mode)",
+                       "per_gaussian_stages": "separate kernels" if args.stage_kernels else
+                       "fused (gs_gaussian_forward / gs_gaussian_backward)",
                        "parallelism": "camera-per-rank dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

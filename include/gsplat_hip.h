@@ -72,6 +72,12 @@ typedef struct GsCamera {
 #define GS_FLAG_CLAMP_IMAGE 4u   /* gs_rasterize_forward also writes min(image, 1) (model.cpp:222);  \
                                     gs_rasterize_backward masks v_out where the raw image > 1     */
 
+#define GS_FLAG_KEEP_RECORDS 8u    /* gs_rasterize_backward: leave the gradients in the 64-byte       \
+                                     records of its workspace (v_xy / v_conic / v_colors / v_opacity \
+                                     may be NULL); gs_gaussian_backward consumes them               */
+#define GS_FLAG_RECORDS_ZEROED 16u /* gs_rasterize_backward: the record workspace is already zero     \
+                                     (gs_gaussian_backward leaves it so): skip the memset           */
+
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
 int gs_version(void);                /* 10000*major + 100*minor + patch */
@@ -254,6 +260,41 @@ int gs_debug_time_next_kernel(void *event_start, void *event_stop);
 /* Test hook: the nine-value wave reduction of the backward kernel.
  *   in [blocks, 9, 64] (value i of lane l at in[b][i][l])  ->  out[blocks, 9] = sums over lanes. */
 int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-Gaussian stages (second step).  The three per-Gaussian forward
+ * stages — gs_project_forward, gs_sh_forward_fused, gs_pack_splats — and the three backward ones —
+ * the record split of gs_rasterize_backward, gs_sh_backward_fused, gs_project_backward — each as
+ * ONE kernel: the 2-D intermediates (xys, conics, cov2d, colours; v_xy, v_conic, v_colors) never
+ * touch HBM.  Same device functions as the stage kernels (gs_gaussian.h), so the results are the
+ * same bits.  Model::forward's glue is always fused here: `scales` obeys GsCamera.flags
+ * (GS_CAM_LOG_SCALES), `opacities` obeys GS_FLAG_LOGIT_OPACITY, colours are max(SH + 0.5, 0).
+ *
+ * gs_gaussian_forward
+ *   in : means[N,3] scales[N,3] quats[N,4] opacities[N] features_dc[N,3] features_rest[N,K-1,3]
+ *        (NULL for K = 1), cam_pos[3] (host or device), degrees_to_use
+ *   out: packed[N,12] (the record gs_bin_* / gs_rasterize_* consume), depths[N], radii[N],
+ *        rgb_raw[N,3] (SH colour before +0.5 / clamp: the backward's clamp mask),
+ *        xys[N,2] (optional, NULL to skip: Model::afterTrain only needs its gradient)
+ * gs_gaussian_backward
+ *   in : the same parameters, radii, rgb_raw, and `records` = the workspace gs_rasterize_backward
+ *        filled under GS_FLAG_KEEP_RECORDS
+ *   out: v_means[N,3] v_scales[N,3] v_quats[N,4] v_opacity[N] v_dc[N,3] v_rest[N,K-1,3],
+ *        v_xy[N,2] (optional: d loss / d xys for the densification statistics);
+ *        the records are zeroed behind the read (=> GS_FLAG_RECORDS_ZEROED next frame). */
+int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev, const float *projmat_dev,
+                        int N, int K, int degrees_to_use, const float *means, const float *scales,
+                        const float *quats, const float *opacities, const float *features_dc,
+                        const float *features_rest, const float *cam_pos, float *packed,
+                        float *depths, int32_t *radii, float *rgb_raw, float *xys, uint32_t flags,
+                        gs_stream_t stream);
+int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_dev, const float *projmat_dev,
+                         int N, int K, int degrees_to_use, const float *means, const float *scales,
+                         const float *quats, const float *opacities, const float *cam_pos,
+                         const int32_t *radii, const float *rgb_raw, void *records,
+                         size_t records_bytes, float *v_means, float *v_scales, float *v_quats,
+                         float *v_opacity, float *v_dc, float *v_rest, float *v_xy, uint32_t flags,
+                         gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,8 +18,8 @@ ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["gs_api.hip", "gs_project.hip", "gs_sh.hip", "gs_bin.hip", "gs_raster.hip",
-               "gs_loss.hip", "gs_adam.hip", "gs_densify.hip"]
-HIP_HEADERS = ["gs_device.h", os.path.join(INCLUDE, "gsplat_hip.h"),
+               "gs_loss.hip", "gs_adam.hip", "gs_densify.hip", "gs_fused.hip"]
+HIP_HEADERS = ["gs_device.h", "gs_gaussian.h", os.path.join(INCLUDE, "gsplat_hip.h"),
                os.path.join(INCLUDE, "gsplat_train.h"), os.path.join(INCLUDE, "gsplat_densify.h")]
 HIP_LIB = os.path.join(CSRC, "libgsplat_hip.so")
 TORCH_LIB = os.path.join(CSRC, "libgsplat_torch.so")

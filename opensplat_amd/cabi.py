@@ -20,6 +20,8 @@ GS_SPLAT_DWORDS = 12
 GS_FLAG_FAST_EXP = 1
 GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
+GS_FLAG_KEEP_RECORDS = 8
+GS_FLAG_RECORDS_ZEROED = 16
 GS_CAM_LOG_SCALES = 1
 
 # every symbol include/gsplat_hip.h declares (tests check they are all exported)
@@ -27,7 +29,7 @@ SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
-    "gs_debug_reduce9", "gs_debug_time_next_kernel",
+    "gs_debug_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
@@ -197,26 +199,31 @@ GS_ERR_CAPACITY = -5
 
 
 def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
-                 workspace: BinWorkspace | None = None, flags=0, speculative=False) -> Binned:
+                 workspace: BinWorkspace | None = None, flags=0, speculative=False,
+                 packed=None) -> Binned:
     """pack -> count + scan -> scatter + per-tile sort.
 
     Default: gs_bin_and_sort (one stream sync to read the intersection count M, like the
     reference).  speculative=True: the id buffer keeps the capacity of earlier calls and NOTHING
     synchronises; the caller enqueues the forward kernel and then calls validate_binning(), which
-    drains the stream and tells whether M fitted (if not: call again — the buffers have grown)."""
+    drains the stream and tells whether M fitted (if not: call again — the buffers have grown).
+    packed: records already built by gaussian_forward (xys .. cov2d are then ignored)."""
     l = lib()
-    N = xys.shape[0]
-    dev = xys.device
+    N = depths.shape[0]
+    dev = depths.device
     w = workspace or BinWorkspace()
-    packed = w.get("packed", (N, GS_SPLAT_DWORDS), torch.float32, dev)
+    have_packed = packed is not None
+    if not have_packed:
+        packed = w.get("packed", (N, GS_SPLAT_DWORDS), torch.float32, dev)
     tiles_hit = w.get("tiles_hit", (N,), torch.int32, dev)
     tiles = ((W + GS_TILE - 1) // GS_TILE) * ((H + GS_TILE - 1) // GS_TILE)
     tile_bins = w.get("tile_bins", (tiles, 2), torch.int32, dev)
     # tiles by descending list length: the compositing launches start with the long lists
     tile_order = w.get("tile_order", (tiles,), torch.int32, dev)
-    _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
-                            _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
-                            C.c_uint32(flags), _stream()), "gs_pack_splats")
+    if not have_packed:
+        _check(l.gs_pack_splats(C.c_int(W), C.c_int(H), C.c_int(N), _p(xys), _p(radii), _p(conics),
+                                _p(colors), _p(opacities), _p(cov2d), _p(packed), _p(tiles_hit),
+                                C.c_uint32(flags), _stream()), "gs_pack_splats")
     m_host = w.m_host if w.m_host is not None else torch.zeros(2, dtype=torch.int32).pin_memory()
     while True:
         cap = max(w.capacity, 1024)
@@ -288,7 +295,10 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
 def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx, v_out, flags=0,
                        v_out_alpha=None, out=None, workspace=None, img_raw=None):
     dev = binned.packed.device
-    if out is None:
+    if flags & GS_FLAG_KEEP_RECORDS:   # gradients stay in the workspace records (gaussian_backward)
+        out = dict(v_xy=None, v_conic=None, v_colors=None, v_opacity=None)
+        assert workspace is not None
+    elif out is None:
         out = dict(v_xy=torch.empty((N, 2), device=dev), v_conic=torch.empty((N, 3), device=dev),
                    v_colors=torch.empty((N, 3), device=dev), v_opacity=torch.empty((N,), device=dev))
     ws_bytes = lib().gs_rasterize_backward_workspace_bytes(N)
@@ -514,3 +524,44 @@ def reset_opacity(opacity_logits, reset_value=0.2, exp_avg=None, exp_avg_sq=None
     _check(lib().gs_reset_opacity(C.c_int(opacity_logits.numel()), C.c_float(reset_value),
                                   _p(opacity_logits), _p(exp_avg), _p(exp_avg_sq), _stream()),
            "gs_reset_opacity")
+
+
+# ---------------------------------------------------------------------------------------------
+# Fused per-Gaussian stages (include/gsplat_hip.h): projection + SH + pack / their backwards
+
+def gaussian_forward(cam: GsCamera, means, scales, quats, opacities, features_dc, features_rest,
+                     cam_pos, degrees_to_use, flags=0, out=None, want_xys=False, viewmat_dev=None,
+                     projmat_dev=None):
+    """-> dict(packed [N,12], depths, radii, rgb_raw, xys or None)."""
+    N, dev = means.shape[0], means.device
+    K = 1 + (features_rest.shape[1] if features_rest is not None and features_rest.numel() > 0 else 0)
+    f = dict(device=dev, dtype=torch.float32)
+    if out is None:
+        out = dict(packed=torch.empty((N, GS_SPLAT_DWORDS), **f), depths=torch.empty((N,), **f),
+                   radii=torch.empty((N,), device=dev, dtype=torch.int32),
+                   rgb_raw=torch.empty((N, 3), **f), xys=torch.empty((N, 2), **f) if want_xys else None)
+    _check(lib().gs_gaussian_forward(C.byref(cam), _p(viewmat_dev), _p(projmat_dev), C.c_int(N),
+                                     C.c_int(K), C.c_int(degrees_to_use), _p(means), _p(scales),
+                                     _p(quats), _p(opacities), _p(features_dc),
+                                     _p(features_rest) if K > 1 else C.c_void_p(0), _vec3(cam_pos),
+                                     _p(out["packed"]), _p(out["depths"]), _p(out["radii"]),
+                                     _p(out["rgb_raw"]), _p(out.get("xys")), C.c_uint32(flags),
+                                     _stream()), "gs_gaussian_forward")
+    return out
+
+
+def gaussian_backward(cam: GsCamera, means, scales, quats, opacities, cam_pos, K, degrees_to_use,
+                      radii, rgb_raw, records, out, flags=0, v_xy=None, viewmat_dev=None,
+                      projmat_dev=None):
+    """records: the uint8 workspace rasterize_backward filled under GS_FLAG_KEEP_RECORDS (left
+    zeroed).  out: dict(v_means, v_scales, v_quats, v_opacity, v_dc, v_rest)."""
+    N = means.shape[0]
+    _check(lib().gs_gaussian_backward(C.byref(cam), _p(viewmat_dev), _p(projmat_dev), C.c_int(N),
+                                      C.c_int(K), C.c_int(degrees_to_use), _p(means), _p(scales),
+                                      _p(quats), _p(opacities), _vec3(cam_pos), _p(radii), _p(rgb_raw),
+                                      _p(records), C.c_size_t(records.numel() * records.element_size()),
+                                      _p(out["v_means"]), _p(out["v_scales"]), _p(out["v_quats"]),
+                                      _p(out["v_opacity"]), _p(out["v_dc"]),
+                                      _p(out["v_rest"]) if K > 1 else C.c_void_p(0), _p(v_xy),
+                                      C.c_uint32(flags), _stream()), "gs_gaussian_backward")
+    return out

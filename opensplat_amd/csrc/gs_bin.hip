@@ -30,7 +30,7 @@
 // tile_bins is [tiles, 2] (the reference allocates [M, 2], bindings.cu:324-326).
 #include <cstring>
 
-#include "gs_device.h"
+#include "gs_gaussian.h"
 
 namespace gs {
 
@@ -59,47 +59,13 @@ k_pack_splats(int W, int H, int N, const float *__restrict__ xys,
     if (n >= N) return;
     float x = xys[2 * n], y = xys[2 * n + 1];
     float A = conics[3 * n], B = conics[3 * n + 1], C = conics[3 * n + 2];
-    const float det = A * C - B * B;
-    float cxx, cyy;
-    if (cov2d) {
-        cxx = cov2d[3 * n];
-        cyy = cov2d[3 * n + 2];
-    } else {
-        // conic = cov2d^-1  ->  cov2d = conic^-1: xx = C / det, yy = A / det
-        cxx = C / det;
-        cyy = A / det;
-    }
-    PixRect r = pixel_rect(x, y, cxx, cyy, W, H);
-    float opac = opacities[n];
-    if (flags & GS_FLAG_LOGIT_OPACITY) opac = 1.0f / (1.0f + expf(-opac));  // torch::sigmoid, model.cpp:215
-    // conservative w.r.t. rounding of the log, the exp and the product opacity*exp(-sigma)
-    float smax = (opac > 0.0f) ? (logf(255.0f * opac) + 2.0e-3f) : -1.0f;
-    uint32_t binding = 1u;
-    // trust the ellipse box only for a well-conditioned, positive-definite conic
-    if (smax >= 0.0f && A > 0.0f && C > 0.0f && det > 1.0e-4f * (A * C) && det < 3.0e38f) {
-        const float k2 = 2.0f * smax / det;
-        const float hx = sqrtf(k2 * C) * 1.001f + 1.0e-3f;
-        const float hy = sqrtf(k2 * A) * 1.001f + 1.0e-3f;
-        PixRect e;
-        e.x0 = max(0, f2i_sat(ceilf(x - hx)));
-        e.x1 = min(W, f2i_sat(floorf(x + hx)) + 1);
-        e.y0 = max(0, f2i_sat(ceilf(y - hy)));
-        e.y1 = min(H, f2i_sat(floorf(y + hy)) + 1);
-        PixRect t;
-        t.x0 = max(r.x0, e.x0); t.x1 = min(r.x1, e.x1);
-        t.y0 = max(r.y0, e.y0); t.y1 = min(r.y1, e.y1);
-        binding = (t.x0 != e.x0 || t.x1 != e.x1 || t.y0 != e.y0 || t.y1 != e.y1) ? 1u : 0u;
-        r = t;
-    }
-    int tiles = (radii[n] > 0 && smax >= 0.0f) ? rect_tiles(r) : 0;
-    if (tiles == 0) r.x0 = r.x1 = r.y0 = r.y1 = 0;
-    uint32_t rx = (uint32_t)r.x0 | ((uint32_t)r.x1 << 16);
-    uint32_t ry = (uint32_t)r.y0 | ((uint32_t)r.y1 << 16);
-    smax = __uint_as_float((__float_as_uint(smax) & ~1u) | binding);
-    packed[3 * n + 0] = make_float4(x, y, A, B);
-    packed[3 * n + 1] = make_float4(C, opac, smax, __uint_as_float(rx));
-    packed[3 * n + 2] =
-        make_float4(colors[3 * n], colors[3 * n + 1], colors[3 * n + 2], __uint_as_float(ry));
+    float4 p0, p1, p2;
+    const int tiles = pack_one(W, H, x, y, A, B, C, cov2d != nullptr, cov2d ? cov2d[3 * n] : 0.0f,
+                               cov2d ? cov2d[3 * n + 2] : 0.0f, opacities[n], radii[n],
+                               colors[3 * n], colors[3 * n + 1], colors[3 * n + 2], flags, p0, p1, p2);
+    packed[3 * n + 0] = p0;
+    packed[3 * n + 1] = p1;
+    packed[3 * n + 2] = p2;
     tiles_hit[n] = tiles;
 }
 

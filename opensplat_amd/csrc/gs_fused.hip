@@ -1,0 +1,344 @@
+// gs_fused.hip — the per-Gaussian stages of the path as ONE kernel per direction
+// (gs_gaussian_forward / gs_gaussian_backward, include/gsplat_hip.h "Fused per-Gaussian stages").
+//
+// Forward  = gs_project_forward + gs_sh_forward_fused + gs_pack_splats:
+//   reads  means 12 + scales 12 + quats 16 + opacity 4 + SH 12K               (232 B at K = 16)
+//   writes packed 48 + depth 4 + radius 4 + raw rgb 12 (+ xys 8)               ( 68 B)
+//   instead of 84 + (12K + 12) + 24 read and 84 + 24 + 52 written by the three stage kernels: the
+//   2-D intermediates (xys, conics, cov2d, cov3d, colours, tile counts) stay in registers.
+// Backward = record split + gs_sh_backward_fused + gs_project_backward:
+//   reads  the 64-byte gradient record, parameters 44, radius 4, raw rgb 12    (124 B)
+//   writes v_SH 12K + v_means 12 + v_scales 12 + v_quats 16 + v_opacity 4, and zeroes the record
+//   (which replaces the next frame's memset).
+// One lane per Gaussian; the higher-band SH rows of a wave's 64 Gaussians move through an LDS slab
+// of odd row stride with coalesced 16-byte global accesses (as in gs_sh.hip).  Both kernels are
+// HBM-streaming; the arithmetic (~750 VALU per wave forward) hides under the SH traffic.
+// Device functions are shared with the stage kernels (gs_gaussian.h): identical results.
+#include "gs_gaussian.h"
+
+namespace gs {
+
+constexpr int kRec = 16;  // floats per gradient record (gs_raster.hip: kGradRec)
+
+template <int K>
+__global__ void __launch_bounds__(ShSplit<K>::kBlock)
+k_gaussian_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev,
+                   int N, int nb, const float *__restrict__ means, const float *__restrict__ scales,
+                   const float *__restrict__ quats, const float *__restrict__ opacities,
+                   const float *__restrict__ dc, const float *__restrict__ rest, float cx, float cy,
+                   float cz, const float *__restrict__ cp_dev, float4 *__restrict__ packed,
+                   float *__restrict__ depths, int32_t *__restrict__ radii,
+                   float *__restrict__ rgb_raw, float *__restrict__ xys, uint32_t flags) {
+    constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
+    load_device_matrices(cam, vm_dev, pm_dev);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    // The wave's slab of higher-band coefficients is fetched into registers FIRST (coalesced 16-byte
+    // loads, fixed trip count), the projection arithmetic of this lane's Gaussian runs while those
+    // loads are in flight, and only then do the values go through LDS to their rows.
+    constexpr int kSlabIters = (64 * ROW + 255) / 256;
+    float4 buf[kSlabIters > 0 ? kSlabIters : 1];
+    const int total = cnt * ROW;
+    if constexpr (ROW > 0) {
+        const float *src = rest + g0 * ROW;  // 16-B aligned: 64 * ROW * 4 bytes per wave
+#pragma unroll
+        for (int it = 0; it < kSlabIters; it++) {
+            const int i = (it * 64 + lane) * 4;
+            buf[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i + 3 < total) {
+                const float4_u v = *reinterpret_cast<const float4_u *>(src + i);
+                buf[it] = make_float4(v.x, v.y, v.z, v.w);
+            } else if (i < total) {   // ragged end of the last wave
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < 4 && i + k < total; k++) e[k] = src[i + k];
+                buf[it] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+    const int64_t g = g0 + min(lane, max(cnt - 1, 0));  // idle lanes shadow the last Gaussian
+    const bool active = lane < cnt;
+
+    // ---- projection (gs_project_forward) ---------------------------------------------------------
+    Proj o;
+    ProjOut po;
+    if (cnt > 0) {
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        if (cam.flags & GS_CAM_LOG_SCALES) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
+        }
+        const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
+        float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        project_one(cam, mean, scale, quat, o);
+        project_outputs(cam, o, po);
+    }
+    if constexpr (ROW > 0) {
+#pragma unroll
+        for (int it = 0; it < kSlabIters; it++) {
+            const int i = (it * 64 + lane) * 4;
+            const float e[4] = {buf[it].x, buf[it].y, buf[it].z, buf[it].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int idx = i + k;
+                if (idx < total) slab[(idx / ROW) * ROWP + (idx % ROW)] = e[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // ---- SH colour (gs_sh_forward_fused) ---------------------------------------------------------
+    float x, y, z;
+    view_dir(means, g, cx, cy, cz, x, y, z);
+    float r[25];
+    sh_basis(nb, x, y, z, r);
+    float c0 = r[0] * dc[3 * g], c1 = r[0] * dc[3 * g + 1], c2 = r[0] * dc[3 * g + 2];
+    const float *row = slab + lane * ROWP;
+#pragma unroll
+    for (int b = 1; b < K; b++) {
+        c0 += r[b] * row[3 * (b - 1) + 0];
+        c1 += r[b] * row[3 * (b - 1) + 1];
+        c2 += r[b] * row[3 * (b - 1) + 2];
+    }
+    rgb_raw[3 * g + 0] = c0;
+    rgb_raw[3 * g + 1] = c1;
+    rgb_raw[3 * g + 2] = c2;
+
+    depths[g] = o.p[2];
+    radii[g] = po.radius;
+    if (xys) {
+        xys[2 * g + 0] = po.u;
+        xys[2 * g + 1] = po.v;
+    }
+
+    // ---- packed compositing record (gs_pack_splats) -------------------------------------------------
+    float4 p0, p1, p2;
+    pack_one(cam.W, cam.H, po.u, po.v, po.conic[0], po.conic[1], po.conic[2], true, o.a, o.c,
+             opacities[g], po.radius, fmaxf(c0 + 0.5f, 0.0f), fmaxf(c1 + 0.5f, 0.0f),
+             fmaxf(c2 + 0.5f, 0.0f), flags, p0, p1, p2);
+    packed[3 * g + 0] = p0;
+    packed[3 * g + 1] = p1;
+    packed[3 * g + 2] = p2;
+}
+
+template <int K>
+__global__ void __launch_bounds__(ShSplit<K>::kBlock)
+k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev,
+                    int N, int nb, const float *__restrict__ means, const float *__restrict__ scales,
+                    const float *__restrict__ quats, const float *__restrict__ opacities, float cx,
+                    float cy, float cz, const float *__restrict__ cp_dev,
+                    const int32_t *__restrict__ radii, const float *__restrict__ rgb_raw,
+                    float4 *__restrict__ records, float *__restrict__ v_means,
+                    float *__restrict__ v_scales, float *__restrict__ v_quats,
+                    float *__restrict__ v_opacity, float *__restrict__ v_dc,
+                    float *__restrict__ v_rest, float *__restrict__ v_xy, uint32_t flags) {
+    constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
+    load_device_matrices(cam, vm_dev, pm_dev);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if (lane < cnt) {
+        const int64_t g = g0 + lane;
+        // ---- the gradient record of gs_rasterize_backward: {vx vy vA vB | vC vr vg vb | vo - - -}
+        const float4 ra = records[4 * g + 0], rb = records[4 * g + 1];
+        float vo = reinterpret_cast<const float *>(records)[kRec * (size_t)g + 8];
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        records[4 * g + 0] = zero;  // next frame's accumulation starts from zero: no memset
+        records[4 * g + 1] = zero;
+        records[4 * g + 2] = zero;
+        if (flags & GS_FLAG_LOGIT_OPACITY) {  // d sigmoid: s (1 - s), model.cpp:215
+            const float sg = 1.0f / (1.0f + expf(-opacities[g]));
+            vo *= sg * (1.0f - sg);
+        }
+        v_opacity[g] = vo;
+        if (v_xy) {
+            v_xy[2 * g + 0] = ra.x;
+            v_xy[2 * g + 1] = ra.y;
+        }
+
+        // ---- SH backward (gs_sh_backward_fused) ------------------------------------------------------
+        float x, y, z;
+        view_dir(means, g, cx, cy, cz, x, y, z);
+        float r[25];
+        sh_basis(nb, x, y, z, r);
+        const float v0 = (rgb_raw[3 * g + 0] + 0.5f >= 0.0f) ? rb.y : 0.0f;
+        const float v1 = (rgb_raw[3 * g + 1] + 0.5f >= 0.0f) ? rb.z : 0.0f;
+        const float v2 = (rgb_raw[3 * g + 2] + 0.5f >= 0.0f) ? rb.w : 0.0f;
+        v_dc[3 * g + 0] = r[0] * v0;
+        v_dc[3 * g + 1] = r[0] * v1;
+        v_dc[3 * g + 2] = r[0] * v2;
+        float *row = slab + lane * ROWP;
+#pragma unroll
+        for (int b = 1; b < K; b++) {
+            row[3 * (b - 1) + 0] = r[b] * v0;
+            row[3 * (b - 1) + 1] = r[b] * v1;
+            row[3 * (b - 1) + 2] = r[b] * v2;
+        }
+
+        // ---- projection backward (gs_project_backward) -----------------------------------------------
+        float4_u *vq4 = reinterpret_cast<float4_u *>(v_quats);
+        if (radii[g] <= 0) {  // culled Gaussians get no gradient (backward.cu:380-382)
+            v_means[3 * g] = v_means[3 * g + 1] = v_means[3 * g + 2] = 0.0f;
+            v_scales[3 * g] = v_scales[3 * g + 1] = v_scales[3 * g + 2] = 0.0f;
+            vq4[g] = (float4_u)(0.0f);
+        } else {
+            float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+            float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+            if (cam.flags & GS_CAM_LOG_SCALES) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
+            }
+            const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
+            float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+            Proj o;
+            project_one(cam, mean, scale, quat, o);
+            ProjGrad pg;
+            project_backward_one(cam, o, scale, ra.x, ra.y, ra.z, ra.w, rb.x, 0.0f, pg);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                v_means[3 * g + j] = pg.v_mean[j];
+                v_scales[3 * g + j] = pg.v_scale[j];
+            }
+            float4_u vq;
+            vq.x = pg.v_quat[0]; vq.y = pg.v_quat[1]; vq.z = pg.v_quat[2]; vq.w = pg.v_quat[3];
+            vq4[g] = vq;
+        }
+    }
+    __syncthreads();
+    if constexpr (ROW > 0) {
+        float *dst = v_rest + g0 * ROW;
+        const int total = cnt * ROW;
+        for (int i = lane * 4; i < total; i += 64 * 4) {
+            if (i + 3 < total) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int idx = i + k;
+                    e[k] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+                }
+                float4_u v;
+                v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
+                *reinterpret_cast<float4_u *>(dst + i) = v;
+            } else {
+                for (int idx = i; idx < total; idx++) dst[idx] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_gaussian_forward(const CamArgs &cam, const float *vm_dev, const float *pm_dev, int N,
+                                   int nb, const float *means, const float *scales,
+                                   const float *quats, const float *opacities, const float *dc,
+                                   const float *rest, const float *cp, float *packed, float *depths,
+                                   int32_t *radii, float *rgb_raw, float *xys, uint32_t flags,
+                                   hipStream_t s) {
+    constexpr int BLK = ShSplit<K>::kBlock;
+    const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    const bool dev = on_device(cp);
+    hipLaunchKernelGGL(k_gaussian_forward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
+                       pm_dev, N, nb, means, scales, quats, opacities, dc, rest, dev ? 0.f : cp[0],
+                       dev ? 0.f : cp[1], dev ? 0.f : cp[2], dev ? cp : nullptr,
+                       reinterpret_cast<float4 *>(packed), depths, radii, rgb_raw, xys, flags);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+template <int K>
+static int launch_gaussian_backward(const CamArgs &cam, const float *vm_dev, const float *pm_dev, int N,
+                                    int nb, const float *means, const float *scales,
+                                    const float *quats, const float *opacities, const float *cp,
+                                    const int32_t *radii, const float *rgb_raw, void *records,
+                                    float *v_means, float *v_scales, float *v_quats, float *v_opacity,
+                                    float *v_dc, float *v_rest, float *v_xy, uint32_t flags,
+                                    hipStream_t s) {
+    constexpr int BLK = ShSplit<K>::kBlock;
+    const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    const bool dev = on_device(cp);
+    hipLaunchKernelGGL(k_gaussian_backward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
+                       pm_dev, N, nb, means, scales, quats, opacities, dev ? 0.f : cp[0],
+                       dev ? 0.f : cp[1], dev ? 0.f : cp[2], dev ? cp : nullptr, radii, rgb_raw,
+                       reinterpret_cast<float4 *>(records), v_means, v_scales, v_quats, v_opacity, v_dc,
+                       v_rest, v_xy, flags);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+}  // namespace gs
+
+extern "C" int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev,
+                                   const float *projmat_dev, int N, int K, int degrees_to_use,
+                                   const float *means, const float *scales, const float *quats,
+                                   const float *opacities, const float *features_dc,
+                                   const float *features_rest, const float *cam_pos, float *packed,
+                                   float *depths, int32_t *radii, float *rgb_raw, float *xys,
+                                   uint32_t flags, gs_stream_t stream) {
+    const int deg = gs::deg_from_bases(K);
+    if (!cam || N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg)
+        return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!means || !scales || !quats || !opacities || !features_dc || (K > 1 && !features_rest) ||
+        !cam_pos || !packed || !depths || !radii || !rgb_raw)
+        return GS_ERR_INVALID_ARGUMENT;
+    if (cam->img_width <= 0 || cam->img_height <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (cam->img_width > 65535 || cam->img_height > 65535) return GS_ERR_UNSUPPORTED;
+    if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;  // the record is three aligned float4s
+    // (quats / features_rest may be slices of a flat parameter buffer: 4-byte alignment suffices)
+    const gs::CamArgs a = gs::make_cam(cam);
+    const int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+#define GS_FWD(KK)                                                                                    \
+    return gs::launch_gaussian_forward<KK>(a, viewmat_dev, projmat_dev, N, nb, means, scales, quats,  \
+                                           opacities, features_dc, features_rest, cam_pos, packed,    \
+                                           depths, radii, rgb_raw, xys, flags, s)
+    switch (K) {
+    case 1: GS_FWD(1);
+    case 4: GS_FWD(4);
+    case 9: GS_FWD(9);
+    case 16: GS_FWD(16);
+    default: GS_FWD(25);
+    }
+#undef GS_FWD
+}
+
+extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_dev,
+                                    const float *projmat_dev, int N, int K, int degrees_to_use,
+                                    const float *means, const float *scales, const float *quats,
+                                    const float *opacities, const float *cam_pos,
+                                    const int32_t *radii, const float *rgb_raw, void *records,
+                                    size_t records_bytes, float *v_means, float *v_scales,
+                                    float *v_quats, float *v_opacity, float *v_dc, float *v_rest,
+                                    float *v_xy, uint32_t flags, gs_stream_t stream) {
+    const int deg = gs::deg_from_bases(K);
+    if (!cam || N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg)
+        return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!means || !scales || !quats || !opacities || !cam_pos || !radii || !rgb_raw || !records ||
+        !v_means || !v_scales || !v_quats || !v_opacity || !v_dc || (K > 1 && !v_rest))
+        return GS_ERR_INVALID_ARGUMENT;
+    if (records_bytes < (size_t)N * gs::kRec * sizeof(float)) return GS_ERR_WORKSPACE;
+    if ((uintptr_t)records & 63u) return GS_ERR_INVALID_ARGUMENT;
+    const gs::CamArgs a = gs::make_cam(cam);
+    const int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+#define GS_BWD(KK)                                                                                    \
+    return gs::launch_gaussian_backward<KK>(a, viewmat_dev, projmat_dev, N, nb, means, scales, quats, \
+                                            opacities, cam_pos, radii, rgb_raw, records, v_means,     \
+                                            v_scales, v_quats, v_opacity, v_dc, v_rest, v_xy, flags, s)
+    switch (K) {
+    case 1: GS_BWD(1);
+    case 4: GS_BWD(4);
+    case 9: GS_BWD(9);
+    case 16: GS_BWD(16);
+    default: GS_BWD(25);
+    }
+#undef GS_BWD
+}

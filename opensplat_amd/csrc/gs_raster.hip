@@ -783,9 +783,10 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     const float *img_raw = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img : nullptr;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0) return GS_OK;
-    if (!tile_bins || !background || !final_Ts || !final_idx || !v_out || !v_xy || !v_conic ||
-        !v_colors || !v_opacity || !workspace)
+    const bool keep_records = (flags & GS_FLAG_KEEP_RECORDS) != 0u;
+    if (!tile_bins || !background || !final_Ts || !final_idx || !v_out || !workspace)
         return GS_ERR_INVALID_ARGUMENT;
+    if (!keep_records && (!v_xy || !v_conic || !v_colors || !v_opacity)) return GS_ERR_INVALID_ARGUMENT;
     if (((uintptr_t)packed & 15u) || ((uintptr_t)workspace & 63u)) return GS_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < gs_rasterize_backward_workspace_bytes(N)) return GS_ERR_WORKSPACE;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
@@ -794,7 +795,8 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     float *gacc = static_cast<float *>(workspace);
-    GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
+    if (!(flags & GS_FLAG_RECORDS_ZEROED))
+        GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
     int units;
     const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentBackward, list_stats, tile_order, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
@@ -811,6 +813,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                            img_raw, gacc);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
+    if (keep_records) return GS_OK;  // the 64-byte records go straight to gs_gaussian_backward
     hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
                        reinterpret_cast<const float4 *>(gacc),
                        (flags & GS_FLAG_LOGIT_OPACITY) ? pk : nullptr, v_xy, v_conic, v_colors,

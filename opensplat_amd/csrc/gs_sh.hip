@@ -10,53 +10,10 @@
 // by 12K bytes.  Instead each wave moves its 64 Gaussians' coefficients as one contiguous
 // 64*12K-byte slab with fully coalesced 16-byte loads through LDS (rows padded by one dword so
 // the per-lane row walk is bank-conflict free), then each lane reduces its own row.
-#include "gs_device.h"
+#include "gs_gaussian.h"
 
 namespace gs {
 
-__device__ __forceinline__ void sh_basis(int nb, float x, float y, float z, float *r) {
-    // gsplat_cpu.cpp:436-483; r[] has 25 slots, entries >= nb stay 0
-#pragma unroll
-    for (int i = 0; i < 25; i++) r[i] = 0.0f;
-    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-    r[0] = C0;
-    if (nb <= 1) return;
-    r[1] = C1 * -y;
-    r[2] = C1 * z;
-    r[3] = C1 * -x;
-    if (nb <= 4) return;
-    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    r[4] = 1.0925484305920792f * xy;
-    r[5] = -1.0925484305920792f * yz;
-    r[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
-    r[7] = -1.0925484305920792f * xz;
-    r[8] = 0.5462742152960396f * (xx - yy);
-    if (nb <= 9) return;
-    r[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
-    r[10] = 2.890611442640554f * xy * z;
-    r[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
-    r[12] = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-    r[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
-    r[14] = 1.445305721320277f * z * (xx - yy);
-    r[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
-    if (nb <= 16) return;
-    r[16] = 2.5033429417967046f * xy * (xx - yy);
-    r[17] = -1.7701307697799304f * yz * (3.0f * xx - yy);
-    r[18] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
-    r[19] = -0.6690465435572892f * yz * (7.0f * zz - 3.0f);
-    r[20] = 0.10578554691520431f * (zz * (35.0f * zz - 30.0f) + 3.0f);
-    r[21] = -0.6690465435572892f * xz * (7.0f * zz - 3.0f);
-    r[22] = 0.47308734787878004f * (xx - yy) * (7.0f * zz - 1.0f);
-    r[23] = -1.7701307697799304f * xz * (xx - 3.0f * yy);
-    r[24] = 0.6258357354491761f * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
-}
-
-__host__ __device__ inline int num_bases(int degree) {  // gsplat_cpu.cpp:409-422
-    return degree == 0 ? 1 : degree == 1 ? 4 : degree == 2 ? 9 : degree == 3 ? 16 : 25;
-}
-
-// 4 waves per block (2 for K = 25 so the padded slabs stay under 64 KiB of dynamic LDS);
-// each wave owns 64 consecutive Gaussians.
 template <int K>
 struct ShCfg {
     static constexpr int kBlock = (K > 16) ? 128 : 256;
@@ -214,22 +171,6 @@ static int launch_bwd(int N, int nb, const float *dirs, const float *v_colors, f
 // clamp_min(rgb + 0.5, 0) (model.cpp:192) plus the raw rgb the backward needs for the clamp mask.
 // Layout trick as in k_sh_forward: a wave moves the 64 * 12(K-1)-byte slab of its 64 Gaussians'
 // higher-band coefficients with coalesced 16-byte loads through LDS rows of odd stride.
-template <int K>
-struct ShSplit {
-    static constexpr int ROW = 3 * (K - 1);
-    static constexpr int ROWP = (ROW == 0) ? 1 : (ROW | 1);
-    static constexpr int kBlock = (K > 16) ? 128 : 256;
-};
-
-__device__ __forceinline__ void view_dir(const float *__restrict__ means, int64_t g, float cx,
-                                         float cy, float cz, float &x, float &y, float &z) {
-    // (means - T) / ||means - T||, model.cpp:176-177 (torch::norm, no epsilon)
-    x = means[3 * g] - cx;
-    y = means[3 * g + 1] - cy;
-    z = means[3 * g + 2] - cz;
-    const float n = sqrtf(x * x + y * y + z * z);
-    x /= n; y /= n; z /= n;
-}
 
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
@@ -339,7 +280,6 @@ k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, fl
 // K = 16 fused forward, four lanes per Gaussian (see k_sh_forward16_quad): lane q combines the
 // coefficients c = 12q .. 12q+11 of the virtual [dc | rest] row.  Rows of features_rest are 180 bytes,
 // so the 16-byte loads are only 4-byte aligned — gfx950 global loads allow that.
-typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 __global__ void __launch_bounds__(256)
 k_sh_forward_fused16_quad(int N, int nb, const float *__restrict__ means, float cx, float cy,
@@ -412,16 +352,6 @@ static int launch_bwd_fused(int N, int nb, const float *means, const float *cp, 
     return GS_OK;
 }
 
-static int deg_from_bases(int K) {  // spherical_harmonics.cpp:3-16, but strict
-    switch (K) {
-    case 1: return 0;
-    case 4: return 1;
-    case 9: return 2;
-    case 16: return 3;
-    case 25: return 4;
-    default: return -1;
-    }
-}
 
 }  // namespace gs
 

@@ -87,26 +87,27 @@ class Trainer:
         N, dev = self.N, self.dev
         f = dict(device=dev, dtype=torch.float32)
         i = dict(device=dev, dtype=torch.int32)
-        self.proj = dict(xys=torch.empty((N, 2), **f), depths=torch.empty((N,), **f),
-                         radii=torch.empty((N,), **i), conics=torch.empty((N, 3), **f),
-                         num_tiles_hit=torch.empty((N,), **i), cov3d=torch.empty((N, 6), **f),
-                         cov2d=torch.empty((N, 3), **f))
-        self.sh_out = (torch.empty((N, 3), **f), torch.empty((N, 3), **f))
+        # per-Gaussian outputs of gs_gaussian_forward (the 2-D intermediates stay in registers)
+        self.proj = dict(packed=torch.empty((N, cabi.GS_SPLAT_DWORDS), **f), depths=torch.empty((N,), **f),
+                         radii=torch.empty((N,), **i), rgb_raw=torch.empty((N, 3), **f), xys=None)
         self.bin_ws = cabi.BinWorkspace()
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i), img_clamped=torch.empty((H, W, 3), **f))
-        self.bwd_ws = torch.empty((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
+        # gradient records of the compositing backward; gs_gaussian_backward leaves them zeroed
+        self.bwd_ws = torch.zeros((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
                                   device=dev, dtype=torch.uint8)
-        self.g2d = torch.zeros(N * 8, **f)
-        self.rgrads = dict(v_xy=self.g2d[: 2 * N].view(N, 2), v_conic=self.g2d[2 * N: 5 * N].view(N, 3),
-                           v_colors=self.g2d[5 * N: 8 * N].view(N, 3), v_opacity=self.grads.v_opacity)
+        self.v_xy = torch.zeros((N, 2), **f)     # d loss / d xys: the densification statistics' input
+        self.rgrads = dict(v_xy=self.v_xy)
+        self.gout = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
+                         v_quats=self.grads.v_quats, v_opacity=self.grads.v_opacity,
+                         v_dc=self.grads.v_dc, v_rest=self.grads.v_rest)
         self.loss_ws = torch.empty(cabi.lib().gs_loss_workspace_bytes(W, H), device=dev,
                                    dtype=torch.uint8)
         self.loss_out = (torch.empty(3, **f), torch.empty((H, W, 3), **f))
         self._shape = (W, H)
 
     def render(self, cam: dict, background, degrees_to_use: int):
-        """Model::forward (model.cpp:83-225) for one camera -> (clamped rgb [H,W,3], binned, raw)."""
+        """Model::forward (model.cpp:83-225) for one camera -> clamped rgb [H, W, 3]."""
         W, H = cam["W"], cam["H"]
         self._buffers(W, H)
         gcam = cabi.make_camera(cam["viewmat"], cam["projmat"], cam["fx"], cam["fy"], cam["cx"],
@@ -115,33 +116,28 @@ class Trainer:
         cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)   # model.cpp:95
         flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
         while True:
-            p = cabi.project_forward(gcam, self.means, self.log_scales, self.quats, out=self.proj)
-            colors, rgb_raw = cabi.sh_forward_fused(degrees_to_use, self.means, cam_pos,
-                                                    self.features_dc,
-                                                    self.features_rest if self.K > 1 else None,
-                                                    out=self.sh_out)
-            b = cabi.bin_and_sort(W, H, p["xys"], p["depths"], p["radii"], p["conics"], colors,
-                                  self.opacity_logits, p["cov2d"], self.bin_ws, flags=flags,
-                                  speculative=True)
+            p = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats,
+                                      self.opacity_logits, self.features_dc,
+                                      self.features_rest if self.K > 1 else None, cam_pos,
+                                      degrees_to_use, flags, out=self.proj)
+            b = cabi.bin_and_sort(W, H, None, p["depths"], None, None, None, None, None, self.bin_ws,
+                                  speculative=True, packed=p["packed"])
             f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
-        self._ctx = (gcam, cam_pos, p, rgb_raw, b, f, flags, degrees_to_use, background, W, H)
+        self._ctx = (gcam, cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
         return f["img_clamped"]
 
     def backward(self, v_rgb):
         """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
-        g = cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"],
-                                    v_rgb, flags, out=self.rgrads, workspace=self.bwd_ws,
-                                    img_raw=f["img"])
-        cabi.sh_backward_fused(deg, self.K, self.means, cam_pos, rgb_raw, g["v_colors"],
-                               out=(self.grads.v_dc, self.grads.v_rest if self.K > 1 else None))
-        w1 = dist.allreduce_sh_async(self.grads)      # overlaps the projection backward
-        cabi.project_backward(gcam, self.means, self.log_scales, self.quats, p["radii"], g["v_xy"],
-                              g["v_conic"], None,
-                              out=dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
-                                       v_quats=self.grads.v_quats))
+        keep = cabi.GS_FLAG_KEEP_RECORDS | cabi.GS_FLAG_RECORDS_ZEROED
+        cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
+                                flags | keep, workspace=self.bwd_ws, img_raw=f["img"])
+        cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
+                               cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws, self.gout, flags,
+                               v_xy=self.v_xy)
+        w1 = dist.allreduce_sh_async(self.grads)
         w2 = dist.allreduce_rest_async(self.grads)
         dist.wait_all(w1, w2)
 

@@ -134,3 +134,100 @@ def test_log_scale_projection_equals_exp_then_project():
     assert rel_err(np_(gb["v_means"]), np_(ga["v_means"])) < 1e-4
     assert rel_err(np_(gb["v_quats"]), np_(ga["v_quats"])) < 1e-4
     assert rel_err(np_(gb["v_scales"]), np_(ga["v_scales"] * torch.exp(ls))) < 1e-4
+
+
+# ---- fused per-Gaussian stages (gs_gaussian_forward / gs_gaussian_backward) ----------------------
+
+@pytest.mark.parametrize("K,deg,N", [(16, 3, 5000), (4, 1, 3001), (1, 0, 777), (9, 2, 64), (25, 4, 1500)])
+def test_gaussian_forward_backward_equal_the_stage_kernels(K, deg, N):
+    """One kernel per direction vs the three stage kernels it replaces, same flags: the device
+    functions are shared (gs_gaussian.h), so the packed records, depths, radii, raw colours and all
+    six gradient tensors must be the same bits."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(N, 320, 200, K=K, seed=91, znear=1.0, zfar=100.0, yaw_deg=2.0,
+                            degrees_to_use=deg)
+    s.sh_coeffs[:, 0, :] += 0.7
+    s.means[::7, 2] = -1.0                      # behind the camera: culled
+    raw = _raw_params(s)
+    means, ls, q, lo = to_dev(s.means), to_dev(raw[0]), to_dev(raw[1]), to_dev(raw[2].reshape(-1))
+    dc, rest = to_dev(raw[3]), (to_dev(raw[4]) if K > 1 else None)
+    cam = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H,
+                           flags=cabi.GS_CAM_LOG_SCALES)
+    cam_pos = raw[5]
+    flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
+    # stage kernels
+    p = cabi.project_forward(cam, means, ls, q)
+    colors, rgb_raw = cabi.sh_forward_fused(deg, means, cam_pos, dc, rest)
+    b = cabi.bin_and_sort(s.W, s.H, p["xys"], p["depths"], p["radii"], p["conics"], colors, lo,
+                          p["cov2d"], flags=flags)
+    # fused
+    g = cabi.gaussian_forward(cam, means, ls, q, lo, dc, rest, cam_pos, deg, flags, want_xys=True)
+    torch.cuda.synchronize()
+    if K == 16:   # the K = 16 stage kernel sums the SH bands four lanes wide: colours differ in the last bits
+        keep = [0, 1, 2, 3, 4, 5, 6, 7, 11]
+        assert torch.equal(g["packed"][:, keep], b.packed[:, keep])
+        assert (g["packed"][:, 8:11] - b.packed[:, 8:11]).abs().max().item() < 2e-6
+        assert (g["rgb_raw"] - rgb_raw).abs().max().item() < 2e-6
+        rgb_raw = g["rgb_raw"]          # same clamp mask on both backward paths below
+        b.packed = g["packed"]
+    else:
+        assert torch.equal(g["packed"], b.packed)
+        assert torch.equal(g["rgb_raw"], rgb_raw)
+    assert torch.equal(g["depths"], p["depths"]) and torch.equal(g["radii"], p["radii"])
+    assert torch.equal(g["xys"], p["xys"])
+    assert (g["radii"] == 0).sum() > 0
+    b2 = cabi.bin_and_sort(s.W, s.H, None, g["depths"], None, None, None, None, packed=g["packed"])
+    assert torch.equal(b2.gaussian_ids_sorted, b.gaussian_ids_sorted) and torch.equal(b2.tile_bins, b.tile_bins)
+
+    f = cabi.rasterize_forward(s.W, s.H, b, s.background, flags,
+                               out=dict(img=torch.empty((s.H, s.W, 3), device="cuda"),
+                                        final_Ts=torch.empty((s.H, s.W), device="cuda"),
+                                        final_idx=torch.empty((s.H, s.W), device="cuda", dtype=torch.int32),
+                                        img_clamped=torch.empty((s.H, s.W, 3), device="cuda")))
+    v_out = to_dev(np.random.RandomState(4).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32))
+    ws = torch.zeros(cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64, device="cuda", dtype=torch.uint8)
+    # stage path
+    gr = cabi.rasterize_backward(s.W, s.H, N, b, s.background, f["final_Ts"], f["final_idx"], v_out,
+                                 flags, workspace=ws, img_raw=f["img"])
+    v_dc, v_rest = cabi.sh_backward_fused(deg, K, means, cam_pos, rgb_raw, gr["v_colors"])
+    pb = cabi.project_backward(cam, means, ls, q, p["radii"], gr["v_xy"], gr["v_conic"])
+    # fused path: records kept, consumed and zeroed by gaussian_backward
+    ws2 = torch.zeros_like(ws)
+    cabi.rasterize_backward(s.W, s.H, N, b, s.background, f["final_Ts"], f["final_idx"], v_out,
+                            flags | cabi.GS_FLAG_KEEP_RECORDS | cabi.GS_FLAG_RECORDS_ZEROED,
+                            workspace=ws2, img_raw=f["img"])
+    fz = dict(device="cuda", dtype=torch.float32)
+    out = dict(v_means=torch.empty((N, 3), **fz), v_scales=torch.empty((N, 3), **fz),
+               v_quats=torch.empty((N, 4), **fz), v_opacity=torch.empty((N,), **fz),
+               v_dc=torch.empty((N, 3), **fz), v_rest=torch.empty((N, max(K - 1, 1), 3), **fz))
+    v_xy = torch.empty((N, 2), **fz)
+    cabi.gaussian_backward(cam, means, ls, q, lo, cam_pos, K, deg, g["radii"], g["rgb_raw"], ws2, out,
+                           flags, v_xy=v_xy)
+    torch.cuda.synchronize()
+    # the compositing backward accumulates with atomics: two runs differ in the last bits, so the
+    # comparison is at summation-order tolerance, and exact where no atomics are involved
+    def close(a, b_, name):
+        a, b_ = np_(a), np_(b_)
+        assert rel_err(a, b_) < 2e-5, name
+    close(v_xy, gr["v_xy"], "v_xy")
+    close(out["v_opacity"], gr["v_opacity"], "v_opacity")
+    close(out["v_dc"], v_dc, "v_dc")
+    if K > 1:
+        close(out["v_rest"][:, :K - 1], v_rest, "v_rest")
+    close(out["v_means"], pb["v_means"], "v_means")
+    close(out["v_scales"], pb["v_scales"], "v_scales")
+    close(out["v_quats"], pb["v_quats"], "v_quats")
+    assert not ws2[: N * 64].any()            # records left zeroed for the next frame
+    # determinism of the non-atomic part: feed the SAME records to both consumers
+    ws3 = ws.clone()                           # records of the stage run (not zeroed by it)
+    out2 = {k: torch.empty_like(v) for k, v in out.items()}
+    cabi.gaussian_backward(cam, means, ls, q, lo, cam_pos, K, deg, g["radii"], g["rgb_raw"], ws3, out2, flags)
+    torch.cuda.synchronize()
+    assert torch.equal(out2["v_means"], pb["v_means"]) and torch.equal(out2["v_scales"], pb["v_scales"])
+    assert torch.equal(out2["v_quats"], pb["v_quats"]) and torch.equal(out2["v_dc"], v_dc)
+    assert torch.equal(out2["v_opacity"], gr["v_opacity"])
+    if K > 1:
+        assert torch.equal(out2["v_rest"][:, :K - 1], v_rest)
