@@ -121,7 +121,7 @@ class Pipeline:
                                 "gaussian_bwd", "allreduce"]
             self.gfwd = dict(packed=torch.empty((N, 12), **f), depths=self.proj["depths"],
                              radii=self.proj["radii"], rgb_raw=self.sh_out[1], xys=None)
-            self.bwd_ws.zero_()   # the fused backward leaves the records zeroed (no memset per step)
+            self.bwd_ws.zero_()
             self.gout = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
                              v_quats=self.grads.v_quats, v_opacity=self.grads.v_opacity,
                              v_dc=self.grads.v_dc, v_rest=self.grads.v_rest)
@@ -200,7 +200,11 @@ class Pipeline:
     def step_fused(self, events=None, kernel_events=None):
         """Same work with gs_gaussian_forward / gs_gaussian_backward around binning + compositing."""
         torch, cabi, s = self.torch, self.cabi, self.s
-        KEEP = cabi.GS_FLAG_KEEP_RECORDS | cabi.GS_FLAG_RECORDS_ZEROED
+        # GSPLAT_RECORDS_ZEROED=1: gs_gaussian_backward zeroes the gradient records behind its read
+        # and the per-frame memset is skipped — measured SLOWER at C2 (1.27 vs 1.25 ms): the memset
+        # leaves the records in the last-level cache right before the compositing atomics arrive
+        ZEROED = cabi.GS_FLAG_RECORDS_ZEROED if os.environ.get("GSPLAT_RECORDS_ZEROED") else 0
+        KEEP = cabi.GS_FLAG_KEEP_RECORDS | ZEROED
         while True:
             ev_local = []
 
@@ -232,7 +236,7 @@ class Pipeline:
             mark()
             cabi.gaussian_backward(self.cam, self.means, self.scales, self.quats, self.opac,
                                    self.cam_pos, s.K, s.degrees_to_use, g["radii"], g["rgb_raw"],
-                                   self.bwd_ws, self.gout, 0, viewmat_dev=self.vm_dev,
+                                   self.bwd_ws, self.gout, ZEROED, viewmat_dev=self.vm_dev,
                                    projmat_dev=self.pm_dev)
             mark()
             break

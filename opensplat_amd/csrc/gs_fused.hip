@@ -8,11 +8,11 @@
 //   2-D intermediates (xys, conics, cov2d, cov3d, colours, tile counts) stay in registers.
 // Backward = record split + gs_sh_backward_fused + gs_project_backward:
 //   reads  the 64-byte gradient record, parameters 44, radius 4, raw rgb 12    (124 B)
-//   writes v_SH 12K + v_means 12 + v_scales 12 + v_quats 16 + v_opacity 4, and zeroes the record
-//   (which replaces the next frame's memset).
+//   writes v_SH 12K + v_means 12 + v_scales 12 + v_quats 16 + v_opacity 4 (and, on request,
+//   zeroes the record so that the next frame can skip its memset — slower at C2, see the header).
 // One lane per Gaussian; the higher-band SH rows of a wave's 64 Gaussians move through an LDS slab
 // of odd row stride with coalesced 16-byte global accesses (as in gs_sh.hip).  Both kernels are
-// HBM-streaming; the arithmetic (~750 VALU per wave forward) hides under the SH traffic.
+// HBM-streaming; at K = 16 the forward runs as two LDS-free kernels instead (k_project_pack).
 // Device functions are shared with the stage kernels (gs_gaussian.h): identical results.
 #include "gs_gaussian.h"
 
@@ -126,6 +126,48 @@ k_gaussian_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *_
     packed[3 * g + 2] = p2;
 }
 
+// K = 16: the SH rows are 180 bytes; one lane per Gaussian needs them in an 11.5 KB-per-wave LDS slab,
+// which caps the occupancy at three waves per SIMD and leaves the kernel above waiting on memory
+// (measured 103 us at N = 1 M).  Faster: the four-lanes-per-Gaussian SH kernel of gs_sh.hip (no
+// LDS, 3.9 TB/s) writes the raw rgb, and this LDS-free kernel does projection + packed record.
+__global__ void __launch_bounds__(256)
+k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev, int N,
+               const float *__restrict__ means, const float *__restrict__ scales,
+               const float *__restrict__ quats, const float *__restrict__ opacities,
+               const float *__restrict__ rgb_raw, float4 *__restrict__ packed,
+               float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ xys,
+               uint32_t flags) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    load_device_matrices(cam, vm_dev, pm_dev);
+    float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+    float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    if (cam.flags & GS_CAM_LOG_SCALES) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
+    }
+    const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
+    float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+    Proj o;
+    project_one(cam, mean, scale, quat, o);
+    ProjOut po;
+    project_outputs(cam, o, po);
+    depths[g] = o.p[2];
+    radii[g] = po.radius;
+    if (xys) {
+        xys[2 * g + 0] = po.u;
+        xys[2 * g + 1] = po.v;
+    }
+    const float c0 = rgb_raw[3 * g + 0], c1 = rgb_raw[3 * g + 1], c2 = rgb_raw[3 * g + 2];
+    float4 p0, p1, p2;
+    pack_one(cam.W, cam.H, po.u, po.v, po.conic[0], po.conic[1], po.conic[2], true, o.a, o.c,
+             opacities[g], po.radius, fmaxf(c0 + 0.5f, 0.0f), fmaxf(c1 + 0.5f, 0.0f),
+             fmaxf(c2 + 0.5f, 0.0f), flags, p0, p1, p2);
+    packed[3 * g + 0] = p0;
+    packed[3 * g + 1] = p1;
+    packed[3 * g + 2] = p2;
+}
+
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
 k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev,
@@ -151,9 +193,11 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         const float4 ra = records[4 * g + 0], rb = records[4 * g + 1];
         float vo = reinterpret_cast<const float *>(records)[kRec * (size_t)g + 8];
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        records[4 * g + 0] = zero;  // next frame's accumulation starts from zero: no memset
-        records[4 * g + 1] = zero;
-        records[4 * g + 2] = zero;
+        if (flags & GS_FLAG_RECORDS_ZEROED) {  // keep the "records are zero between frames" invariant
+            records[4 * g + 0] = zero;
+            records[4 * g + 1] = zero;
+            records[4 * g + 2] = zero;
+        }
         if (flags & GS_FLAG_LOGIT_OPACITY) {  // d sigmoid: s (1 - s), model.cpp:215
             const float sg = 1.0f / (1.0f + expf(-opacities[g]));
             vo *= sg * (1.0f - sg);
@@ -303,7 +347,16 @@ extern "C" int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev
     case 1: GS_FWD(1);
     case 4: GS_FWD(4);
     case 9: GS_FWD(9);
-    case 16: GS_FWD(16);
+    case 16: {  // two LDS-free kernels beat the one-kernel slab variant (see k_project_pack)
+        const int rc = gs::launch_sh_forward_fused16_quad(N, nb, means, cam_pos, features_dc,
+                                                          features_rest, nullptr, rgb_raw, s);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(gs::k_project_pack, dim3((N + 255) / 256), dim3(256), 0, s, a, viewmat_dev,
+                           projmat_dev, N, means, scales, quats, opacities, rgb_raw,
+                           reinterpret_cast<float4 *>(packed), depths, radii, xys, flags);
+        GS_LAUNCH_CHECK();
+        return GS_OK;
+    }
     default: GS_FWD(25);
     }
 #undef GS_FWD

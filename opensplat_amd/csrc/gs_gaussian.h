@@ -386,4 +386,10 @@ static inline int deg_from_bases(int K) {  // spherical_harmonics.cpp:3-16, but 
 }
 
 
+// gs_sh.hip: the K = 16 split-coefficient SH forward, four lanes per Gaussian, no LDS (colors may be
+// NULL: only the raw rgb is written).
+int launch_sh_forward_fused16_quad(int N, int nb, const float *means, const float *cam_pos,
+                                   const float *features_dc, const float *features_rest,
+                                   float *colors, float *rgb_raw, hipStream_t s);
+
 }  // namespace gs

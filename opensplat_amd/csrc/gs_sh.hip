@@ -320,10 +320,26 @@ k_sh_forward_fused16_quad(int N, int nb, const float *__restrict__ means, float 
         rgb_raw[3 * g + 0] = c0;
         rgb_raw[3 * g + 1] = c1;
         rgb_raw[3 * g + 2] = c2;
-        colors[3 * g + 0] = fmaxf(c0 + 0.5f, 0.0f);
-        colors[3 * g + 1] = fmaxf(c1 + 0.5f, 0.0f);
-        colors[3 * g + 2] = fmaxf(c2 + 0.5f, 0.0f);
+        if (colors) {
+            colors[3 * g + 0] = fmaxf(c0 + 0.5f, 0.0f);
+            colors[3 * g + 1] = fmaxf(c1 + 0.5f, 0.0f);
+            colors[3 * g + 2] = fmaxf(c2 + 0.5f, 0.0f);
+        }
     }
+}
+
+// Host launcher shared with gs_fused.hip (gs_gaussian_forward at K = 16); colors may be NULL.
+int launch_sh_forward_fused16_quad(int N, int nb, const float *means, const float *cam_pos,
+                                   const float *features_dc, const float *features_rest,
+                                   float *colors, float *rgb_raw, hipStream_t s) {
+    const bool dev = on_device(cam_pos);
+    const int64_t threads = (int64_t)N * 4;
+    hipLaunchKernelGGL(k_sh_forward_fused16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       s, N, nb, means, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
+                       dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr, features_dc, features_rest,
+                       colors, rgb_raw);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
 }
 
 template <int K>
@@ -413,16 +429,9 @@ extern "C" int gs_sh_forward_fused(int N, int K, int degrees_to_use, const float
     case 1: return gs::launch_fwd_fused<1>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     case 4: return gs::launch_fwd_fused<4>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     case 9: return gs::launch_fwd_fused<9>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
-    case 16: {
-        const bool dev = gs::on_device(cam_pos);
-        const int64_t threads = (int64_t)N * 4;
-        hipLaunchKernelGGL(gs::k_sh_forward_fused16_quad, dim3((unsigned)((threads + 255) / 256)),
-                           dim3(256), 0, s, N, nb, means, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
-                           dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr, features_dc, features_rest,
-                           colors, rgb_raw);
-        GS_LAUNCH_CHECK();
-        return GS_OK;
-    }
+    case 16:
+        return gs::launch_sh_forward_fused16_quad(N, nb, means, cam_pos, features_dc, features_rest,
+                                                  colors, rgb_raw, s);
     default: return gs::launch_fwd_fused<25>(N, nb, means, cam_pos, features_dc, features_rest, colors, rgb_raw, s);
     }
 }

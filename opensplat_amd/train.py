@@ -93,7 +93,7 @@ class Trainer:
         self.bin_ws = cabi.BinWorkspace()
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i), img_clamped=torch.empty((H, W, 3), **f))
-        # gradient records of the compositing backward; gs_gaussian_backward leaves them zeroed
+        # gradient records of the compositing backward, consumed in place by gs_gaussian_backward
         self.bwd_ws = torch.zeros((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
                                   device=dev, dtype=torch.uint8)
         self.v_xy = torch.zeros((N, 2), **f)     # d loss / d xys: the densification statistics' input
@@ -131,7 +131,7 @@ class Trainer:
     def backward(self, v_rgb):
         """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
-        keep = cabi.GS_FLAG_KEEP_RECORDS | cabi.GS_FLAG_RECORDS_ZEROED
+        keep = cabi.GS_FLAG_KEEP_RECORDS
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
                                 flags | keep, workspace=self.bwd_ws, img_raw=f["img"])
         cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
