@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--fast-exp", action="store_true",
                     help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", default="given", choices=["given", "morton", "tile"],
+                    help="EXPERIMENT: permute the scene's Gaussians before the run — 3-D Morton order "
+                         "of the means, or by the 16x16 tile of the projected centre (upper bound)")
     ap.add_argument("--stage-kernels", action="store_true",
                     help="run projection / SH / pack and their backwards as separate kernels "
                          "(operator granularity) instead of the fused per-Gaussian kernels")
@@ -252,6 +255,33 @@ class Pipeline:
             events.append(e)
 
 
+def reorder_scene(s, how):
+    """Permute the Gaussians of scene `s` (any order is a valid input: the result is the same image
+    and the same gradients, permuted)."""
+    if how == "tile":
+        fx, fy = s.fx, s.fy
+        p = s.means @ s.viewmat[:3, :3].T + s.viewmat[:3, 3]
+        u = np.clip(p[:, 0] / p[:, 2] * fx + s.cx, 0, s.W - 1).astype(np.int64) // 16
+        v = np.clip(p[:, 1] / p[:, 2] * fy + s.cy, 0, s.H - 1).astype(np.int64) // 16
+        key = v * 100000 + u
+    else:
+        lo, hi = s.means.min(0), s.means.max(0)
+        q = ((s.means - lo) / (hi - lo + 1e-9) * 1023).astype(np.uint64)
+
+        def spread(x):
+            x = (x | (x << 16)) & 0x030000FF
+            x = (x | (x << 8)) & 0x0300F00F
+            x = (x | (x << 4)) & 0x030C30C3
+            x = (x | (x << 2)) & 0x09249249
+            return x
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    perm = np.argsort(key, kind="stable")
+    for name in ("means", "scales", "quats", "opacities", "sh_coeffs", "dirs", "colors"):
+        a = getattr(s, name, None)
+        if a is not None:
+            setattr(s, name, np.ascontiguousarray(a[perm]))
+
+
 def algorithmic_bytes(N, K, M, P):
     """compulsory HBM traffic of one fwd+bwd, and the per-kernel shares used for
     roofline.achieved (stated in DESIGN.md §Measurement)."""
@@ -341,6 +371,8 @@ def main():
         workload = ("C4: %d shared Gaussians, %d cameras at 1920x1080 (one per rank, yaw offsets), "
                     "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians, world))
 
+    if args.order != "given":
+        reorder_scene(scene, args.order)
     flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
     pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels)
 
