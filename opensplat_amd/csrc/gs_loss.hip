@@ -7,9 +7,10 @@
 //
 //   k_ssim_maps   one workgroup per 32x22 output tile: stages the (32+10)x(22+10) halo of both
 //                 images (all three channels, exactly as they lie in the HWC rows) in LDS, runs
-//                 the separable window over the five products {x, y, xx, yy, xy} — horizontal pass
-//                 LDS->LDS with four outputs per thread, vertical pass LDS->registers with three
-//                 outputs per thread — evaluates the SSIM map and its three partial derivatives
+//                 the separable window over the four quantities {x, y, xx + yy, xy} (only the SUM of
+//                 the second moments enters the map and its derivatives) — horizontal pass LDS->LDS
+//                 with four outputs per thread, vertical pass LDS->registers with three outputs per
+//                 thread — evaluates the SSIM map and its three partial derivatives
 //                 (w.r.t. mu2, E[yy], E[xy]) and writes those planar; per-workgroup partial sums
 //                 of the SSIM map and of |gt - rendered|;
 //   k_ssim_grad   the transposed (flipped-window) convolution of the three derivative maps, again
@@ -17,9 +18,11 @@
 //                 the L1 sign term; output staged in LDS so that the HWC rows are written coalesced;
 //   k_loss_finalize  sums the partials in fp64 and writes {mainLoss, l1, ssim}.
 //
-// Both tiled kernels are HBM-streaming (algorithmic bytes per pixel: 24 read + 108 written by the
-// first, 108 + 24 read + 12 written by the second), the separable passes cost
-// ~35 LDS reads per pixel-channel instead of 121 x 5 multiply-adds from global memory.
+// Algorithmic bytes per pixel: 24 read + 108 written by the first kernel, 108 + 24 read + 12
+// written by the second.  Measured on MI355X the first is VALU-bound (the window's
+// pair structure, conv_pairs, cuts the multiply-adds per output from eleven to six), the second
+// latency-bound (next channel's halo prefetched into registers); tiles are numbered so that each
+// XCD works on a contiguous band of the image and halo re-reads hit its L2.
 #include <math.h>
 
 #include "gs_device.h"

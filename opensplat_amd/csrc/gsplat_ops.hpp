@@ -139,6 +139,30 @@ private:
 // OptimScheduler::getLearningRate (optim_scheduler.cpp:4-7)
 float schedulerLearningRate(float lrInit, float lrFinal, int maxSteps, int step);
 
+// SURVEY.md §8 row f4 — Model::afterTrain's tensor work (model.cpp:311-494) on the device
+// (include/gsplat_densify.h).  The schedule (refineEvery, warmupLength, ...) stays with the caller.
+//   densifyStats   model.cpp:317-337; allocates the three accumulators when they are empty (the
+//                  reference's `!xysGradNorm.numel()` first-call branch), else updates in place
+//   densify        model.cpp:345-458 + addToOptimizer / removeFromOptimizer: returns the six
+//                  parameter tensors and their Adam moments of the refined set; the normal samples
+//                  come from torch::randn on the parameters' device, as in the reference
+//   resetOpacity   model.cpp:464-479 (moments optional, see gs_reset_opacity)
+void densifyStats(const torch::Tensor &xysGrad, const torch::Tensor &radii, int lastHeight,
+                  int lastWidth, torch::Tensor &xysGradNorm, torch::Tensor &visCounts,
+                  torch::Tensor &max2DSize);
+struct DensifyResult {
+    std::vector<torch::Tensor> params, expAvg, expAvgSq;  // means, scales, quats, opacities, featuresDc, featuresRest
+    int nSplits = 0, nDups = 0, added = 0, culled = 0;
+};
+DensifyResult densify(const std::vector<torch::Tensor> &params, const std::vector<torch::Tensor> &expAvg,
+                      const std::vector<torch::Tensor> &expAvgSq, const torch::Tensor &xysGradNorm,
+                      const torch::Tensor &visCounts, const torch::Tensor &max2DSize, int lastWidth,
+                      int lastHeight, float densifyGradThresh, float densifySizeThresh,
+                      bool checkScreenSize, float splitScreenSize, bool cullHuge);
+void resetOpacity(torch::Tensor &opacities, float resetValue,
+                  c10::optional<torch::Tensor> expAvg = c10::nullopt,
+                  c10::optional<torch::Tensor> expAvgSq = c10::nullopt);
+
 // Process-wide switch for the compositing kernels' exponential: false (default) = glibc-bit-exact
 // expf (contributor sets identical to gsplat-cpu); true = hardware v_exp_f32 (GS_FLAG_FAST_EXP).
 void gsplatSetFastExp(bool enabled);

@@ -20,6 +20,7 @@
 
 #include "../../include/gsplat_hip.h"
 #include "../../include/gsplat_train.h"
+#include "../../include/gsplat_densify.h"
 
 using torch::Tensor;
 using torch::autograd::AutogradContext;
@@ -600,6 +601,96 @@ float schedulerLearningRate(float lrInit, float lrFinal, int maxSteps, int step)
     return gs_sched_lr(lrInit, lrFinal, maxSteps, step);
 }
 
+// ---- row f4: densification (include/gsplat_densify.h) ---------------------------------------------
+void densifyStats(const Tensor &xysGrad, const Tensor &radii, int lastHeight, int lastWidth,
+                  Tensor &xysGradNorm, Tensor &visCounts, Tensor &max2DSize) {
+    GS_CHECK_DEV(xysGrad); GS_CHECK_F32(xysGrad); GS_CHECK_DEV(radii); GS_CHECK_I32(radii);
+    const int64_t N = radii.numel();
+    TORCH_CHECK(xysGrad.numel() == 2 * N, "xysGrad must be [N, 2]");
+    c10::DeviceGuard guard(radii.device());
+    const bool first = !xysGradNorm.numel();   // model.cpp:321,329
+    if (first) {
+        xysGradNorm = torch::empty({N}, xysGrad.options());
+        visCounts = torch::empty({N}, xysGrad.options());
+        max2DSize = torch::empty({N}, xysGrad.options());
+    }
+    Tensor g = xysGrad.contiguous(), r = radii.contiguous();
+    check_status(gs_densify_stats((int)N, fptr(g), r.data_ptr<int32_t>(),
+                                  (float)std::max(lastHeight, lastWidth), first ? 1 : 0,
+                                  fptr_mut(xysGradNorm), fptr_mut(visCounts), fptr_mut(max2DSize),
+                                  current_stream()),
+                 "gs_densify_stats");
+}
+
+namespace {
+GsGaussianSet as_set(const std::vector<Tensor> &t) {
+    GsGaussianSet s = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (t.size() != 6) return s;
+    float **f[6] = {&s.means, &s.log_scales, &s.quats, &s.opacity_logits, &s.features_dc, &s.features_rest};
+    for (int i = 0; i < 6; i++)
+        if (t[i].defined() && t[i].numel() > 0) *f[i] = const_cast<float *>(t[i].data_ptr<float>());
+    return s;
+}
+}  // namespace
+
+DensifyResult densify(const std::vector<Tensor> &params, const std::vector<Tensor> &expAvg,
+                      const std::vector<Tensor> &expAvgSq, const Tensor &xysGradNorm,
+                      const Tensor &visCounts, const Tensor &max2DSize, int lastWidth, int lastHeight,
+                      float densifyGradThresh, float densifySizeThresh, bool checkScreenSize,
+                      float splitScreenSize, bool cullHuge) {
+    TORCH_CHECK(params.size() == 6, "six parameter tensors expected");
+    TORCH_CHECK(expAvg.empty() || expAvg.size() == 6, "six exp_avg tensors (or none) expected");
+    TORCH_CHECK(expAvgSq.size() == expAvg.size(), "exp_avg / exp_avg_sq must come together");
+    for (auto &p : params) { GS_CHECK_DEV(p); GS_CHECK_F32(p); TORCH_CHECK(p.is_contiguous(), "contiguous parameters expected"); }
+    const int N = (int)params[0].size(0);
+    const int K = 1 + (int)(params[5].numel() > 0 ? params[5].size(1) : 0);
+    c10::DeviceGuard guard(params[0].device());
+    const GsDensifyConfig cfg = {0.5f * (float)std::max(lastWidth, lastHeight), densifyGradThresh,
+                                 densifySizeThresh, splitScreenSize, checkScreenSize ? 1 : 0, 0.1f,
+                                 cullHuge ? 1 : 0, 0.5f, 0.15f};
+    auto bytes = gs_densify_workspace_bytes(N);
+    Tensor ws = torch::empty({(int64_t)bytes}, params[0].options().dtype(torch::kUInt8));
+    Tensor counts = torch::zeros({8}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    check_status(gs_densify_plan(N, &cfg, fptr(xysGradNorm), fptr(visCounts), fptr(max2DSize),
+                                 fptr(params[1]), fptr(params[3]), counts.data_ptr<int32_t>(),
+                                 ws.data_ptr(), bytes, current_stream()),
+                 "gs_densify_plan");
+    c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();   // the one sync: nSplits, newN
+    const int32_t *c = counts.data_ptr<int32_t>();
+    DensifyResult r;
+    r.nSplits = c[GS_DENSIFY_N_SPLITS]; r.nDups = c[GS_DENSIFY_N_DUPS];
+    r.added = c[GS_DENSIFY_ADDED]; r.culled = c[GS_DENSIFY_CULLED];
+    const int64_t newN = c[GS_DENSIFY_NEW_N];
+    Tensor samples;
+    if (r.nSplits > 0) samples = torch::randn({2 * (int64_t)r.nSplits, 3}, params[0].options());  // model.cpp:360
+    auto alloc = [&](std::vector<Tensor> &dst) {
+        for (auto &p : params) {
+            auto sizes = p.sizes().vec();
+            sizes[0] = newN;
+            dst.push_back(torch::empty(sizes, p.options()));
+        }
+    };
+    alloc(r.params);
+    if (!expAvg.empty()) { alloc(r.expAvg); alloc(r.expAvgSq); }
+    const GsGaussianSet src[3] = {as_set(params), as_set(expAvg), as_set(expAvgSq)};
+    const GsGaussianSet dst[3] = {as_set(r.params), as_set(r.expAvg), as_set(r.expAvgSq)};
+    check_status(gs_densify_apply(N, K, (int)newN, samples.defined() ? fptr(samples) : nullptr, src, dst,
+                                  ws.data_ptr(), bytes, current_stream()),
+                 "gs_densify_apply");
+    return r;
+}
+
+void resetOpacity(Tensor &opacities, float resetValue, c10::optional<Tensor> expAvg,
+                  c10::optional<Tensor> expAvgSq) {
+    GS_CHECK_DEV(opacities); GS_CHECK_F32(opacities);
+    TORCH_CHECK(opacities.is_contiguous(), "opacities must be contiguous");
+    c10::DeviceGuard guard(opacities.device());
+    check_status(gs_reset_opacity((int)opacities.numel(), resetValue, fptr_mut(opacities),
+                                  expAvg ? expAvg->data_ptr<float>() : nullptr,
+                                  expAvgSq ? expAvgSq->data_ptr<float>() : nullptr, current_stream()),
+                 "gs_reset_opacity");
+}
+
 // ---- Python-visible registration (torch.ops.opensplat_amd.*) -------------------------------------
 namespace {
 
@@ -639,6 +730,33 @@ std::vector<Tensor> op_splat_render(const Tensor &means, const Tensor &logScales
 }
 
 void op_set_fast_exp(bool enabled) { gsplatSetFastExp(enabled); }
+
+// -> [params x6, exp_avg x6, exp_avg_sq x6 (moment lists empty when none were given), counts int32[4]
+//     = {nSplits, nDups, added, culled} on the host]
+std::vector<Tensor> op_densify(std::vector<Tensor> params, std::vector<Tensor> expAvg,
+                               std::vector<Tensor> expAvgSq, const Tensor &xysGradNorm,
+                               const Tensor &visCounts, const Tensor &max2DSize, int64_t lastWidth,
+                               int64_t lastHeight, double densifyGradThresh, double densifySizeThresh,
+                               bool checkScreenSize, double splitScreenSize, bool cullHuge) {
+    DensifyResult r = densify(params, expAvg, expAvgSq, xysGradNorm, visCounts, max2DSize,
+                              (int)lastWidth, (int)lastHeight, (float)densifyGradThresh,
+                              (float)densifySizeThresh, checkScreenSize, (float)splitScreenSize, cullHuge);
+    std::vector<Tensor> out = r.params;
+    out.insert(out.end(), r.expAvg.begin(), r.expAvg.end());
+    out.insert(out.end(), r.expAvgSq.begin(), r.expAvgSq.end());
+    Tensor counts = torch::empty({4}, torch::kInt32);
+    int32_t *c = counts.data_ptr<int32_t>();
+    c[0] = r.nSplits; c[1] = r.nDups; c[2] = r.added; c[3] = r.culled;
+    out.push_back(counts);
+    return out;
+}
+
+std::vector<Tensor> op_densify_stats(const Tensor &xysGrad, const Tensor &radii, int64_t lastHeight,
+                                     int64_t lastWidth, Tensor xysGradNorm, Tensor visCounts,
+                                     Tensor max2DSize) {
+    densifyStats(xysGrad, radii, (int)lastHeight, (int)lastWidth, xysGradNorm, visCounts, max2DSize);
+    return {xysGradNorm, visCounts, max2DSize};
+}
 
 Tensor op_main_loss(const Tensor &rgb, const Tensor &gt, double ssimWeight) {
     return MainLoss::apply(rgb, gt, ssimWeight);
@@ -688,6 +806,14 @@ TORCH_LIBRARY(opensplat_amd, m) {
           &op_splat_render);
     m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
     m.def("main_loss(Tensor rgb, Tensor gt, float ssim_weight) -> Tensor", &op_main_loss);
+    m.def("densify_stats(Tensor xys_grad, Tensor radii, int last_height, int last_width, "
+          "Tensor xys_grad_norm, Tensor vis_counts, Tensor max_2d_size) -> Tensor[]",
+          &op_densify_stats);
+    m.def("densify(Tensor[] params, Tensor[] exp_avg, Tensor[] exp_avg_sq, Tensor xys_grad_norm, "
+          "Tensor vis_counts, Tensor max_2d_size, int last_width, int last_height, "
+          "float densify_grad_thresh, float densify_size_thresh, bool check_screen_size, "
+          "float split_screen_size, bool cull_huge) -> Tensor[]",
+          &op_densify);
     m.def("adam_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, "
           "float[] lrs, int step) -> ()",
           &op_adam_step);

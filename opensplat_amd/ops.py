@@ -88,3 +88,27 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lrs, step):
     params / exp_avg / exp_avg_sq are updated in place; `step` is 1-based."""
     _ops.adam_step(list(params), list(grads), list(exp_avg), list(exp_avg_sq),
                    [float(x) for x in lrs], int(step))
+
+
+def densify_stats(xys_grad, radii, last_height, last_width, stats=None):
+    """Model::afterTrain's per-iteration statistics (model.cpp:317-337).  stats = (xysGradNorm,
+    visCounts, max2DSize) from the previous call, or None right after a refinement; returns them."""
+    empty = torch.empty(0, device=radii.device)
+    a, b, c = stats if stats is not None else (empty, empty.clone(), empty.clone())
+    return tuple(_ops.densify_stats(xys_grad, radii, int(last_height), int(last_width), a, b, c))
+
+
+def densify(params, exp_avg, exp_avg_sq, stats, last_width, last_height, densify_grad_thresh=0.0002,
+            densify_size_thresh=0.01, check_screen_size=True, split_screen_size=0.05, cull_huge=True):
+    """One refinement (model.cpp:345-458 + optimiser-state surgery).  params / exp_avg / exp_avg_sq:
+    lists [means, scales(log), quats, opacities(logit, [N,1]), featuresDc, featuresRest] (moment
+    lists may be empty).  -> (params, exp_avg, exp_avg_sq, dict(n_splits, n_dups, added, culled))."""
+    out = _ops.densify(list(params), list(exp_avg or []), list(exp_avg_sq or []), stats[0], stats[1],
+                       stats[2], int(last_width), int(last_height), float(densify_grad_thresh),
+                       float(densify_size_thresh), bool(check_screen_size), float(split_screen_size),
+                       bool(cull_huge))
+    counts = dict(zip(["n_splits", "n_dups", "added", "culled"], [int(x) for x in out[-1]]))
+    body = out[:-1]
+    if len(body) == 18:
+        return body[:6], body[6:12], body[12:18], counts
+    return body[:6], None, None, counts

@@ -87,3 +87,32 @@ def test_operators_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="GPU"):
         ops.project_gaussians(torch.zeros(4, 3), torch.ones(4, 3), 1.0, torch.ones(4, 4),
                               torch.eye(4), torch.eye(4), 10.0, 10.0, 8.0, 8.0, 16, 16)
+
+
+def test_fused_stage_argument_validation_without_gpu():
+    """gs_gaussian_forward / gs_gaussian_backward reject bad arguments before touching the device."""
+    l = cabi.lib()
+    cam = cabi.GsCamera()
+    cam.img_width, cam.img_height = 640, 480
+    null, one, rec = ctypes.c_void_p(0), ctypes.c_void_p(256), ctypes.c_void_p(4096)
+    i = ctypes.c_int
+    u = ctypes.c_uint32
+    fwd = lambda N, K, deg, rest=one, packed=one: l.gs_gaussian_forward(
+        ctypes.byref(cam), null, null, i(N), i(K), i(deg), one, one, one, one, one, rest, one, packed,
+        one, one, one, null, u(0), null)
+    assert fwd(0, 16, 3) == 0                      # nothing to do
+    assert fwd(-1, 16, 3) == -1
+    assert fwd(10, 5, 0) == -1                     # not a valid number of SH bases
+    assert fwd(10, 4, 2) == -1                     # degree too high for K
+    assert fwd(10, 16, 3, rest=null) == -1         # K > 1 needs features_rest
+    assert fwd(10, 16, 3, packed=ctypes.c_void_p(260)) == -1   # packed records are aligned float4s
+    cam.img_width = 70000
+    assert fwd(10, 16, 3) == -2
+    cam.img_width = 640
+    bwd = lambda N, K, deg, rbytes, records=rec: l.gs_gaussian_backward(
+        ctypes.byref(cam), null, null, i(N), i(K), i(deg), one, one, one, one, one, one, one, records,
+        ctypes.c_size_t(rbytes), one, one, one, one, one, one, null, u(0), null)
+    assert bwd(0, 16, 3, 0) == 0
+    assert bwd(10, 16, 3, 10 * 64 - 1) == -3       # record workspace too small
+    assert bwd(10, 16, 3, 640, records=ctypes.c_void_p(4100)) == -1   # 64-byte aligned records
+    assert bwd(10, 7, 0, 640) == -1

@@ -211,3 +211,39 @@ def test_trainer_after_train_schedule_and_refinement(restated):
     for buf in (T.params, T.grads, T.exp_avg, T.exp_avg_sq):
         assert buf.flat.numel() == T.N * (3 * 4 + 11) and torch.isfinite(buf.flat).all()
     assert T.opacity_logits.max().item() <= np.log(0.2 / 0.8) + 1.0   # reset at step 24, one Adam step since
+
+
+def test_libtorch_densify_operators_equal_the_cabi_path():
+    """torch_ops.cpp: densifyStats / densify (C++ host, torch::randn for the samples) against the
+    ctypes-level path fed the same random stream."""
+    from opensplat_amd import ops
+
+    prob = scenes.densify_problem(5000, 9, seed=41)
+    P = [dev(a) for a in prob["params"]]
+    M = [dev(a) for a in prob["exp_avg"]]
+    V = [dev(a) for a in prob["exp_avg_sq"]]
+    stats = (dev(prob["xys_grad_norm"]), dev(prob["vis_counts"]), dev(prob["max_2d_size"]))
+    torch.manual_seed(123)
+    p1, m1, v1, c1 = ops.densify(P, M, V, stats, prob["width"], prob["height"])
+    torch.manual_seed(123)
+    cfg = cabi.densify_config(prob["width"], prob["height"])
+    p2, m2, v2, c2 = cabi.densify(cfg, P, M, V, *stats)
+    torch.cuda.synchronize()
+    assert (c1["n_splits"], c1["n_dups"], c1["added"], c1["culled"]) == \
+           (c2["n_splits"], c2["n_dups"], c2["added"], c2["culled"])
+    for a, b in zip(p1 + m1 + v1, p2 + m2 + v2):
+        assert torch.equal(a, b)
+    # no optimiser state
+    p3, m3, v3, c3 = ops.densify(P, None, None, stats, prob["width"], prob["height"])
+    assert m3 is None and p3[0].shape[0] == c2["new_n"]
+    # statistics: first call allocates, second accumulates
+    N = 700
+    rs = np.random.RandomState(2)
+    g = dev((rs.standard_normal((N, 2)) * 1e-4).astype(np.float32))
+    r = dev((rs.randint(0, 30, N) * (rs.rand(N) < 0.6)).astype(np.int32))
+    st = ops.densify_stats(g, r, 480, 640)
+    st = ops.densify_stats(g, r, 480, 640, st)
+    a, b, c = [torch.zeros(N, device=DEV) for _ in range(3)]
+    cabi.densify_stats(g, r, 640.0, True, a, b, c)
+    cabi.densify_stats(g, r, 640.0, False, a, b, c)
+    assert torch.equal(st[0], a) and torch.equal(st[1], b) and torch.equal(st[2], c)
