@@ -40,7 +40,8 @@ constexpr int kOutPitch = 3 * kTW + 1;                   // 97
 constexpr int kLossThreads = 256;
 static_assert(kHH * (kTW / 4) == kLossThreads, "horizontal pass: one item per thread");
 static_assert(kTH <= 3 * (kLossThreads / kTW), "vertical pass: three rows per thread");
-static_assert(kHH % 2 == 0 && kTH % 2 == 0 && 3 * kHW <= 128 && kLossThreads == 256, "row-pair loads");
+static_assert(kHH % 4 == 0 && kTH % 2 == 0 && 3 * kHW <= 128 && kHW <= 64 && kLossThreads == 256,
+              "row-pair / row-quad loads");
 
 // The reference's window has the shape {a, b,b, c,c, d,d, e,e, f,f} (floor((i - 11) / 2) takes every
 // value but -6 twice, ssim.cpp:42): one single weight and five PAIR weights.  A pass then needs one
@@ -118,8 +119,8 @@ __global__ void __launch_bounds__(kLossThreads)
 k_ssim_maps(int W, int H, int tiles_x, Window win, const float *__restrict__ rendered,
             const float *__restrict__ gt, float *__restrict__ maps /* [3 maps][3 ch][H][W] */,
             float2 *__restrict__ partial /* {ssim sum, l1 sum} per workgroup */) {
-    __shared__ float rx[kHH][kRawPitch];  // gt       (img1, ssim.cpp:8)
-    __shared__ float ry[kHH][kRawPitch];  // rendered (img2, ssim.cpp:9)
+    __shared__ float rx[kHH][kMapPitch];  // gt       (img1, ssim.cpp:8), ONE channel at a time
+    __shared__ float ry[kHH][kMapPitch];  // rendered (img2, ssim.cpp:9)
     __shared__ float hb[4][kHH][kHPitch];  // window sums of x, y, xx + yy, xy
     __shared__ float red[4];
     const int tid = threadIdx.x;
@@ -127,39 +128,48 @@ k_ssim_maps(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
     tile_origin(tiles_x, tile, x0, y0);
     const size_t P = (size_t)W * H;
 
-    // halo rows are contiguous runs of 126 floats in the HWC images; zero padding outside.
-    // Fixed trip count, no index division: lane -> float of the row, two rows per iteration.
-    {
-        const int c = tid & 127, rr = tid >> 7;
-        const int gxf = (x0 - kRad) * 3 + c;
-        const bool col_ok = c < 3 * kHW && gxf >= 0 && gxf < 3 * W;
+    // Halo of ONE channel at a time (28 KB of LDS instead of 49: five workgroups per CU instead of
+    // three — the kernel is latency-bound): lane -> halo column, four rows per iteration; the
+    // stride-3 reads of the three channel passes touch the same lines (L1 / L2 hits), and the next
+    // channel's values are fetched into registers while this channel is convolved.
+    const int lc = tid & 63, lrr = tid >> 6;
+    const int lgx = x0 - kRad + lc;
+    const bool lcol_ok = lc < kHW && lgx >= 0 && lgx < W;
+    float pa[kHH / 4], pb[kHH / 4];
+    auto fetch = [&](int ch) {
 #pragma unroll
-        for (int it = 0; it < kHH / 2; it++) {
-            const int r = 2 * it + rr, gy = y0 - kRad + r;
-            float a = 0.0f, b = 0.0f;
-            if (col_ok && gy >= 0 && gy < H) {
-                const size_t o = (size_t)gy * W * 3 + gxf;
-                a = gt[o];
-                b = rendered[o];
-            }
-            if (c < 3 * kHW) {
-                rx[r][c] = a;
-                ry[r][c] = b;
+        for (int it = 0; it < kHH / 4; it++) {
+            const int gy = y0 - kRad + 4 * it + lrr;
+            pa[it] = 0.0f;
+            pb[it] = 0.0f;
+            if (lcol_ok && gy >= 0 && gy < H) {
+                const size_t o = ((size_t)gy * W + lgx) * 3 + ch;
+                pa[it] = gt[o];
+                pb[it] = rendered[o];
             }
         }
-    }
-    __syncthreads();
+    };
+    fetch(0);
 
     float ssim_sum = 0.0f, l1_sum = 0.0f;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // ssim.cpp:26-27
     for (int ch = 0; ch < 3; ch++) {
+        if (lc < kHW) {
+#pragma unroll
+            for (int it = 0; it < kHH / 4; it++) {
+                rx[4 * it + lrr][lc] = pa[it];
+                ry[4 * it + lrr][lc] = pb[it];
+            }
+        }
+        __syncthreads();  // (also: the previous channel's vertical pass is done with hb)
+        if (ch < 2) fetch(ch + 1);
         {   // horizontal pass: thread = (halo row, group of four output columns)
             const int row = tid % kHH, c0 = 4 * (tid / kHH);
             float xv[kWin + 3], yv[kWin + 3], in[kWin + 3], o[4];
 #pragma unroll
             for (int k = 0; k < kWin + 3; k++) {
-                xv[k] = rx[row][(c0 + k) * 3 + ch];
-                yv[k] = ry[row][(c0 + k) * 3 + ch];
+                xv[k] = rx[row][c0 + k];
+                yv[k] = ry[row][c0 + k];
             }
             conv_pairs<false, 4>(win, xv, o);
 #pragma unroll
@@ -200,17 +210,21 @@ k_ssim_maps(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
                     const float A1 = 2.0f * mu1mu2 + C1, A2 = 2.0f * s12 + C2;
                     // sigma1Sq + sigma2Sq = (E[xx] + E[yy]) - mu1^2 - mu2^2
                     const float B1 = mu1Sq + mu2Sq + C1, B2 = (acc[2][j] - mu1Sq - mu2Sq) + C2;
-                    const float invB = 1.0f / (B1 * B2);
+                    // reciprocals: hardware estimate + one Newton step (|rel. error| < 2^-22; four IEEE
+                    // divisions per pixel-channel were 15 % of this VALU-bound kernel's instructions)
+                    float r1 = __builtin_amdgcn_rcpf(B1), r2 = __builtin_amdgcn_rcpf(B2);
+                    r1 = fmaf(fmaf(-B1, r1, 1.0f), r1, r1);
+                    r2 = fmaf(fmaf(-B2, r2, 1.0f), r2, r2);
+                    const float invB = r1 * r2;
                     const float S = (A1 * A2) * invB;  // ssim.cpp:29
                     ssim_sum += S;
-                    const float xc = rx[r + kRad][(c + kRad) * 3 + ch];
-                    const float yc = ry[r + kRad][(c + kRad) * 3 + ch];
+                    const float xc = rx[r + kRad][c + kRad];
+                    const float yc = ry[r + kRad][c + kRad];
                     l1_sum += fabsf(xc - yc);  // model.cpp:55
                     // dS/dmu2, dS/dE[yy], dS/dE[xy] with the other window sums held fixed
                     const size_t o = (size_t)ch * P + (size_t)gy * W + gx;
-                    maps[o] = 2.0f * m1 * (A2 - A1) * invB -
-                              2.0f * m2 * S * (1.0f / B1 - 1.0f / B2);
-                    maps[3 * P + o] = -S / B2;
+                    maps[o] = 2.0f * m1 * (A2 - A1) * invB - 2.0f * m2 * S * (r1 - r2);
+                    maps[3 * P + o] = -S * r2;
                     maps[6 * P + o] = 2.0f * A1 * invB;
                 }
             }
@@ -229,25 +243,14 @@ k_ssim_grad(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
             float *__restrict__ v_rendered) {
     __shared__ float raw[3][kHH][kMapPitch];
     __shared__ float hb[3][kHH][kHPitch];
-    __shared__ float xs[kTH][kOutPitch];  // gt tile, overwritten in place by the result
-    __shared__ float ys[kTH][kOutPitch];  // rendered tile
+    __shared__ float outb[kTH][kOutPitch];  // result tile, written back as coalesced HWC rows
     const int tid = threadIdx.x;
     int tile, x0, y0;
     tile_origin(tiles_x, tile, x0, y0);
     const size_t P = (size_t)W * H;
 
-    // the tile's own pixels, as the 96-float HWC row segments they are
     const int oc = tid & 127, orr = tid >> 7;
     const bool ocol_ok = oc < 3 * kTW && x0 * 3 + oc < 3 * W;
-#pragma unroll
-    for (int it = 0; it < kTH / 2; it++) {
-        const int r = 2 * it + orr, gy = y0 + r;
-        if (ocol_ok && gy < H) {
-            const size_t o = (size_t)gy * W * 3 + x0 * 3 + oc;
-            xs[r][oc] = gt[o];
-            ys[r][oc] = rendered[o];
-        }
-    }
     // halo of the three derivative maps: lane -> (map, column), two rows per iteration
     const int lq = (tid & 127) / kHW, lc = (tid & 127) - lq * kHW, lrr = tid >> 7;
     const int lgx = x0 - kRad + lc;
@@ -303,7 +306,11 @@ k_ssim_grad(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
                 if (r < kTH) {
                     float v = 0.0f;
                     if (gx < W && gy < H) {
-                        const float xc = xs[r][c * 3 + ch], yc = ys[r][c * 3 + ch];
+                        // (stride-3 reads of the two images: the three channel passes of a wave
+                        // touch the same lines, so two of three are L1 / L2 hits; staging the tile
+                        // in LDS instead costs 17 KB and a workgroup of occupancy — measured slower)
+                        const size_t o = ((size_t)gy * W + gx) * 3 + ch;
+                        const float xc = gt[o], yc = rendered[o];
                         // d ssim_map-sum / d y[q]
                         const float dS = acc[0][j] + 2.0f * yc * acc[1][j] + xc * acc[2][j];
                         // d|gt - r|/dr = -sign(gt - r), sign(0) = 0 (torch::abs backward)
@@ -311,7 +318,7 @@ k_ssim_grad(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
                         const float sg = d > 0.0f ? -1.0f : (d < 0.0f ? 1.0f : 0.0f);
                         v = c_l1 * sg - c_ssim * dS;
                     }
-                    xs[r][c * 3 + ch] = v;
+                    outb[r][c * 3 + ch] = v;
                 }
             }
         }
@@ -321,7 +328,7 @@ k_ssim_grad(int W, int H, int tiles_x, Window win, const float *__restrict__ ren
 #pragma unroll
     for (int it = 0; it < kTH / 2; it++) {
         const int r = 2 * it + orr, gy = y0 + r;
-        if (ocol_ok && gy < H) v_rendered[(size_t)gy * W * 3 + x0 * 3 + oc] = xs[r][oc];
+        if (ocol_ok && gy < H) v_rendered[(size_t)gy * W * 3 + x0 * 3 + oc] = outb[r][oc];
     }
 }
 

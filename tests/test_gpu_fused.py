@@ -197,7 +197,7 @@ def test_gaussian_forward_backward_equal_the_stage_kernels(K, deg, N):
                v_dc=torch.empty((N, 3), **fz), v_rest=torch.empty((N, max(K - 1, 1), 3), **fz))
     v_xy = torch.empty((N, 2), **fz)
     cabi.gaussian_backward(cam, means, ls, q, lo, cam_pos, K, deg, g["radii"], g["rgb_raw"], ws2, out,
-                           flags, v_xy=v_xy)
+                           flags | cabi.GS_FLAG_RECORDS_ZEROED, v_xy=v_xy)
     torch.cuda.synchronize()
     # the compositing backward accumulates with atomics: two runs differ in the last bits, so the
     # comparison is at summation-order tolerance, and exact where no atomics are involved
@@ -212,12 +212,13 @@ def test_gaussian_forward_backward_equal_the_stage_kernels(K, deg, N):
     close(out["v_means"], pb["v_means"], "v_means")
     close(out["v_scales"], pb["v_scales"], "v_scales")
     close(out["v_quats"], pb["v_quats"], "v_quats")
-    assert not ws2[: N * 64].any()            # records left zeroed for the next frame
+    assert not ws2[: N * 64].any()            # GS_FLAG_RECORDS_ZEROED: records zeroed behind the read
     # determinism of the non-atomic part: feed the SAME records to both consumers
     ws3 = ws.clone()                           # records of the stage run (not zeroed by it)
     out2 = {k: torch.empty_like(v) for k, v in out.items()}
     cabi.gaussian_backward(cam, means, ls, q, lo, cam_pos, K, deg, g["radii"], g["rgb_raw"], ws3, out2, flags)
     torch.cuda.synchronize()
+    assert torch.equal(ws3, ws)                # without the flag the records are left alone
     assert torch.equal(out2["v_means"], pb["v_means"]) and torch.equal(out2["v_scales"], pb["v_scales"])
     assert torch.equal(out2["v_quats"], pb["v_quats"]) and torch.equal(out2["v_dc"], v_dc)
     assert torch.equal(out2["v_opacity"], gr["v_opacity"])
