@@ -54,17 +54,23 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
     const float *g = a.g[grp] + i0;
     const float nss = a.neg_step_size[grp];
     if (i0 + 4 <= n && ((a.aligned >> grp) & 1u)) {
-        float4 P = *reinterpret_cast<const float4 *>(p);
-        const float4 G = *reinterpret_cast<const float4 *>(g);
-        float4 M = *reinterpret_cast<const float4 *>(m);
-        float4 V = *reinterpret_cast<const float4 *>(v);
-        adam1(P.x, G.x, M.x, V.x, nss, a);
-        adam1(P.y, G.y, M.y, V.y, nss, a);
-        adam1(P.z, G.z, M.z, V.z, nss, a);
-        adam1(P.w, G.w, M.w, V.w, nss, a);
-        *reinterpret_cast<float4 *>(p) = P;
-        *reinterpret_cast<float4 *>(m) = M;
-        *reinterpret_cast<float4 *>(v) = V;
+        // streaming: every byte is touched once per step and the working set (1.65 GB at N = 1 M)
+        // is far beyond any cache -> non-temporal loads and stores
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 P = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+        const f4 G = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(g));
+        f4 M = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(m));
+        f4 V = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(v));
+        float pe[4] = {P.x, P.y, P.z, P.w}, me[4] = {M.x, M.y, M.z, M.w}, ve[4] = {V.x, V.y, V.z, V.w};
+        const float ge[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) adam1(pe[k], ge[k], me[k], ve[k], nss, a);
+        P.x = pe[0]; P.y = pe[1]; P.z = pe[2]; P.w = pe[3];
+        M.x = me[0]; M.y = me[1]; M.z = me[2]; M.w = me[3];
+        V.x = ve[0]; V.y = ve[1]; V.z = ve[2]; V.w = ve[3];
+        __builtin_nontemporal_store(P, reinterpret_cast<f4 *>(p));
+        __builtin_nontemporal_store(M, reinterpret_cast<f4 *>(m));
+        __builtin_nontemporal_store(V, reinterpret_cast<f4 *>(v));
     } else {
         for (int k = 0; k < 4 && i0 + k < n; k++) {
             float P = p[k], M = m[k], V = v[k];
