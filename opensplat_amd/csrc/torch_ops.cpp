@@ -183,6 +183,41 @@ static thread_local std::shared_ptr<at::cuda::CUDAEvent> g_scanDone;
 // {M, longest tile list} of the last validated frame: scheduling hint for the compositing kernels
 static int32_t g_listStats[2] = {0, 0};
 
+// Binning of already-packed records (gs_pack_splats or gs_gaussian_forward): count + scan, scatter,
+// per-tile sort.  -> (packed, idsSorted[capacity], tileBins, mHost[2] pinned, tileOrder)
+static std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binPacked(const Tensor &packed,
+                                                                    const Tensor &depths, int H, int W) {
+    const int64_t N = depths.size(0);
+    auto i32 = depths.options().dtype(torch::kInt32);
+    gs_stream_t s = current_stream();
+    // The id list is sized from the last intersection count this process saw (+12.5 %) and the
+    // count of THIS call is only read back after the caller has enqueued the compositing kernel
+    // (validateBinning): the stream never idles waiting for the host, where the reference blocks
+    // in the middle of the forward (rasterize_gaussians.cpp:62-63).  A stale guess costs one repeat.
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    Tensor tileBins = torch::empty({tiles, 2}, i32);
+    Tensor mHost = torch::zeros({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    const int64_t cap = std::max<int64_t>(g_capacityHint.load(), 1024);
+    Tensor idsSorted = torch::empty({cap}, i32);
+    size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
+    Tensor ws = torch::empty({(int64_t)wsBytes}, depths.options().dtype(torch::kUInt8));
+    // tiles by descending list length: the compositing launches start with the long lists
+    Tensor tileOrder = torch::empty({tiles}, i32);
+    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
+                             tileOrder.data_ptr<int32_t>(), mHost.data_ptr<int32_t>(),
+                             ws.data_ptr(), wsBytes, s),
+                 "gs_bin_scan");
+    // validateBinning waits for this event (the scan kernel has stored the count), not for the stream
+    auto scanDone = std::make_shared<at::cuda::CUDAEvent>();
+    scanDone->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+    g_scanDone = scanDone;
+    check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
+                             tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
+                             g_listStats, ws.data_ptr(), wsBytes, s),
+                 "gs_bin_sort");
+    return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
+}
+
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
     const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
     const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth,
@@ -202,32 +237,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
                                 opacityIsLogit ? GS_FLAG_LOGIT_OPACITY : 0u, s),
                  "gs_pack_splats");
 
-    // The id list is sized from the last intersection count this process saw (+12.5 %) and the
-    // count of THIS call is only read back after the caller has enqueued the compositing kernel
-    // (validateBinning): the stream never idles waiting for the host, where the reference blocks
-    // in the middle of the forward (rasterize_gaussians.cpp:62-63).  A stale guess costs one repeat.
-    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    Tensor tileBins = torch::empty({tiles, 2}, i32);
-    Tensor mHost = torch::zeros({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    const int64_t cap = std::max<int64_t>(g_capacityHint.load(), 1024);
-    Tensor idsSorted = torch::empty({cap}, i32);
-    size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
-    Tensor ws = torch::empty({(int64_t)wsBytes}, xys.options().dtype(torch::kUInt8));
-    // tiles by descending list length: the compositing launches start with the long lists
-    Tensor tileOrder = torch::empty({tiles}, i32);
-    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
-                             tileOrder.data_ptr<int32_t>(), mHost.data_ptr<int32_t>(),
-                             ws.data_ptr(), wsBytes, s),
-                 "gs_bin_scan");
-    // validateBinning waits for this event (the scan kernel has stored the count), not for the stream
-    auto scanDone = std::make_shared<at::cuda::CUDAEvent>();
-    scanDone->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
-    g_scanDone = scanDone;
-    check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
-                             tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                             g_listStats, ws.data_ptr(), wsBytes, s),
-                 "gs_bin_sort");
-    return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
+    return binPacked(packed, depths, H, W);
 }
 
 // Waits until the scan kernel of the preceding binAndSortGaussians has stored its intersection
@@ -413,30 +423,25 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
 
     auto f32 = means.options();
     auto i32 = means.options().dtype(torch::kInt32);
+    // projection + SH colour + packed record in one fused stage (gs_gaussian_forward)
     Tensor xys = torch::empty({N, 2}, f32), depths = torch::empty({N}, f32);
-    Tensor radii = torch::empty({N}, i32), conics = torch::empty({N, 3}, f32);
-    Tensor numTilesHit = torch::empty({N}, i32), cov3d = torch::empty({N, 6}, f32);
-    Tensor cov2d = torch::empty({N, 3}, f32);
-    check_status(gs_project_forward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(logScales),
-                                    fptr(quats), fptr_mut(xys), fptr_mut(depths),
-                                    radii.data_ptr<int32_t>(), fptr_mut(conics),
-                                    numTilesHit.data_ptr<int32_t>(), fptr_mut(cov3d),
-                                    fptr_mut(cov2d), s),
-                 "gs_project_forward");
-    Tensor colors = torch::empty({N, 3}, f32), rgbRaw = torch::empty({N, 3}, f32);
-    check_status(gs_sh_forward_fused((int)N, (int)K, (int)degreesToUse, fptr(means), cp,
-                                     fptr(featuresDc), hasRest ? fptr(featuresRest) : nullptr,
-                                     fptr_mut(colors), fptr_mut(rgbRaw), s),
-                 "gs_sh_forward_fused");
-    Tensor imgRaw = torch::empty({H, W, 3}, f32), img = torch::empty({H, W, 3}, f32);
-    Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
+    Tensor radii = torch::empty({N}, i32), rgbRaw = torch::empty({N, 3}, f32);
+    Tensor packedAll = torch::empty({N, GS_SPLAT_DWORDS}, f32);
     uint32_t flags = (g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u) | GS_FLAG_CLAMP_IMAGE |
                      GS_FLAG_LOGIT_OPACITY;
+    check_status(gs_gaussian_forward(&cam, vmDev, pmDev, (int)N, (int)K, (int)degreesToUse, fptr(means),
+                                     fptr(logScales), fptr(quats), fptr(opacityLogits),
+                                     fptr(featuresDc), hasRest ? fptr(featuresRest) : nullptr, cp,
+                                     fptr_mut(packedAll), fptr_mut(depths), radii.data_ptr<int32_t>(),
+                                     fptr_mut(rgbRaw), fptr_mut(xys), flags, s),
+                 "gs_gaussian_forward");
+    Tensor imgRaw = torch::empty({H, W, 3}, f32), img = torch::empty({H, W, 3}, f32);
+    Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
     Tensor bgHold;
     const float *bg = vec3_arg(background, bgHold);
     Tensor packed, idsSorted, tileBins, tileOrder;
     for (;;) {
-        auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacityLogits, cov2d, H, W, true);
+        auto b = binPacked(packedAll, depths, H, W);
         packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
         tileOrder = std::get<4>(b);
         check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
@@ -462,7 +467,7 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
                             gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold,
-                            tileOrder});
+                            tileOrder, opacityLogits});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};
@@ -482,26 +487,21 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     const float *bg = bgHold.data_ptr<float>();
     const float *cp = cpHold.data_ptr<float>();
     auto f32 = means.options();
-    Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : torch::empty({N, 2}, f32);
-    Tensor v_conic = torch::empty({N, 3}, f32), v_colors = torch::empty({N, 3}, f32);
-    Tensor v_opacity = torch::empty({N, 1}, f32);
+    Tensor opacityLogits = sv[17];
+    Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : Tensor();
     const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
     Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
+    const uint32_t flags = (uint32_t)ctx->saved_data["flags"].toInt();
+    // compositing backward: gradients stay in the 64-byte records of `ws` ...
     check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
                                        tileBins.data_ptr<int32_t>(), fptr(packed), bg, fptr(finalTs),
                                        finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
-                                       fptr(imgRaw), fptr_mut(v_xy), fptr_mut(v_conic),
-                                       fptr_mut(v_colors), fptr_mut(v_opacity), ws.data_ptr(), wsBytes,
-                                       g_listStats,
+                                       fptr(imgRaw), nullptr, nullptr, nullptr, nullptr, ws.data_ptr(),
+                                       wsBytes, g_listStats,
                                        tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
-                                       (uint32_t)ctx->saved_data["flags"].toInt(), s),
+                                       flags | GS_FLAG_KEEP_RECORDS, s),
                  "gs_rasterize_backward");
-    Tensor v_dc = torch::empty({N, 3}, f32);
-    Tensor v_rest = K > 1 ? torch::empty({N, K - 1, 3}, f32) : Tensor();
-    check_status(gs_sh_backward_fused((int)N, (int)K, (int)ctx->saved_data["degreesToUse"].toInt(),
-                                      fptr(means), cp, fptr(rgbRaw), fptr(v_colors), fptr_mut(v_dc),
-                                      K > 1 ? fptr_mut(v_rest) : nullptr, s),
-                 "gs_sh_backward_fused");
+    // ... and one fused stage turns them into the six parameter gradients (gs_gaussian_backward)
     GsCamera cam = make_camera(ctx->saved_data["fx"].toDouble(), ctx->saved_data["fy"].toDouble(),
                                ctx->saved_data["cx"].toDouble(), ctx->saved_data["cy"].toDouble(), H, W,
                                0.01, 1.0, GS_CAM_LOG_SCALES);
@@ -509,12 +509,19 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     const float *vmDev = matrix_arg(viewMat, vmHold, cam.viewmat);
     const float *pmDev = matrix_arg(projMat, pmHold, cam.projmat);
     Tensor v_means = torch::empty({N, 3}, f32), v_scales = torch::empty({N, 3}, f32);
-    Tensor v_quats = torch::empty({N, 4}, f32);
-    check_status(gs_project_backward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(logScales),
-                                     fptr(quats), radii.data_ptr<int32_t>(), fptr(v_xy), nullptr,
-                                     fptr(v_conic), fptr_mut(v_means), fptr_mut(v_scales),
-                                     fptr_mut(v_quats), s),
-                 "gs_project_backward");
+    Tensor v_quats = torch::empty({N, 4}, f32), v_opacity = torch::empty({N, 1}, f32);
+    Tensor v_dc = torch::empty({N, 3}, f32);
+    Tensor v_rest = K > 1 ? torch::empty({N, K - 1, 3}, f32) : Tensor();
+    if (N > 0)
+        check_status(gs_gaussian_backward(&cam, vmDev, pmDev, (int)N, (int)K,
+                                          (int)ctx->saved_data["degreesToUse"].toInt(), fptr(means),
+                                          fptr(logScales), fptr(quats), fptr(opacityLogits), cp,
+                                          radii.data_ptr<int32_t>(), fptr(rgbRaw), ws.data_ptr(), wsBytes,
+                                          fptr_mut(v_means), fptr_mut(v_scales), fptr_mut(v_quats),
+                                          fptr_mut(v_opacity), fptr_mut(v_dc),
+                                          K > 1 ? fptr_mut(v_rest) : nullptr,
+                                          v_xy.defined() ? fptr_mut(v_xy) : nullptr, flags, s),
+                     "gs_gaussian_backward");
     Tensor none;
     return {v_means, v_scales, v_quats, v_opacity, v_dc, v_rest, none, none, none, none, none, none,
             none, none, none, none, none, none};
