@@ -246,9 +246,7 @@ class Pipeline:
         self.num_isects = b.num_isects
         if events is not None:
             events.extend(ev_local)
-        w1 = self.dist.allreduce_sh_async(self.grads)
-        w2 = self.dist.allreduce_rest_async(self.grads)
-        self.dist.wait_all(w1, w2)
+        self.dist.wait_all(self.dist.allreduce_all_async(self.grads))
         if events is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()

@@ -85,6 +85,14 @@ def allreduce_rest_async(buf: GradBuffer):
     return dist.all_reduce(buf.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
 
 
+def allreduce_all_async(buf: GradBuffer):
+    """The whole flat buffer in ONE collective: what the fused per-Gaussian backward wants, since it
+    delivers all six gradient tensors at once (one 236 MB message at C2 instead of 204 + 32)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    return dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def wait_all(*works) -> None:
     for w in works:
         if w is not None:

@@ -137,9 +137,7 @@ class Trainer:
         cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
                                cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws, self.gout, flags,
                                v_xy=self.v_xy)
-        w1 = dist.allreduce_sh_async(self.grads)
-        w2 = dist.allreduce_rest_async(self.grads)
-        dist.wait_all(w1, w2)
+        dist.wait_all(dist.allreduce_all_async(self.grads))
 
     def adam_groups(self):
         P, G, M, V = self.params, self.grads, self.exp_avg, self.exp_avg_sq

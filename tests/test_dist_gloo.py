@@ -14,7 +14,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, N, K, q):
+def _worker(rank, world, port, N, K, q, one_collective=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from opensplat_amd import dist as gdist
@@ -29,21 +29,29 @@ def _worker(rank, world, port, N, K, q):
         buf.v_means[N // 2:] = 0
     else:
         buf.v_means[: N // 2] = 0
-    w1 = gdist.allreduce_sh_async(buf)
-    # ... projection backward would run here, overlapping w1 ...
-    w2 = gdist.allreduce_rest_async(buf)
-    gdist.wait_all(w1, w2)
+    if one_collective:   # the fused per-Gaussian backward delivers everything at once
+        gdist.wait_all(gdist.allreduce_all_async(buf))
+    else:
+        w1 = gdist.allreduce_sh_async(buf)
+        # ... projection backward would run here, overlapping w1 ...
+        w2 = gdist.allreduce_rest_async(buf)
+        gdist.wait_all(w1, w2)
     q.put((rank, buf.flat.numpy().tobytes()))  # bytes: no shared-memory handles to outlive us
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_allreduce_of_flat_grad_buffer_world2():
+import pytest
+
+
+@pytest.mark.parametrize("one_collective", [False, True], ids=["two_blocks", "one_collective"])
+def test_allreduce_of_flat_grad_buffer_world2(one_collective):
     N, K, world = 257, 16, 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, K, q, one_collective))
+             for r in range(world)]
     for p in procs:
         p.start()
     import numpy as np
@@ -75,6 +83,6 @@ def test_single_process_is_noop():
 
     buf = gdist.GradBuffer(5, 4, torch.device("cpu"))
     buf.flat.fill_(3.0)
-    assert gdist.allreduce_sh_async(buf) is None
+    assert gdist.allreduce_sh_async(buf) is None and gdist.allreduce_all_async(buf) is None
     gdist.allreduce_grads(buf)
     assert (buf.flat == 3.0).all()
