@@ -119,7 +119,8 @@ def main():
     torch.cuda.synchronize()
 
     init = sfm_like_init(gt_params, a.init_points, K, rs)
-    T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train)
+    T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
+                      morton_order=True)
     sh_interval = max(a.iters // 4, 1)          # --sh-degree-interval 1000 at 3000+ iterations
 
     def evaluate():
