@@ -401,3 +401,110 @@ extern "C" int ref_save_splat(const char *filename, int numPoints, const float *
         return -1;
     }
 }
+
+// ---- COLMAP poses, camera set-up, model initialisation --------------------------
+// quatToRotMat and autoScaleAndCenterPoses are the reference's own (tensor_math.cpp, compiled in place);
+// the statements of colmap.cpp:88-118 (pose of one image record), model.cpp:35-47,85-113 (projection
+// matrix, camera block of Model::forward) and model.cpp:23-33 + model.hpp:37,41 (random quaternions)
+// are restated verbatim: colmap.cpp / model.cpp include OpenCV headers and cannot be compiled here.
+#include "constants.hpp"
+
+extern "C" int ref_quat_to_rotmat(const float *q4, float *R9) {
+    try {
+        torch::Tensor R = quatToRotMat(tf(q4, {4}));
+        out_f(R, R9);
+        return 0;
+    } catch (const std::exception &e) { g_train_err = e.what(); return -1; }
+}
+
+extern "C" int ref_colmap_pose(const double *q, const double *t, float *pose16) {
+    try {
+        torch::Tensor qVec = torch::tensor({q[0], q[1], q[2], q[3]}, torch::kFloat32);
+        torch::Tensor R = quatToRotMat(qVec);
+        torch::Tensor T = torch::tensor({{t[0]}, {t[1]}, {t[2]}}, torch::kFloat32);
+        torch::Tensor Rinv = R.transpose(0, 1);
+        torch::Tensor Tinv = torch::matmul(-Rinv, T);
+        torch::Tensor pose = torch::zeros({4, 4}, torch::kFloat32);
+        pose.index_put_({Slice(None, 3), Slice(None, 3)}, Rinv);
+        pose.index_put_({Slice(None, 3), Slice(3, 4)}, Tinv);
+        pose[3][3] = 1.0f;
+        // Convert COLMAP's camera CRS (OpenCV) to OpenGL
+        pose.index_put_({Slice(0, 3), Slice(1, 3)}, pose.index({Slice(0, 3), Slice(1, 3)}) * -1.0f);
+        out_f(pose, pose16);
+        return 0;
+    } catch (const std::exception &e) { g_train_err = e.what(); return -1; }
+}
+
+extern "C" int ref_auto_scale_and_center(int n, const float *poses_in, float *poses_out, float *center3,
+                                         float *scale) {
+    try {
+        torch::Tensor poses = tf(poses_in, {n, 4, 4});
+        auto r = autoScaleAndCenterPoses(poses);
+        out_f(std::get<0>(r), poses_out);
+        out_f(std::get<1>(r), center3);
+        *scale = std::get<2>(r);
+        return 0;
+    } catch (const std::exception &e) { g_train_err = e.what(); return -1; }
+}
+
+// model.cpp:85-113: out8 = {fx, fy, cx, cy, height, width, fovX, fovY}; projview = projMat @ viewMat (:152)
+extern "C" int ref_render_camera(const float *camToWorld16, float camFx, float camFy, float camCx, float camCy,
+                                 int camHeight, int camWidth, float scaleFactor, float *view16,
+                                 float *projview16, float *out8) {
+    try {
+        torch::Tensor camToWorld = tf(camToWorld16, {4, 4});
+        const float fx = camFx / scaleFactor;
+        const float fy = camFy / scaleFactor;
+        const float cx = camCx / scaleFactor;
+        const float cy = camCy / scaleFactor;
+        const int height = static_cast<int>(static_cast<float>(camHeight) / scaleFactor);
+        const int width = static_cast<int>(static_cast<float>(camWidth) / scaleFactor);
+        torch::Tensor R = camToWorld.index({Slice(None, 3), Slice(None, 3)});
+        torch::Tensor T = camToWorld.index({Slice(None, 3), Slice(3, 4)});
+        R = torch::matmul(R, torch::diag(torch::tensor({1.0f, -1.0f, -1.0f})));
+        torch::Tensor Rinv = R.transpose(0, 1);
+        torch::Tensor Tinv = torch::matmul(-Rinv, T);
+        torch::Tensor viewMat = torch::eye(4);
+        viewMat.index_put_({Slice(None, 3), Slice(None, 3)}, Rinv);
+        viewMat.index_put_({Slice(None, 3), Slice(3, 4)}, Tinv);
+        float fovX = 2.0f * std::atan(width / (2.0f * fx));
+        float fovY = 2.0f * std::atan(height / (2.0f * fy));
+        const float zNear = 0.001f, zFar = 1000.0f;   // projectionMatrix, model.cpp:35-47
+        float t = zNear * std::tan(0.5f * fovY);
+        float b = -t;
+        float r = zNear * std::tan(0.5f * fovX);
+        float l = -r;
+        torch::Tensor projMat = torch::tensor({
+            {2.0f * zNear / (r - l), 0.0f, (r + l) / (r - l), 0.0f},
+            {0.0f, 2 * zNear / (t - b), (t + b) / (t - b), 0.0f},
+            {0.0f, 0.0f, (zFar + zNear) / (zFar - zNear), -1.0f * zFar * zNear / (zFar - zNear)},
+            {0.0f, 0.0f, 1.0f, 0.0f}});
+        out_f(viewMat, view16);
+        out_f(torch::matmul(projMat, viewMat), projview16);
+        const float o[8] = {fx, fy, cx, cy, (float)height, (float)width, fovX, fovY};
+        std::memcpy(out8, o, sizeof(o));
+        return 0;
+    } catch (const std::exception &e) { g_train_err = e.what(); return -1; }
+}
+
+// model.hpp:37,41 + model.cpp:23-33, and rgb2sh (spherical_harmonics.cpp, compiled) of model.hpp:46
+extern "C" int ref_model_init(int n, const uint8_t *rgb, float *quats_out, float *features_dc_out,
+                              float *opacity_out) {
+    try {
+        torch::manual_seed(42);
+        torch::Tensor u = torch::rand(n);
+        torch::Tensor v = torch::rand(n);
+        torch::Tensor w = torch::rand(n);
+        torch::Tensor quats = torch::stack({torch::sqrt(1 - u) * torch::sin(2 * PI * v),
+                                            torch::sqrt(1 - u) * torch::cos(2 * PI * v),
+                                            torch::sqrt(u) * torch::sin(2 * PI * w),
+                                            torch::sqrt(u) * torch::cos(2 * PI * w)}, -1);
+        torch::Tensor colors = torch::from_blob(const_cast<uint8_t *>(rgb), {n, 3}, torch::kUInt8).clone();
+        torch::Tensor dc = rgb2sh(colors.toType(torch::kFloat64) / 255.0).toType(torch::kFloat32);
+        torch::Tensor op = torch::logit(0.1f * torch::ones({n, 1}));
+        out_f(quats, quats_out);
+        out_f(dc, features_dc_out);
+        out_f(op, opacity_out);
+        return 0;
+    } catch (const std::exception &e) { g_train_err = e.what(); return -1; }
+}

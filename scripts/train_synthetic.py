@@ -89,6 +89,18 @@ def sfm_like_init(gt, n, K, rs):
             np.zeros((n, K - 1, 3), f)]
 
 
+def rotmat_to_quat(R):
+    """[w, x, y, z] of a rotation matrix (COLMAP's qvec)."""
+    R = np.asarray(R, np.float64)
+    w = math.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    x = math.sqrt(max(0.0, 1.0 + R[0, 0] - R[1, 1] - R[2, 2])) / 2.0
+    y = math.sqrt(max(0.0, 1.0 - R[0, 0] + R[1, 1] - R[2, 2])) / 2.0
+    z = math.sqrt(max(0.0, 1.0 - R[0, 0] - R[1, 1] + R[2, 2])) / 2.0
+    x = math.copysign(x, R[2, 1] - R[1, 2]); y = math.copysign(y, R[0, 2] - R[2, 0])
+    z = math.copysign(z, R[1, 0] - R[0, 1])
+    return np.array([w, x, y, z])
+
+
 def psnr(a, b):
     mse = float(((a - b) ** 2).mean())
     return 10.0 * math.log10(1.0 / max(mse, 1e-12))
@@ -102,6 +114,10 @@ def main():
     ap.add_argument("--width", type=int, default=384)
     ap.add_argument("--height", type=int, default=288)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--via-colmap", action="store_true",
+                    help="write the capture as a COLMAP project (sparse/0/*.bin + images/*.npy) and train "
+                         "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
+                         "Model-style initialisation from the sparse points (row f3)")
     a = ap.parse_args()
     rs = np.random.RandomState(0)
     K, W, H = 16, a.width, a.height
@@ -119,6 +135,24 @@ def main():
     torch.cuda.synchronize()
 
     init = sfm_like_init(gt_params, a.init_points, K, rs)
+    if a.via_colmap:
+        from opensplat_amd import colmap
+        tmp = tempfile.mkdtemp(prefix="capture_")
+        os.makedirs(os.path.join(tmp, "images"))
+        ccams, w2c = [], []
+        for i, (c, img) in enumerate(zip(cams, images)):
+            np.save(os.path.join(tmp, "images", "%05d.npy" % i),
+                    np.clip(np.rint(img.cpu().numpy() * 255.0), 0, 255).astype(np.uint8))
+            ccams.append(colmap.Camera(id=i + 1, width=W, height=H, fx=c["fx"], fy=c["fy"], cx=c["cx"], cy=c["cy"]))
+            w2c.append((rotmat_to_quat(c["viewmat"][:3, :3]), c["viewmat"][:3, 3]))
+        rgb8 = np.clip(np.rint((init[4] * C0 + 0.5) * 255.0), 0, 255).astype(np.uint8)
+        colmap.write_colmap(tmp, ccams, w2c, init[0], rgb8)
+        data = colmap.read_colmap(tmp)
+        for c in data.cameras:
+            colmap.load_image(c)
+        cams = [colmap.render_camera(c) for c in data.cameras]
+        images = [torch.from_numpy(c.image).to(DEV) for c in data.cameras]
+        init = colmap.init_from_points(data.points_xyz, data.points_rgb, sh_degree=3)
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
                       morton_order=True)
     sh_interval = max(a.iters // 4, 1)          # --sh-degree-interval 1000 at 3000+ iterations
@@ -173,6 +207,7 @@ def main():
     out = {"workload": f"synthetic capture: {a.gt_gaussians} ground-truth Gaussians, {n_train} training + "
                        f"{n_test} held-out cameras at {W}x{H}, SH degree 3; {a.init_points} initial points; "
                        f"{a.iters} iterations with the reference's densification defaults",
+           "input": "COLMAP project on disk (opensplat_amd.colmap)" if a.via_colmap else "in-memory capture",
            "psnr_curve": curve, "refinements": refinements, "final_gaussians": T.N,
            "train_seconds": train_time, "iterations_per_s": a.iters / train_time,
            "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,

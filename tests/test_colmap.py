@@ -1,0 +1,172 @@
+"""CPU: SURVEY.md §8 row f3 — COLMAP ingest, camera set-up and model initialisation
+(opensplat_amd/colmap.py) against the reference's own tensor_math.cpp and the restated statements of
+colmap.cpp / model.cpp in oracle/ref_train_shim.cpp (live, where oracle/_ref is built), and against
+COLMAP's binary layout through hand-packed records and a write / read round trip."""
+import ctypes as C
+import math
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from opensplat_amd import colmap
+
+F = C.POINTER(C.c_float)
+fp = lambda a: a.ctypes.data_as(F)
+
+
+def rand_poses(n, seed):
+    rs = np.random.RandomState(seed)
+    q = rs.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = rs.uniform(-5, 5, (n, 3))
+    return q, t
+
+
+def test_pose_math_matches_the_reference(reference):
+    l = reference.lib
+    q, t = rand_poses(12, 1)
+    poses = []
+    for i in range(12):
+        R = np.zeros(9, np.float32)
+        qf = q[i].astype(np.float32) * np.float32(1.7)          # un-normalised in
+        assert l.ref_quat_to_rotmat(fp(qf), fp(R)) == 0
+        assert np.abs(colmap.quat_to_rotmat(qf) - R.reshape(3, 3)).max() < 2e-7
+        p = np.zeros(16, np.float32)
+        assert l.ref_colmap_pose(q[i].ctypes.data_as(C.POINTER(C.c_double)),
+                                 t[i].ctypes.data_as(C.POINTER(C.c_double)), fp(p)) == 0
+        mine = colmap.colmap_pose(q[i], t[i])
+        assert np.abs(mine - p.reshape(4, 4)).max() < 2e-6
+        poses.append(p.reshape(4, 4))
+    poses = np.stack(poses)
+    out = np.zeros_like(poses); c = np.zeros(3, np.float32); s = C.c_float()
+    assert l.ref_auto_scale_and_center(12, fp(np.ascontiguousarray(poses)), fp(out), fp(c), C.byref(s)) == 0
+    mp, mc, ms = colmap.auto_scale_and_center_poses(poses)
+    assert np.abs(mp - out).max() < 1e-6 and np.abs(mc - c).max() < 1e-6 and abs(ms - s.value) < 1e-6 * s.value
+    assert np.abs(mp[:, :3, 3]).max() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_render_camera_matches_model_forward(reference):
+    l = reference.lib
+    q, t = rand_poses(5, 2)
+    poses, _, _ = colmap.auto_scale_and_center_poses(np.stack([colmap.colmap_pose(a, b) for a, b in zip(q, t)]))
+    for i, ds in enumerate([1.0, 2.0, 4.0, 1.0, 8.0]):
+        cam = colmap.Camera(id=1, width=1957, height=1091, fx=1500.5, fy=1480.25, cx=980.0, cy=540.5,
+                            cam_to_world=poses[i])
+        v = np.zeros(16, np.float32); pv = np.zeros(16, np.float32); o = np.zeros(8, np.float32)
+        assert l.ref_render_camera(fp(np.ascontiguousarray(poses[i])), C.c_float(cam.fx), C.c_float(cam.fy),
+                                   C.c_float(cam.cx), C.c_float(cam.cy), cam.height, cam.width,
+                                   C.c_float(ds), fp(v), fp(pv), fp(o)) == 0
+        r = colmap.render_camera(cam, ds)
+        assert (r["H"], r["W"]) == (int(o[4]), int(o[5]))
+        assert np.allclose([r["fx"], r["fy"], r["cx"], r["cy"]], o[:4], rtol=1e-7)
+        assert np.abs(r["viewmat"] - v.reshape(4, 4)).max() < 1e-6
+        assert np.abs(r["projmat"] - pv.reshape(4, 4)).max() < 1e-5 * np.abs(pv).max()
+
+
+def test_init_from_points_matches_the_reference_constructor(reference):
+    l = reference.lib
+    rs = np.random.RandomState(3)
+    n = 500
+    xyz = rs.uniform(-1, 1, (n, 3)).astype(np.float32)
+    rgb = rs.randint(0, 256, (n, 3)).astype(np.uint8)
+    quats = np.zeros((n, 4), np.float32); dc = np.zeros((n, 3), np.float32); op = np.zeros((n, 1), np.float32)
+    assert l.ref_model_init(n, rgb.ctypes.data_as(C.POINTER(C.c_uint8)), fp(quats), fp(dc), fp(op)) == 0
+    P = colmap.init_from_points(xyz, rgb, sh_degree=3)
+    assert np.array_equal(P[0], xyz)
+    assert np.abs(P[2] - quats).max() < 1e-6           # same torch CPU random stream (seed 42)
+    assert np.abs(P[4] - dc).max() < 1e-6 and np.array_equal(P[3], op)
+    assert P[5].shape == (n, 15, 3) and not P[5].any()
+    # scales: mean distance to the three nearest neighbours, brute force
+    d = np.sqrt(((xyz[:, None, :] - xyz[None, :, :]) ** 2).sum(-1))
+    d.sort(axis=1)
+    want = np.log(d[:, 1:4].mean(1))
+    assert np.abs(P[1][:, 0] - want).max() < 1e-4 and np.array_equal(P[1][:, 0], P[1][:, 2])
+
+
+def make_dataset(root, n_img=6, with_sparse=True):
+    rs = np.random.RandomState(5)
+    q, t = rand_poses(n_img, 7)
+    cams = [colmap.Camera(id=3, width=64, height=48, fx=70.0, fy=71.0, cx=32.0, cy=24.0)] * n_img
+    pts = rs.uniform(-2, 2, (40, 3))
+    rgb = rs.randint(0, 256, (40, 3))
+    colmap.write_colmap(root, cams, list(zip(q, t)), pts, rgb)
+    return q, t, pts, rgb
+
+
+def test_colmap_round_trip_and_layout(tmp_path):
+    q, t, pts, rgb = make_dataset(str(tmp_path))
+    d = colmap.read_colmap(str(tmp_path))                # finds sparse/0 (colmap.cpp:14-16)
+    assert len(d.cameras) == 6 and d.points_xyz.shape == (40, 3)
+    assert np.array_equal(d.points_rgb, rgb.astype(np.uint8))
+    poses = np.stack([colmap.colmap_pose(a, b) for a, b in zip(q, t)])
+    norm, center, scale = colmap.auto_scale_and_center_poses(poses)
+    for c, p in zip(d.cameras, norm):
+        assert np.array_equal(c.cam_to_world, p)
+        assert (c.width, c.height, c.fx, c.fy) == (64, 48, 70.0, 71.0)
+        assert c.file_path.startswith(os.path.join(str(tmp_path), "images"))
+    assert np.allclose(d.points_xyz, (pts.astype(np.float32) - center) * np.float32(scale), atol=1e-6)
+    # the published layout, by hand: one SIMPLE_RADIAL camera record
+    rec = struct.pack("<Q", 1) + struct.pack("<IiQQ4d", 9, colmap.SIMPLE_RADIAL, 100, 80, 55.0, 50.0, 40.0, 0.01)
+    open(tmp_path / "sparse" / "0" / "cameras.bin", "wb").write(rec)
+    with pytest.raises(KeyError):                        # images reference camera 3, file now has 9
+        colmap.read_colmap(str(tmp_path))
+    # unsupported model id -> error like the reference's runtime_error
+    open(tmp_path / "sparse" / "0" / "cameras.bin", "wb").write(
+        struct.pack("<Q", 1) + struct.pack("<IiQQ", 1, 7, 10, 10))
+    with pytest.raises(ValueError):
+        colmap.read_colmap(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        colmap.read_colmap(str(tmp_path / "nowhere"))
+
+
+def png_bytes(img, filter_type):
+    h, w, _ = img.shape
+    rows = []
+    prev = np.zeros(w * 3, np.int32)
+    for y in range(h):
+        line = img[y].reshape(-1).astype(np.int32)
+        if filter_type == 0:
+            f = line
+        elif filter_type == 1:
+            f = (line - np.concatenate([np.zeros(3, np.int32), line[:-3]])) & 255
+        elif filter_type == 2:
+            f = (line - prev) & 255
+        else:
+            a = np.concatenate([np.zeros(3, np.int32), line[:-3]])
+            f = (line - ((a + prev) >> 1)) & 255
+        rows.append(bytes([filter_type]) + f.astype(np.uint8).tobytes())
+        prev = line
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b"")
+
+
+def test_image_loading_without_opencv(tmp_path):
+    rs = np.random.RandomState(9)
+    img = rs.randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    np.save(tmp_path / "a.npy", img)
+    open(tmp_path / "a.ppm", "wb").write(b"P6\n# comment\n64 48\n255\n" + img.tobytes())
+    for ft in (0, 1, 2, 3):
+        open(tmp_path / f"f{ft}.png", "wb").write(png_bytes(img, ft))
+        assert np.array_equal(colmap.read_image_u8(str(tmp_path / f"f{ft}.png")), img)
+    assert np.array_equal(colmap.read_image_u8(str(tmp_path / "a.npy")), img)
+    assert np.array_equal(colmap.read_image_u8(str(tmp_path / "a.ppm")), img)
+    # intrinsics follow the image: calibrated at twice the stored resolution, then down-scaled by 2
+    cam = colmap.Camera(id=1, width=128, height=96, fx=140.0, fy=142.0, cx=64.0, cy=48.0,
+                        file_path=str(tmp_path / "a.npy"))
+    colmap.load_image(cam, downscale=2)
+    assert (cam.width, cam.height) == (32, 24) and cam.image.shape == (24, 32, 3)
+    assert (cam.fx, cam.fy, cam.cx, cam.cy) == (35.0, 35.5, 16.0, 12.0)
+    box = img.astype(np.uint32).reshape(24, 2, 32, 2, 3).sum((1, 3))
+    assert np.array_equal(np.rint(cam.image * 255).astype(np.uint32), (box + 2) // 4)
+    dist = colmap.Camera(id=1, width=64, height=48, fx=70, fy=70, cx=32, cy=24, k1=0.1,
+                         file_path=str(tmp_path / "a.npy"))
+    with pytest.raises(NotImplementedError):
+        colmap.load_image(dist)
+    with pytest.raises(ValueError):
+        open(tmp_path / "x.jpg", "wb").write(b"\xff\xd8")
+        colmap.read_image_u8(str(tmp_path / "x.jpg"))
