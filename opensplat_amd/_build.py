@@ -70,9 +70,35 @@ def build_torch(force: bool = False) -> str:
     return TORCH_LIB
 
 
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "simple_trainer_hip.cpp")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "simple_trainer_hip")
+
+
+def build_example(force: bool = False) -> str:
+    """examples/simple_trainer_hip: a C++ caller of gsplat_ops.hpp (BASELINE config 1), linked
+    against the two in-tree libraries only."""
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    deps = [EXAMPLE_SRC, os.path.join(CSRC, "gsplat_ops.hpp"), TORCH_LIB]
+    if force or _stale(EXAMPLE_BIN, deps):
+        _run(["g++", "-std=c++17", "-O2", "-w",
+              "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+              "-I" + CSRC, "-I" + os.path.join(tdir, "include"),
+              "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+              EXAMPLE_SRC, "-o", EXAMPLE_BIN,
+              "-Wl,--no-as-needed",   # keep the torch libraries as direct dependencies of the program
+              "-L" + CSRC, "-lgsplat_torch", "-lgsplat_hip",
+              "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
+              "-lc10_hip", "-Wl,--disable-new-dtags",   # RPATH, so that it also serves libgsplat_torch.so's deps
+              "-Wl,-rpath," + CSRC, "-Wl,-rpath," + os.path.join(tdir, "lib")])
+    return EXAMPLE_BIN
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_torch(force)
+    build_example(force)
 
 
 if __name__ == "__main__":
