@@ -58,7 +58,8 @@ class Trainer:
                  warmup_length: int = 500, reset_alpha_every: int = 30,
                  densify_grad_thresh: float = 0.0002, densify_size_thresh: float = 0.01,
                  stop_screen_size_at: int = 4000, split_screen_size: float = 0.05,
-                 num_cameras: int = 1, morton_order: bool = False):
+                 num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
+                 resolution_schedule: int = 3000, sh_degree_interval: int = 1000):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -82,6 +83,8 @@ class Trainer:
         self.densify_grad_thresh, self.densify_size_thresh = densify_grad_thresh, densify_size_thresh
         self.stop_screen_size_at, self.split_screen_size = stop_screen_size_at, split_screen_size
         self.num_cameras = num_cameras
+        self.num_downscales, self.resolution_schedule = num_downscales, resolution_schedule
+        self.sh_degree_interval = sh_degree_interval
         # re-sort the Gaussians along a 3-D Morton curve whenever a refinement rebuilds the tensors:
         # neighbours in space become neighbours in memory (binning scatter and the per-Gaussian
         # kernels gain locality: +1..3 % per iteration at 1 M Gaussians)
@@ -92,6 +95,16 @@ class Trainer:
         self._shape = None
         self.world = torch.distributed.get_world_size() if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+
+    def degrees_to_use(self, step: int) -> int:
+        """model.cpp:178: one more SH degree every sh_degree_interval steps."""
+        sh_degree = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[self.K]
+        return min(step // self.sh_degree_interval, sh_degree)
+
+    def downscale_factor(self, step: int) -> int:
+        """Model::getDownscaleFactor (model.cpp:249-251): training starts on images reduced by
+        2^num_downscales and doubles the resolution every resolution_schedule steps."""
+        return 2 ** max(self.num_downscales - step // self.resolution_schedule, 0)
 
     # the six tensors, as views of the flat parameter buffer
     means = property(lambda s: s.params.v_means)

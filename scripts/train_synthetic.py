@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--width", type=int, default=384)
     ap.add_argument("--height", type=int, default=288)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--num-downscales", type=int, default=2)
     ap.add_argument("--via-colmap", action="store_true",
                     help="write the capture as a COLMAP project (sparse/0/*.bin + images/*.npy) and train "
                          "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
@@ -153,9 +154,34 @@ def main():
         cams = [colmap.render_camera(c) for c in data.cameras]
         images = [torch.from_numpy(c.image).to(DEV) for c in data.cameras]
         init = colmap.init_from_points(data.points_xyz, data.points_rgb, sh_degree=3)
+    # schedules scaled to the run: the CLI defaults (--sh-degree-interval 1000, --num-downscales 2,
+    # --resolution-schedule 3000) are meant for 30 000 iterations
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
-                      morton_order=True)
-    sh_interval = max(a.iters // 4, 1)          # --sh-degree-interval 1000 at 3000+ iterations
+                      morton_order=True, sh_degree_interval=max(a.iters // 4, 1),
+                      num_downscales=a.num_downscales, resolution_schedule=max(a.iters // 6, 1))
+    sh_interval = T.sh_degree_interval
+
+    def reduced(cam, f):
+        """Camera block of Model::forward at scaleFactor f (model.cpp:85-92)."""
+        if f == 1:
+            return cam
+        c = dict(cam)
+        c.update(fx=cam["fx"] / f, fy=cam["fy"] / f, cx=cam["cx"] / f, cy=cam["cy"] / f,
+                 W=int(cam["W"] / f), H=int(cam["H"] / f))
+        fovx, fovy = 2.0 * math.atan(c["W"] / (2.0 * c["fx"])), 2.0 * math.atan(c["H"] / (2.0 * c["fy"]))
+        c["projmat"] = (scenes.projection_matrix(0.001, 1000.0, fovx, fovy) @ cam["viewmat"]).astype(np.float32)
+        return c
+
+    pyramid = {}
+
+    def target(ci, f):
+        """Camera::getImage(downscaleFactor) (input_data.cpp:96-114): area-averaged pyramid, cached."""
+        if f == 1:
+            return images[ci]
+        if (ci, f) not in pyramid:
+            img = images[ci][: (H // f) * f, : (W // f) * f].permute(2, 0, 1)[None]
+            pyramid[(ci, f)] = torch.nn.functional.avg_pool2d(img, f)[0].permute(1, 2, 0).contiguous()
+        return pyramid[(ci, f)]
 
     def evaluate():
         vals = []
@@ -172,8 +198,9 @@ def main():
     train_time = 0.0
     for step in range(1, a.iters + 1):
         ci = int(order.randint(0, n_train))
-        deg = min(step // sh_interval, 3)        # model.cpp:85 degreesToUse
-        loss = T.train_step(cams[ci], images[ci], bg, deg)
+        deg = T.degrees_to_use(step)             # model.cpp:178
+        f = T.downscale_factor(step)             # model.cpp:249-251
+        loss = T.train_step(reduced(cams[ci], f), target(ci, f), bg, deg)
         if step % max(a.iters // 6, 1) == 0:
             last_loss = [float(x) for x in loss.cpu()]   # before a refinement reallocates buffers
         c = T.after_train(step)
