@@ -77,3 +77,28 @@ def test_sh_helpers():
     assert [ops.deg_from_sh(k) for k in (1, 4, 9, 16, 25)] == [0, 1, 2, 3, 4]
     rgb = torch.tensor([0.0, 0.25, 1.0])
     assert torch.allclose(ops.sh2rgb(ops.rgb2sh(rgb)), rgb, atol=1e-6)
+
+
+def test_trainer_schedules_and_morton_permutation_on_cpu():
+    """Host logic of opensplat_amd.train that needs no GPU: the reference's SH-degree and resolution
+    schedules (model.cpp:178, 249-251) and the Z-order permutation used at refinement."""
+    import types
+
+    import torch
+
+    from opensplat_amd import train
+
+    T = types.SimpleNamespace(K=16, sh_degree_interval=1000, num_downscales=2, resolution_schedule=3000)
+    assert [train.Trainer.degrees_to_use(T, s) for s in (1, 999, 1000, 2500, 3000, 30000)] == [0, 0, 1, 2, 3, 3]
+    assert [train.Trainer.downscale_factor(T, s) for s in (1, 2999, 3000, 5999, 6000, 30000)] == [4, 4, 2, 2, 1, 1]
+    T.K = 4
+    assert train.Trainer.degrees_to_use(T, 30000) == 1
+    g = torch.Generator().manual_seed(0)
+    means = torch.rand((4096, 3), generator=g)
+    perm = train.morton_permutation(means)
+    assert sorted(perm.tolist()) == list(range(4096))
+    m = means[perm]
+    assert (m[1:] - m[:-1]).norm(dim=1).mean() < 0.3 * (means[1:] - means[:-1]).norm(dim=1).mean()
+    # points in the same octant of the bounding box stay together
+    octant = ((m > 0.5).long() * torch.tensor([1, 2, 4])).sum(1)
+    assert (octant[1:] != octant[:-1]).sum() <= 7
