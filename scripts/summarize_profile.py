@@ -115,7 +115,9 @@ def main():
             traffic[m.group(1)] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
     traffic["_source"] = f"profiles/{tag}_pmc.json (FETCH_SIZE x 2 KiB-units corrected + WRITE_SIZE)"
     # the row-f2 kernels (scripts/profile_f2.sh, tags f2*) keep their own file
-    tname = "traffic_f2.json" if tag.startswith("f2") else "traffic.json"
+    # ... and so do profiles of the non-default configurations (tags like r01i_c3)
+    tname = "traffic_f2.json" if tag.startswith("f2") else \
+        ("traffic_%s.json" % tag.split("_", 1)[1] if "_" in tag else "traffic.json")
     (dst / tname).write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
     print("\n".join(lines))
 
