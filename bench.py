@@ -438,13 +438,17 @@ def main():
         dom_bytes = per_stage["rasterize_bwd" if dom == "k_rasterize_backward" else "rasterize_fwd"]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # the PMC passes are collected on the default command (C2 / C4 per-rank workload, parity exp)
-        default_workload = (scene.N == 1_000_000 and scene.W == 1920 and scene.H == 1080
-                            and not args.fast_exp and not args.hot)
-        if os.path.exists(tpath) and default_workload:
+        # and on --config c3; other workloads carry no measured traffic
+        plain = not args.fast_exp and not args.hot and args.order == "given" and not args.stage_kernels
+        tname = None
+        if plain and scene.N == 1_000_000 and scene.W == 1920 and scene.H == 1080:
+            tname = "traffic.json"
+        elif plain and scene.N == 5_000_000 and scene.W == 3840 and scene.H == 2160:
+            tname = "traffic_c3.json"
+        if tname and os.path.exists(os.path.join(ROOT, "profiles", tname)):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(os.path.join(ROOT, "profiles", tname))).get(dom)
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
