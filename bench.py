@@ -480,6 +480,9 @@ def main():
                                  "required; traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch "
                                  "from profiles/"},
             "kernel_ms": kernel_ms,
+            # pixel x Gaussian evaluations per second of the compositing kernels, counted
+            # as 256 pixels per (tile, Gaussian) list entry (the upper bound both kernels are sized by)
+            "pixel_gaussian_evals_per_s": {k: 256.0 * M / (v * 1e-3) for k, v in kernel_ms.items() if v > 0},
             "event_sampled_steps": len(all_events),
             "path_roofline": {"algorithmic_bytes": total_bytes,
                               "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
