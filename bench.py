@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--order", default="given", choices=["given", "morton", "tile"],
                     help="EXPERIMENT: permute the scene's Gaussians before the run — 3-D Morton order "
                          "of the means, or by the 16x16 tile of the projected centre (upper bound)")
+    ap.add_argument("--train-cpu-baselines", action="store_true",
+                    help="time the reference's CPU code for the training-step rows (mainLoss, Adam, one "
+                         "iteration's render + loss of scripts/train_synthetic.py's initial set), print "
+                         "one JSON object and exit; needs no GPU")
     ap.add_argument("--stage-kernels", action="store_true",
                     help="run projection / SH / pack and their backwards as separate kernels "
                          "(operator granularity) instead of the fused per-Gaussian kernels")
@@ -280,6 +284,58 @@ def reorder_scene(s, how):
             setattr(s, name, np.ascontiguousarray(a[perm]))
 
 
+def train_cpu_baselines():
+    """cpu_baseline leg for rows f2 / f4 / the end-to-end run: the reference's own code (oracle/_ref:
+    ssim.cpp, libtorch Adam, the gsplat-cpu operator chain) on this host's cores, bounded samples."""
+    import importlib.util
+
+    import torch
+
+    import oracle
+    from opensplat_amd import scenes
+
+    if not oracle.have_reference():
+        return {"error": "oracle/_ref is not built"}
+    R = oracle.reference()
+    out = {"kind": "reference", "threads_torch": torch.get_num_threads(), "cores": os.cpu_count()}
+    W, H = 1920, 1080
+    rendered, gt = scenes.loss_images(W, H, seed=1)
+    R.main_loss(rendered[:270], gt[:270], 0.2)                 # warm-up on a quarter frame
+    R.main_loss(rendered, gt, 0.2)
+    out["main_loss_1080p_ms"] = R.last_ms
+    n, total = 4_000_000, 59_000_000
+    p0, grads = scenes.adam_problem(n, 3, 1)
+    t0 = time.time()
+    R.adam_steps(p0, grads, 0.005)
+    out["adam_ms_per_59M_params"] = (time.time() - t0) / 3 * 1e3 * total / n
+    out["adam_sample"] = "3 libtorch Adam steps over %d parameters, scaled to 59 M" % n
+    # one iteration's render + loss on the initial set of scripts/train_synthetic.py
+    spec = importlib.util.spec_from_file_location("train_synthetic",
+                                                  os.path.join(ROOT, "scripts", "train_synthetic_inputs.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    rs = np.random.RandomState(0)
+    Wc, Hc, K, n_init = 384, 288, 16, 6000
+    cam = ts.make_camera((3.5, 0.0, 0.0), Wc, Hc)
+    gt_params = ts.ground_truth(20000, K, rs)
+    means, ls, q, lo, dc, rest = ts.sfm_like_init(gt_params, n_init, K, rs)
+    vm = cam["viewmat"]
+    cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)
+    dirs = means - cam_pos
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    coeffs = np.concatenate([dc[:, None, :], rest], 1)
+    v = np.random.RandomState(2).uniform(-1e-4, 1e-4, (Hc, Wc, 3)).astype(np.float32)
+    r = R.chain_fwd_bwd(means, np.exp(ls), q / np.linalg.norm(q, axis=1, keepdims=True), dirs, coeffs,
+                        (1 / (1 + np.exp(-lo))).astype(np.float32), vm, cam["projmat"], cam["fx"], cam["fy"],
+                        cam["cx"], cam["cy"], Hc, Wc, np.zeros(3, np.float32), v, degrees_to_use=3)
+    a, b = scenes.loss_images(Wc, Hc, seed=2)
+    R.main_loss(a, b, 0.2)
+    out["e2e_iteration"] = {"render_fwd_bwd_s": (r["fwd_ms"] + r["bwd_ms"]) / 1e3, "main_loss_s": R.last_ms / 1e3,
+                            "sample": "render + loss of one iteration on the %d-point initial set of "
+                                      "scripts/train_synthetic.py at %dx%d (no optimiser, no growth)" % (n_init, Wc, Hc)}
+    return out
+
+
 def algorithmic_bytes(N, K, M, P):
     """compulsory HBM traffic of one fwd+bwd, and the per-kernel shares used for
     roofline.achieved (stated in DESIGN.md §Measurement)."""
@@ -339,6 +395,9 @@ def cpu_baseline(scene, n_sample):
 
 def main():
     args = parse_args()
+    if args.train_cpu_baselines:
+        print(json.dumps({"cpu_baselines": train_cpu_baselines()}))
+        return
     import torch
 
     from opensplat_amd import cabi, dist, scenes

@@ -4,9 +4,9 @@ the six-group Adam step at N = 1 M Gaussians / SH degree 3 (59 M parameters), HI
 one MI355X, with
   * the same ops as the reference issues them, run by torch on the SAME GPU (grouped conv2d SSIM +
     autograd; torch::optim::Adam's op sequence per group) — what OpenSplat's GPU build executes;
-  * the reference's own code on the host CPU (oracle/_ref: ssim.cpp + libtorch Adam), bounded
-    sample — the `cpu_baseline`.
-Prints one JSON object.  python scripts/bench_train_step.py [--no-cpu]"""
+(the reference's own code on the host CPU is timed by `python bench.py --train-cpu-baselines`, the one
+place outside tests/ that may touch oracle/).
+Prints one JSON object.  python scripts/bench_train_step.py [--ours-only]"""
 import json
 import os
 import sys
@@ -230,23 +230,6 @@ def main():
         out["densify"]["refine_torch_ops_same_gpu_wall_ms"] = torch_refine_ms(P_, M_, V_, gs_, vc_, m2_,
                                                                               prob["width"], prob["height"])
 
-    if "--no-cpu" not in sys.argv:
-        import oracle
-        if oracle.have_reference():
-            R = oracle.reference()
-            R.main_loss(rendered_np[:270], gt_np[:270], 0.2)           # warm-up, quarter frame
-            t0 = time.time()
-            R.main_loss(rendered_np, gt_np, 0.2)
-            out["cpu_baseline_loss"] = {"ms": R.last_ms, "wall_s": time.time() - t0, "kind": "reference",
-                                        "threads_torch": torch.get_num_threads(),
-                                        "sample": f"1 mainLoss forward+backward at {W}x{H}"}
-            n = 4_000_000
-            p0, grads = scenes.adam_problem(n, 3, 1)
-            t0 = time.time()
-            R.adam_steps(p0, grads, 0.005)
-            dt = (time.time() - t0) / 3
-            out["cpu_baseline_adam"] = {"ms_per_59M_params": dt * 1e3 * total / n, "kind": "reference",
-                                        "sample": f"3 libtorch Adam steps over {n} parameters, scaled"}
     print(json.dumps(out))
 
 

@@ -7,10 +7,10 @@ starts, like OpenSplat does from SfM points (model.hpp:33-60), from a noisy subs
 and colours with kNN-derived scales, and runs the reference's loop (opensplat.cpp:151-170) through
 `opensplat_amd.train.Trainer`: Model::forward -> mainLoss (L1 + SSIM) -> backward -> Adam ->
 scheduler -> afterTrain (densification schedule of the CLI defaults).  Reports PSNR on held-out
-cameras, Gaussian count, iterations/s, a PLY save / load round trip, and the reference's CPU path
-timed on the same scene for the wall-clock comparison.
+cameras, Gaussian count, iterations/s and a PLY save / load round trip (the reference's CPU path on
+the same initial set is timed by `python bench.py --train-cpu-baselines`).
 
-  python scripts/train_synthetic.py [--iters 3000] [--no-cpu]   -> one JSON object on stdout
+  python scripts/train_synthetic.py [--iters 3000] [--via-colmap]   -> one JSON object on stdout
 """
 import argparse
 import json
@@ -21,72 +21,14 @@ import tempfile
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from opensplat_amd import io, scenes, train  # noqa: E402
+from train_synthetic_inputs import C0, ground_truth, make_camera, sfm_like_init  # noqa: E402  (scripts/)
 
 DEV = torch.device("cuda:0")
-C0 = 0.28209479177387814
-
-
-def look_at(pos, target=(0.0, 0.0, 0.0)):
-    """World -> camera (x right, y down, z forward: the convention of scenes.py / model.cpp:93-104)."""
-    pos, target = np.asarray(pos, np.float64), np.asarray(target, np.float64)
-    f = target - pos
-    f /= np.linalg.norm(f)
-    r = np.cross(f, np.array([0.0, -1.0, 0.0]))
-    r /= np.linalg.norm(r)
-    d = np.cross(f, r)
-    R = np.stack([r, d, f])
-    vm = np.eye(4, dtype=np.float32)
-    vm[:3, :3] = R
-    vm[:3, 3] = -R @ pos
-    return vm
-
-
-def make_camera(pos, W, H, fov_deg=50.0):
-    fx = fy = 0.5 * W / math.tan(0.5 * math.radians(fov_deg))
-    fovx, fovy = 2.0 * math.atan(W / (2.0 * fx)), 2.0 * math.atan(H / (2.0 * fy))
-    vm = look_at(pos)
-    pm = (scenes.projection_matrix(0.001, 1000.0, fovx, fovy) @ vm).astype(np.float32)
-    return dict(viewmat=vm, projmat=pm, fx=fx, fy=fy, cx=W / 2.0, cy=H / 2.0, W=W, H=H)
-
-
-def ground_truth(n, K, rs):
-    """A few blobs and a shell of small anisotropic Gaussians with position-dependent colour."""
-    centres = rs.uniform(-0.6, 0.6, (6, 3))
-    which = rs.randint(0, 6, n)
-    means = centres[which] + 0.22 * rs.standard_normal((n, 3))
-    shell = rs.rand(n) < 0.3
-    d = rs.standard_normal((n, 3))
-    means[shell] = 0.95 * d[shell] / np.linalg.norm(d[shell], axis=1, keepdims=True)
-    log_scales = np.log(rs.uniform(0.012, 0.05, (n, 1)) * rs.uniform(0.3, 1.0, (n, 3)))
-    quats = scenes.random_quats(rs.rand(n), rs.rand(n), rs.rand(n))
-    logits = rs.normal(1.5, 1.0, (n, 1))
-    rgb = 0.5 + 0.45 * np.sin(3.0 * means + np.array([0.0, 2.0, 4.0]))
-    dc = (rgb - 0.5) / C0
-    rest = 0.03 * rs.standard_normal((n, K - 1, 3))
-    f = np.float32
-    return [means.astype(f), log_scales.astype(f), quats.astype(f), logits.astype(f), dc.astype(f),
-            rest.astype(f)]
-
-
-def sfm_like_init(gt, n, K, rs):
-    """Model's initialisation from points (model.hpp:36-60): means = points, scales = log of the mean
-    distance to the 3 nearest neighbours, random quats, opacity logit(0.1), featuresDc = rgb2sh."""
-    from scipy.spatial import cKDTree
-
-    idx = rs.choice(gt[0].shape[0], n, replace=False)
-    pts = gt[0][idx] + 0.01 * rs.standard_normal((n, 3)).astype(np.float32)
-    rgb = np.clip(gt[4][idx] * C0 + 0.5 + 0.05 * rs.standard_normal((n, 3)), 0.0, 1.0)
-    dist, _ = cKDTree(pts).query(pts, k=4)
-    scale = np.log(np.maximum(dist[:, 1:].mean(1), 1e-4))[:, None].repeat(3, 1)
-    f = np.float32
-    return [pts.astype(f), scale.astype(f),
-            scenes.random_quats(rs.rand(n), rs.rand(n), rs.rand(n)),
-            np.full((n, 1), math.log(0.1 / 0.9), f), ((rgb - 0.5) / C0).astype(f),
-            np.zeros((n, K - 1, 3), f)]
 
 
 def rotmat_to_quat(R):
@@ -240,32 +182,6 @@ def main():
            "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,
            "ply_round_trip_renders_identically": same}
 
-    if not a.no_cpu:
-        import oracle
-        if oracle.have_reference():
-            R = oracle.reference()
-            # the reference's CPU operators on the INITIAL Gaussian set, one camera
-            c = cams[0]
-            means, ls, q, lo, dc, rest = init
-            vm = c["viewmat"]
-            cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)
-            dirs = means - cam_pos
-            dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
-            coeffs = np.concatenate([dc[:, None, :], rest], 1)
-            v = np.random.RandomState(2).uniform(-1e-4, 1e-4, (H, W, 3)).astype(np.float32)
-            t1 = time.time()
-            r = R.chain_fwd_bwd(means, np.exp(ls), q / np.linalg.norm(q, axis=1, keepdims=True), dirs, coeffs,
-                                (1 / (1 + np.exp(-lo))).astype(np.float32), vm, c["projmat"],
-                                c["fx"], c["fy"], c["cx"], c["cy"], H, W, bg, v, degrees_to_use=3)
-            render_s = (r["fwd_ms"] + r["bwd_ms"]) / 1e3
-            R.main_loss(images[0].cpu().numpy(), images[1].cpu().numpy(), 0.2)
-            loss_s = R.last_ms / 1e3
-            out["cpu_baseline"] = {"kind": "reference", "threads_torch": torch.get_num_threads(),
-                                   "render_fwd_bwd_s": render_s, "main_loss_s": loss_s,
-                                   "sample": f"1 iteration's render + loss on the {a.init_points}-point initial set "
-                                             f"(no optimiser, no growth): {render_s + loss_s:.3f} s -> "
-                                             f">= {(render_s + loss_s) * a.iters:.0f} s for {a.iters} iterations",
-                                   "wall_s": time.time() - t1}
     print(json.dumps(out))
 
 
