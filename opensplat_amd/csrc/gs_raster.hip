@@ -672,7 +672,10 @@ namespace gs {
 // 20 % of the tiles split, 463 at 40 %, 531 at 100 %; the backward only loses (733 / 739 / 757 /
 // 866 us) because its per-entry reduction and atomic are paid by both halves — 20 % / 0 %.
 // Experimental overrides for A/B runs: flags bits 8..15 = tail percent + 1, bits 16..17 = mult.
-constexpr int kSplitPercentForward = 20, kSplitPercentBackward = 0;
+// At C3 (32 400 tiles, 587 entries per tile) the tail is a smaller share of the launch: 10 % is best for
+// BOTH kernels there (forward 2155 us vs 2185 at 20 % / 2200 unsplit; backward 2839 vs 2869 unsplit).
+constexpr int kSplitPercentForward = 20, kSplitPercentBackward = 0, kSplitPercentManyTiles = 10;
+constexpr int kManyTiles = 16384;
 static inline Sched make_sched(int tiles, uint32_t flags, int tail_pct, const int32_t *list_stats,
                                const int32_t *tile_order, int &units) {
     Sched sc;
@@ -749,7 +752,8 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
     int units;
-    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentForward, list_stats, tile_order, units);
+    const gs::Sched sched = gs::make_sched(tiles, flags, tiles >= gs::kManyTiles ? gs::kSplitPercentManyTiles : gs::kSplitPercentForward,
+                                           list_stats, tile_order, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
@@ -798,7 +802,8 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     if (!(flags & GS_FLAG_RECORDS_ZEROED))
         GS_HIP_CHECK(hipMemsetAsync(gacc, 0, gs_rasterize_backward_workspace_bytes(N), s));
     int units;
-    const gs::Sched sched = gs::make_sched(tiles, flags, gs::kSplitPercentBackward, list_stats, tile_order, units);
+    const gs::Sched sched = gs::make_sched(tiles, flags, tiles >= gs::kManyTiles ? gs::kSplitPercentManyTiles : gs::kSplitPercentBackward,
+                                           list_stats, tile_order, units);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
