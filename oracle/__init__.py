@@ -71,6 +71,7 @@ class Restated(_Base):
             build(ref=False)
         self.lib = C.CDLL(path)
         self.lib.orc_rasterize_forward.restype = C.c_void_p
+        self.lib.orc_rasterize_forward_window.restype = C.c_void_p
         self.lib.orc_rasterize_total.restype = C.c_int64
         self.lib.orc_rasterize_total.argtypes = [C.c_void_p]
         self.lib.orc_rasterize_contributors.argtypes = [C.c_void_p, _i32p]
@@ -123,13 +124,16 @@ class Restated(_Base):
         return out
 
     def rasterize_forward(self, W, H, xys, conics, colors, opacities, background, cov2d,
-                          cam_depths, want_contributors=True):
+                          cam_depths, want_contributors=True, window=None):
+        """window = (x0, y0, x1, y1): evaluate only those pixels (full-image coordinates)."""
         N = len(xys)
         x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
         bg, bgp = _f(background); c2, c2p = _f(cov2d); cd, cdp = _f(cam_depths)
         img, ip = _fo((H, W, 3)); fT, fp = _fo((H, W)); cnt, cntp = _io((H, W))
-        st = self.lib.orc_rasterize_forward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op,
-                                            bgp, c2p, cdp, ip, fp, cntp)
+        wx0, wy0, wx1, wy1 = window if window is not None else (0, 0, W, H)
+        st = self.lib.orc_rasterize_forward_window(
+            C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp, c2p, cdp, ip, fp, cntp,
+            C.c_int(wx0), C.c_int(wy0), C.c_int(wx1), C.c_int(wy1))
         ids = None
         if want_contributors:
             total = self.lib.orc_rasterize_total(C.c_void_p(st))
@@ -139,13 +143,15 @@ class Restated(_Base):
         return dict(img=img, final_Ts=fT, px_counts=cnt, contributors=ids, state=st)
 
     def rasterize_backward(self, W, H, xys, conics, colors, opacities, background, cov2d,
-                           cam_depths, final_Ts, state, v_out, free=True):
+                           cam_depths, final_Ts, state, v_out, free=True, window=None):
         N = len(xys)
         x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
         bg, bgp = _f(background); fT, fp = _f(final_Ts); vo, vop = _f(v_out)
         vxy, vxyp = _fo((N, 2)); vcn, vcnp = _fo((N, 3)); vco, vcop = _fo((N, 3)); vop_, vopp = _fo((N,))
-        self.lib.orc_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp,
-                                        fp, C.c_void_p(state), vop, None, vxyp, vcnp, vcop, vopp)
+        wx0, wy0, wx1, wy1 = window if window is not None else (0, 0, W, H)
+        self.lib.orc_rasterize_backward_window(
+            C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp, fp, C.c_void_p(state), vop,
+            None, vxyp, vcnp, vcop, vopp, C.c_int(wx0), C.c_int(wy0), C.c_int(wx1), C.c_int(wy1))
         if free:
             self.lib.orc_rasterize_free(C.c_void_p(state))
         return dict(v_xy=vxy, v_conic=vcn, v_colors=vco, v_opacity=vop_)

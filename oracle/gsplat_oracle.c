@@ -407,11 +407,20 @@ void orc_pixel_rect(float gX, float gY, float cov_xx, float cov_yy, int W, int H
     *c1 = maxy < W ? maxy : W;
 }
 
-void *orc_rasterize_forward(int W, int H, int N, const float *xys, const float *conics,
-                            const float *colors, const float *opacities, const float *background,
-                            const float *cov2d /* N x 2 x 2 */, const float *cam_depths,
-                            float *out_img, float *final_Ts, int32_t *px_counts) {
+/* Window variant: only the pixels of rows [wy0,wy1) x cols [wx0,wx1) are evaluated (every pixel's
+ * recurrence is independent of every other pixel's, so a window is the full image restricted);
+ * pixels outside keep T = 1, colour = background, no contributors.  Lets the parity tests check
+ * crops of BASELINE-size frames in full-image coordinates (no translation round-off). */
+void *orc_rasterize_forward_window(int W, int H, int N, const float *xys, const float *conics,
+                                   const float *colors, const float *opacities,
+                                   const float *background, const float *cov2d /* N x 2 x 2 */,
+                                   const float *cam_depths, float *out_img, float *final_Ts,
+                                   int32_t *px_counts, int wx0, int wy0, int wx1, int wy1) {
     int64_t P = (int64_t)W * H;
+    if (wx0 < 0) wx0 = 0;
+    if (wy0 < 0) wy0 = 0;
+    if (wx1 > W) wx1 = W;
+    if (wy1 > H) wy1 = H;
     int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
     for (int i = 0; i < N; i++) order[i] = i;
     g_sort_key = cam_depths;
@@ -434,6 +443,10 @@ void *orc_rasterize_forward(int W, int H, int N, const float *xys, const float *
         float gX = xys[2 * g + 0], gY = xys[2 * g + 1];
         int r0, r1, c0, c1;
         orc_pixel_rect(gX, gY, cov2d[4 * g + 0], cov2d[4 * g + 3], W, H, &r0, &r1, &c0, &c1);
+        if (r0 < wy0) r0 = wy0;
+        if (r1 > wy1) r1 = wy1;
+        if (c0 < wx0) c0 = wx0;
+        if (c1 > wx1) c1 = wx1;
         for (int i = r0; i < r1; i++) {
             for (int j = c0; j < c1; j++) {
                 int64_t pix = (int64_t)i * W + j;
@@ -495,6 +508,14 @@ void *orc_rasterize_forward(int W, int H, int N, const float *xys, const float *
     return st;
 }
 
+void *orc_rasterize_forward(int W, int H, int N, const float *xys, const float *conics,
+                            const float *colors, const float *opacities, const float *background,
+                            const float *cov2d /* N x 2 x 2 */, const float *cam_depths,
+                            float *out_img, float *final_Ts, int32_t *px_counts) {
+    return orc_rasterize_forward_window(W, H, N, xys, conics, colors, opacities, background, cov2d,
+                                        cam_depths, out_img, final_Ts, px_counts, 0, 0, W, H);
+}
+
 int64_t orc_rasterize_total(void *state) { return ((OrcRaster *)state)->total; }
 
 int orc_rasterize_contributors(void *state, int32_t *ids) {
@@ -515,11 +536,16 @@ int orc_rasterize_free(void *state) {
 
 /* gsplat_cpu.cpp:260-376.  v_out_alpha may be NULL (zeros, rasterize_gaussians.cpp:198).
  * Outputs are zero-filled here, then accumulated in pixel raster order. */
-int orc_rasterize_backward(int W, int H, int N, const float *xys, const float *conics,
-                           const float *colors, const float *opacities, const float *background,
-                           const float *final_Ts, void *state, const float *v_out,
-                           const float *v_out_alpha, float *v_xy, float *v_conic, float *v_colors,
-                           float *v_opacity) {
+int orc_rasterize_backward_window(int W, int H, int N, const float *xys, const float *conics,
+                                  const float *colors, const float *opacities,
+                                  const float *background, const float *final_Ts, void *state,
+                                  const float *v_out, const float *v_out_alpha, float *v_xy,
+                                  float *v_conic, float *v_colors, float *v_opacity, int wx0,
+                                  int wy0, int wx1, int wy1) {
+    if (wx0 < 0) wx0 = 0;
+    if (wy0 < 0) wy0 = 0;
+    if (wx1 > W) wx1 = W;
+    if (wy1 > H) wy1 = H;
     OrcRaster *st = (OrcRaster *)state;
     memset(v_xy, 0, sizeof(float) * 2 * (size_t)N);
     memset(v_conic, 0, sizeof(float) * 3 * (size_t)N);
@@ -527,8 +553,8 @@ int orc_rasterize_backward(int W, int H, int N, const float *xys, const float *c
     memset(v_opacity, 0, sizeof(float) * (size_t)N);
     const float bgX = background[0], bgY = background[1], bgZ = background[2];
     const float alphaThresh = 1.0f / 255.0f;
-    for (int i = 0; i < H; i++) {
-        for (int j = 0; j < W; j++) {
+    for (int i = wy0; i < wy1; i++) {
+        for (int j = wx0; j < wx1; j++) {
             int64_t pix = (int64_t)i * W + j;
             float Tfinal = final_Ts[pix];
             float T = Tfinal;
@@ -571,6 +597,16 @@ int orc_rasterize_backward(int W, int H, int N, const float *xys, const float *c
         }
     }
     return 0;
+}
+
+int orc_rasterize_backward(int W, int H, int N, const float *xys, const float *conics,
+                           const float *colors, const float *opacities, const float *background,
+                           const float *final_Ts, void *state, const float *v_out,
+                           const float *v_out_alpha, float *v_xy, float *v_conic, float *v_colors,
+                           float *v_opacity) {
+    return orc_rasterize_backward_window(W, H, N, xys, conics, colors, opacities, background,
+                                         final_Ts, state, v_out, v_out_alpha, v_xy, v_conic,
+                                         v_colors, v_opacity, 0, 0, W, H);
 }
 
 /* libm expf, exported so tests can check the device expf against the host's bit for bit. */

@@ -10,6 +10,9 @@ opensplat_amd/scenes.py, and a checksum of them is stored to catch generator dri
   ref_camera_sh.npz     perspective camera, SH degree 3 (K=16), N=800, 80x56
   ref_c1_known.npz      the full BASELINE config 1 (N=10 000, 256x256): iteration-1 loss, image
                         mean/sum and max|grad| of simple_trainer.cpp's MSE set-up
+  ref_c1_grads.npz      the same run's COMPLETE gradient tensors (means, scales, quats, colours,
+                        opacities) and image: what north_star's "gradient max-abs-error < 1e-4 vs the
+                        CPU reference" is asserted against on the GPU (python make_golden.py c1grads)
 
 `img`, `final_Ts`, `contributors`, `rast_*` are the reference's *_tensor_cpu functions fed TRUE
 depths (contiguous camDepths); `chain_*` is the reference's end-to-end op chain, which sorts by
@@ -83,8 +86,30 @@ def stages(R, s, v_out):
     return out
 
 
+def c1_grads(R):
+    """BASELINE config 1, iteration 1 of simple_trainer.cpp through the reference's own op chain
+    (ProjectGaussiansCPU -> RasterizeGaussiansCPU under libtorch autograd, mean-MSE loss): every
+    gradient tensor, complete.  The chain composites in the order of the as-read keys (P11)."""
+    s = scenes.config_c1()
+    gt = s.extra["gt_image"]
+    ch0 = R.chain_fwd_bwd(s.means, s.scales, s.quats, None, s.colors, s.opacities, s.viewmat,
+                          s.projmat, s.fx, s.fy, s.cx, s.cy, s.H, s.W, s.background, None)
+    img = ch0["img"]
+    v_out = (2.0 * (img - gt) / img.size).astype(np.float32)   # d mean((img-gt)^2) / d img
+    ch = R.chain_fwd_bwd(s.means, s.scales, s.quats, None, s.colors, s.opacities, s.viewmat,
+                         s.projmat, s.fx, s.fy, s.cx, s.cy, s.H, s.W, s.background, v_out)
+    np.savez_compressed(
+        os.path.join(HERE, "ref_c1_grads.npz"), img=img.astype(np.float16),  # image: statistics only
+        v_means=ch["v_means"], v_scales=ch["v_scales"], v_quats=ch["v_quats"],
+        v_colors=ch["v_coeffs"], v_opacities=ch["v_opacities"],
+        scene_sha256=np.frombuffer(scene_digest(s).encode(), dtype=np.uint8))
+
+
 def main():
     R = oracle.reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "c1grads":
+        c1_grads(R)
+        return
     s = scenes.simple_trainer_scene(600, 64, 48, seed=0)
     v = np.random.RandomState(100).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "ref_c1_small.npz"), **stages(R, s, v))
@@ -111,6 +136,7 @@ def main():
         max_abs_v_opacities=np.abs(ch["v_opacities"]).max(),
         v_means_head=ch["v_means"][:64].copy(), v_scales_head=ch["v_scales"][:64].copy(),
         scene_sha256=np.frombuffer(scene_digest(s).encode(), dtype=np.uint8))
+    c1_grads(R)
     print("C1 iteration-1: loss %.9g image mean %.9g sum %.9g" % (loss, img.mean(dtype=np.float64),
                                                                   img.sum(dtype=np.float64)))
     print("max|grad| means %.6g scales %.6g quats %.6g colors(sigmoid'ed) %.6g opac(sigmoid'ed) %.6g" % (
