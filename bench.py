@@ -49,7 +49,14 @@ def parse_args():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4"])
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c4-sequence"],
+                    help="c4-sequence: ONE GPU cycling through the 8 C4 cameras, a different camera every "
+                         "step (what a training loop does): measures the speculative binning on a moving "
+                         "camera (misses = forwards repeated because the id list was too small)")
+    ap.add_argument("--cameras-per-rank", type=int, default=1,
+                    help="N > 1 only: cameras each rank renders per gradient exchange (gradients "
+                         "accumulated in the flat buffer, ONE all-reduce per c rasterizations); "
+                         "1 = BASELINE config 4")
     ap.add_argument("--fast-exp", action="store_true",
                     help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,6 +122,7 @@ class Pipeline:
         self.pb_out = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
                            v_quats=self.grads.v_quats)
         self.num_isects = 0
+        self.misses = 0          # forwards repeated because the speculative id list was too small
         self.multi = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size() > 1
         # default: the per-Gaussian stages fused into one kernel per direction (gs_gaussian_*);
@@ -133,12 +141,23 @@ class Pipeline:
                              v_quats=self.grads.v_quats, v_opacity=self.grads.v_opacity,
                              v_dc=self.grads.v_dc, v_rest=self.grads.v_rest)
 
-    def step(self, events=None, kernel_events=None):
+    def set_camera(self, viewmat, projmat):
+        """Another camera over the same Gaussians (intrinsics unchanged)."""
+        t = lambda a: self.torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        s = self.s
+        self.cam = self.cabi.make_camera(viewmat, projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H)
+        self.vm_dev.copy_(t(viewmat))
+        self.pm_dev.copy_(t(projmat))
+        R, tr = viewmat[:3, :3], viewmat[:3, 3]
+        self.cam_pos.copy_(t((-R.T @ tr).astype(np.float32)))
+
+    def step(self, events=None, kernel_events=None, accumulate=False, exchange=True):
         """One forward+backward.  events: list that receives the stage-boundary events;
         kernel_events: dict name -> (start, stop) event pairs armed around the two compositing
         kernels alone (gs_debug_time_next_kernel)."""
         if not self.stage_kernels:
-            return self.step_fused(events, kernel_events)
+            return self.step_fused(events, kernel_events, accumulate, exchange)
+        assert not accumulate and exchange, "camera batches per rank run on the fused path"
         torch, cabi, s = self.torch, self.cabi, self.s
 
         def mark():
@@ -174,6 +193,7 @@ class Pipeline:
             # was the id list large enough?  Waits for the scan kernel only (long finished while the
             # forward kernel runs): the stream never drains, the host keeps enqueuing.
             if not cabi.validate_binning(b):
+                self.misses += 1
                 continue
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
@@ -204,8 +224,10 @@ class Pipeline:
         mark()
 
 
-    def step_fused(self, events=None, kernel_events=None):
-        """Same work with gs_gaussian_forward / gs_gaussian_backward around binning + compositing."""
+    def step_fused(self, events=None, kernel_events=None, accumulate=False, exchange=True):
+        """Same work with gs_gaussian_forward / gs_gaussian_backward around binning + compositing.
+        accumulate: add this camera's gradients to the flat buffer (GS_FLAG_ACCUMULATE_GRADS);
+        exchange: all-reduce the flat buffer afterwards (the last camera of a rank's batch)."""
         torch, cabi, s = self.torch, self.cabi, self.s
         # GSPLAT_RECORDS_ZEROED=1: gs_gaussian_backward zeroes the gradient records behind its read
         # and the per-frame memset is skipped — measured SLOWER at C2 (1.27 vs 1.25 ms): the memset
@@ -235,22 +257,25 @@ class Pipeline:
             f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
             mark()
             if not cabi.validate_binning(b):
+                self.misses += 1
                 continue
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"], f["final_idx"],
                                     self.v_out, self.flags | KEEP, workspace=self.bwd_ws)
             mark()
+            ACC = cabi.GS_FLAG_ACCUMULATE_GRADS if accumulate else 0
             cabi.gaussian_backward(self.cam, self.means, self.scales, self.quats, self.opac,
                                    self.cam_pos, s.K, s.degrees_to_use, g["radii"], g["rgb_raw"],
-                                   self.bwd_ws, self.gout, ZEROED, viewmat_dev=self.vm_dev,
+                                   self.bwd_ws, self.gout, ZEROED | ACC, viewmat_dev=self.vm_dev,
                                    projmat_dev=self.pm_dev)
             mark()
             break
         self.num_isects = b.num_isects
         if events is not None:
             events.extend(ev_local)
-        self.dist.wait_all(self.dist.allreduce_all_async(self.grads))
+        if exchange:
+            self.dist.wait_all(self.dist.allreduce_all_async(self.grads))
         if events is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -404,8 +429,34 @@ def main():
 
     # one rank per GPU over RCCL ("nccl"); GSPLAT_DIST_BACKEND=gloo lets the multi-rank code path be
     # exercised on a box with fewer GPUs than ranks (ranks then share devices round-robin)
-    rank, world, local = dist.init_from_env(os.environ.get("GSPLAT_DIST_BACKEND", "nccl"))
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    backend = os.environ.get("GSPLAT_DIST_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (what torchrun would do)
+        have = torch.cuda.device_count()
+        if have < args.gpus and backend == "nccl":
+            sys.exit("bench.py: --gpus %d requested but only %d GPU(s) visible (RCCL needs one GPU per "
+                     "rank; GSPLAT_DIST_BACKEND=gloo shares devices for functional runs)" % (args.gpus, have))
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    rank, world, local = dist.init_from_env(backend)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if os.environ.get("GSPLAT_BENCH_DRY_LAUNCH"):   # launcher test: report the rendezvous and stop
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local}), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        sys.exit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -423,10 +474,19 @@ def main():
         scene = scenes.camera_scene(5 * args.gaussians, 2 * args.width, 2 * args.height, K=16, seed=2,
                                     sigma_px=(1.0, 8.0), name="C3")
         workload = "C3: %d Gaussians, %dx%d, SH degree 3" % (scene.N, scene.W, scene.H)
+    elif cfg == "c4-sequence":
+        assert world == 1, "--config c4-sequence is a one-GPU measurement"
+        scene = scenes.config_c4(0, args.gaussians)
+        workload = ("C4 sequence: %d Gaussians, the 8 C4 cameras (yaw -14 .. +14 deg) at 1920x1080 in "
+                    "turn on ONE GPU, a different camera every step, SH degree 3" % args.gaussians)
     else:
-        scene = scenes.config_c4(rank, args.gaussians)
-        workload = ("C4: %d shared Gaussians, %d cameras at 1920x1080 (one per rank, yaw offsets), "
-                    "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians, world))
+        scene = scenes.config_c4(rank * args.cameras_per_rank, args.gaussians)
+        workload = ("C4: %d shared Gaussians, %d cameras at 1920x1080 (%d per rank, yaw offsets), "
+                    "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians,
+                                                                   world * args.cameras_per_rank,
+                                                                   args.cameras_per_rank))
+    cpr = args.cameras_per_rank if (world > 1 or cfg == "c4") else 1
+    cams = [scenes.yaw_camera(scene.W, scene.H, y) for y in scenes.C4_YAWS]
 
     if args.order != "given":
         reorder_scene(scene, args.order)
@@ -437,8 +497,23 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    sequence = cfg == "c4-sequence"
+    step_no = [0]
+
+    def one_step(ev=None, kev=None):
+        """One bench step: cpr cameras on this rank (gradients accumulated), then the exchange."""
+        if sequence:
+            pipe.set_camera(*cams[step_no[0] % 8])
+        step_no[0] += 1
+        for j in range(cpr):
+            if cpr > 1:
+                pipe.set_camera(*cams[(rank * cpr + j) % 8])
+            last = j == cpr - 1
+            pipe.step(ev if last else None, kev if last else None, accumulate=j > 0, exchange=last)
+
     for _ in range(args.warmup):
-        pipe.step()
+        one_step()
+    misses_warmup = pipe.misses
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -461,11 +536,11 @@ def main():
     for i in range(args.steps):
         if i in kev_pool:
             ev = []
-            pipe.step(ev, kev_pool[i])
+            one_step(ev, kev_pool[i])
             all_events.append(ev)
             all_kernel_events.append(kev_pool[i])
         else:
-            pipe.step()
+            one_step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -499,7 +574,8 @@ def main():
         traffic = None
         # the PMC passes are collected on the default command (C2 / C4 per-rank workload, parity exp)
         # and on --config c3; other workloads carry no measured traffic
-        plain = not args.fast_exp and not args.hot and args.order == "given" and not args.stage_kernels
+        plain = (not args.fast_exp and not args.hot and args.order == "given" and not args.stage_kernels
+                 and not sequence and cpr == 1)
         tname = None
         if plain and scene.N == 1_000_000 and scene.W == 1920 and scene.H == 1080:
             tname = "traffic.json"
@@ -513,7 +589,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "forward+backward rasterizations/sec at 1M Gaussians 1080p",
-            "value": world * args.steps / elapsed,
+            "value": world * cpr * args.steps / elapsed,
             "unit": "rasterizations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -529,7 +605,8 @@ def main():
                        "exp": "hardware v_exp_f32" if args.fast_exp else "glibc-bit-exact expf (parity mode)",
                        "per_gaussian_stages": "separate kernels" if args.stage_kernels else
                        "fused (gs_gaussian_forward / gs_gaussian_backward)",
-                       "parallelism": "camera-per-rank dp%d" % world},
+                       "parallelism": "camera-per-rank dp%d" % world,
+                       "cameras_per_rank_per_step": cpr},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": dom_ms, "algorithmic_bytes": dom_bytes,
@@ -548,6 +625,12 @@ def main():
                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stage_ms": stage_ms,
             "grad_bytes_allreduced": pipe.grads.nbytes if world > 1 else 0,
+            "allreduce_ms_rank0": stage_ms.get("allreduce", 0.0),
+            # speculative binning: forwards repeated because the id list (sized from the previous
+            # call, +12.5 %) was too small — during warm-up / inside the timed region
+            "speculative_binning": {"misses_warmup": misses_warmup,
+                                    "misses_timed": pipe.misses - misses_warmup,
+                                    "id_list_capacity": pipe.ws.capacity},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -77,6 +77,13 @@ typedef struct GsCamera {
                                      may be NULL); gs_gaussian_backward consumes them               */
 #define GS_FLAG_RECORDS_ZEROED 16u /* gs_rasterize_backward: the record workspace is already zero     \
                                      (gs_gaussian_backward leaves it so): skip the memset           */
+#define GS_FLAG_ACCUMULATE_GRADS 32u /* gs_gaussian_backward: ADD the six parameter gradients to the  \
+                                     output tensors instead of overwriting them (several cameras   \
+                                     per optimiser step on one rank, one gradient exchange)         */
+#define GS_FLAG_DETERMINISTIC 64u  /* gs_rasterize_backward: order-independent gradient sums (debug): \
+                                     partial sums are accumulated as 64-bit fixed point, so two     \
+                                     runs are bit-identical; workspace from                         \
+                                     gs_rasterize_backward_workspace_bytes_det                      */
 
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */

@@ -22,6 +22,8 @@ GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
 GS_FLAG_KEEP_RECORDS = 8
 GS_FLAG_RECORDS_ZEROED = 16
+GS_FLAG_ACCUMULATE_GRADS = 32
+GS_FLAG_DETERMINISTIC = 64
 GS_CAM_LOG_SCALES = 1
 
 # every symbol include/gsplat_hip.h declares (tests check they are all exported)
@@ -496,6 +498,8 @@ def densify(cfg: GsDensifyConfig, params, exp_avg, exp_avg_sq, xys_grad_norm, vi
     torch.cuda.current_stream().synchronize()
     c = dict(zip(COUNT_NAMES, [int(x) for x in counts]))
     n_splits, new_n = c["n_splits"], c["new_n"]
+    if new_n <= 0:
+        raise GsError("densification culled every Gaussian (new_n = 0): nothing left to build")
     if samples_fn is None:
         samples_fn = lambda n: torch.randn((2 * n, 3), device=dev)   # model.cpp:360
     samples = samples_fn(n_splits) if n_splits > 0 else None

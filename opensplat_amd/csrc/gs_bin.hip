@@ -838,6 +838,9 @@ extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const floa
                                int32_t *num_isects_host, void *workspace, size_t workspace_bytes,
                                gs_stream_t stream) {
     if (!num_isects_host) return GS_ERR_INVALID_ARGUMENT;
+    // a reused pinned buffer must never report the previous frame's counts, whatever path the scan takes
+    num_isects_host[0] = 0;
+    num_isects_host[1] = 0;
     int rc = gs_bin_scan(W, H, N, packed, tile_bins, tile_order, num_isects_host, workspace,
                          workspace_bytes, stream);
     if (rc != GS_OK) return rc;

@@ -35,6 +35,10 @@ k_gaussian_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *_
     load_device_matrices(cam, vm_dev, pm_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *slab = smem + wave * (64 * ROWP);
+    // GS_FLAG_ACCUMULATE_GRADS: the six parameter gradients are ADDED to what the output tensors
+    // hold (several cameras per optimiser step on one rank, one all-reduce for all of them)
+    const bool accum = (flags & GS_FLAG_ACCUMULATE_GRADS) != 0u;
+    auto put = [accum](float *p, float v) { *p = accum ? *p + v : v; };
     const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
     const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
     // The wave's slab of higher-band coefficients is fetched into registers FIRST (coalesced 16-byte
@@ -185,6 +189,10 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
     load_device_matrices(cam, vm_dev, pm_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *slab = smem + wave * (64 * ROWP);
+    // GS_FLAG_ACCUMULATE_GRADS: the six parameter gradients are ADDED to what the output tensors
+    // hold (several cameras per optimiser step on one rank, one all-reduce for all of them)
+    const bool accum = (flags & GS_FLAG_ACCUMULATE_GRADS) != 0u;
+    auto put = [accum](float *p, float v) { *p = accum ? *p + v : v; };
     const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
     const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
     if (lane < cnt) {
@@ -202,7 +210,7 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
             const float sg = 1.0f / (1.0f + expf(-opacities[g]));
             vo *= sg * (1.0f - sg);
         }
-        v_opacity[g] = vo;
+        put(v_opacity + g, vo);
         if (v_xy) {
             v_xy[2 * g + 0] = ra.x;
             v_xy[2 * g + 1] = ra.y;
@@ -216,9 +224,9 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         const float v0 = (rgb_raw[3 * g + 0] + 0.5f >= 0.0f) ? rb.y : 0.0f;
         const float v1 = (rgb_raw[3 * g + 1] + 0.5f >= 0.0f) ? rb.z : 0.0f;
         const float v2 = (rgb_raw[3 * g + 2] + 0.5f >= 0.0f) ? rb.w : 0.0f;
-        v_dc[3 * g + 0] = r[0] * v0;
-        v_dc[3 * g + 1] = r[0] * v1;
-        v_dc[3 * g + 2] = r[0] * v2;
+        put(v_dc + 3 * g + 0, r[0] * v0);
+        put(v_dc + 3 * g + 1, r[0] * v1);
+        put(v_dc + 3 * g + 2, r[0] * v2);
         float *row = slab + lane * ROWP;
 #pragma unroll
         for (int b = 1; b < K; b++) {
@@ -230,9 +238,11 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         // ---- projection backward (gs_project_backward) -----------------------------------------------
         float4_u *vq4 = reinterpret_cast<float4_u *>(v_quats);
         if (radii[g] <= 0) {  // culled Gaussians get no gradient (backward.cu:380-382)
-            v_means[3 * g] = v_means[3 * g + 1] = v_means[3 * g + 2] = 0.0f;
-            v_scales[3 * g] = v_scales[3 * g + 1] = v_scales[3 * g + 2] = 0.0f;
-            vq4[g] = (float4_u)(0.0f);
+            if (!accum) {
+                v_means[3 * g] = v_means[3 * g + 1] = v_means[3 * g + 2] = 0.0f;
+                v_scales[3 * g] = v_scales[3 * g + 1] = v_scales[3 * g + 2] = 0.0f;
+                vq4[g] = (float4_u)(0.0f);
+            }
         } else {
             float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
             float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
@@ -248,11 +258,12 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
             project_backward_one(cam, o, scale, ra.x, ra.y, ra.z, ra.w, rb.x, 0.0f, pg);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                v_means[3 * g + j] = pg.v_mean[j];
-                v_scales[3 * g + j] = pg.v_scale[j];
+                put(v_means + 3 * g + j, pg.v_mean[j]);
+                put(v_scales + 3 * g + j, pg.v_scale[j]);
             }
             float4_u vq;
             vq.x = pg.v_quat[0]; vq.y = pg.v_quat[1]; vq.z = pg.v_quat[2]; vq.w = pg.v_quat[3];
+            if (accum) vq = vq + vq4[g];
             vq4[g] = vq;
         }
     }
@@ -270,9 +281,11 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
                 }
                 float4_u v;
                 v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
+                if (accum) v = v + *reinterpret_cast<float4_u *>(dst + i);
                 *reinterpret_cast<float4_u *>(dst + i) = v;
             } else {
-                for (int idx = i; idx < total; idx++) dst[idx] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+                for (int idx = i; idx < total; idx++)
+                    put(dst + idx, slab[(idx / ROW) * ROWP + (idx % ROW)]);
             }
         }
     }

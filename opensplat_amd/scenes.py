@@ -95,6 +95,25 @@ def simple_trainer_scene(N: int = 10_000, W: int = 256, H: int = 256, seed: int 
                  colors=torch.sigmoid(rgbs).numpy(), extra=dict(gt_image=gt, raw_rgbs=rgbs.numpy()))
 
 
+def yaw_camera(W: int, H: int, yaw_deg: float, znear: float = 0.001, zfar: float = 1000.0):
+    """(viewmat, projmat) of camera_scene's camera — at the origin, fovX = 90 deg, rotated about +y
+    by yaw_deg (C4: one such camera per rank, C4_YAWS)."""
+    fx = fy = 0.5 * W
+    fovx = 2.0 * math.atan(W / (2.0 * fx))
+    fovy = 2.0 * math.atan(H / (2.0 * fy))
+    viewmat = np.eye(4, dtype=np.float32)
+    if yaw_deg != 0.0:
+        a = math.radians(yaw_deg)
+        R = np.array([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]],
+                     dtype=np.float32)
+        viewmat[:3, :3] = R
+    projmat = projection_matrix(znear, zfar, fovx, fovy) @ viewmat
+    return viewmat, projmat.astype(np.float32)
+
+
+C4_YAWS = [-14.0, -10.0, -6.0, -2.0, 2.0, 6.0, 10.0, 14.0]   # SURVEY.md §8d
+
+
 def camera_scene(N: int, W: int, H: int, K: int = 16, seed: int = 1, sigma_px=(0.5, 4.0),
                  z_range=(2.0, 10.0), znear: float = 0.001, zfar: float = 1000.0,
                  degrees_to_use: int | None = None, yaw_deg: float = 0.0, name: str | None = None,
@@ -131,13 +150,7 @@ def camera_scene(N: int, W: int, H: int, K: int = 16, seed: int = 1, sigma_px=(0
     scales = (s_px[:, None] * aniso * z[:, None] / fx).astype(np.float32)
     quats = random_quats(rng.rand(N), rng.rand(N), rng.rand(N))
     opac = 1.0 / (1.0 + np.exp(-rng.normal(0.0, 2.0, size=(N, 1))))
-    viewmat = np.eye(4, dtype=np.float32)
-    if yaw_deg != 0.0:  # rotate the camera about +y (C4: one camera per rank)
-        a = math.radians(yaw_deg)
-        R = np.array([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]],
-                     dtype=np.float32)
-        viewmat[:3, :3] = R
-    projmat = projection_matrix(znear, zfar, fovx, fovy) @ viewmat
+    viewmat, projmat = yaw_camera(W, H, yaw_deg, znear, zfar)
     sh = None
     dirs = None
     colors = None
@@ -174,8 +187,7 @@ def config_c3(N: int = 5_000_000) -> Scene:
 
 def config_c4(rank: int, N: int = 1_000_000) -> Scene:
     """C4: the C2 Gaussians seen by camera `rank` of 8 (yaw offsets)."""
-    yaws = [-14.0, -10.0, -6.0, -2.0, 2.0, 6.0, 10.0, 14.0]
-    s = camera_scene(N, 1920, 1080, K=16, seed=3, sigma_px=(0.5, 4.0), yaw_deg=yaws[rank % 8],
+    s = camera_scene(N, 1920, 1080, K=16, seed=3, sigma_px=(0.5, 4.0), yaw_deg=C4_YAWS[rank % 8],
                      name=f"C4_cam{rank}")
     return s
 

@@ -31,6 +31,18 @@ import torch
 from . import cabi, dist
 
 
+def rank_merged_config(cfg: "cabi.GsDensifyConfig", world: int) -> "cabi.GsDensifyConfig":
+    """With one camera per rank every rank scales its loss cotangent by 1/world (train_step), so the
+    per-camera d loss / d xys that feeds the densification statistics is 1/world of what a
+    single-camera iteration sees, while --densify-grad-thresh (0.0002, model.cpp:347) is calibrated
+    for unscaled single-camera gradients.  The statistics are linear in the gradient norm and only
+    enter the plan through xysGradNorm / visCounts * half_max_side, so scaling half_max_side by
+    `world` undoes the batch scaling exactly (gsplat's strategy does the same with
+    `grads *= n_cameras`)."""
+    cfg.half_max_side = float(cfg.half_max_side) * float(world)
+    return cfg
+
+
 def morton_permutation(means: torch.Tensor) -> torch.Tensor:
     """Indices that sort the rows of `means` [N, 3] along a 3-D Morton (Z-order) curve, 10 bits per
     axis over the bounding box.  Any permutation of the Gaussians renders the same image."""
@@ -59,7 +71,8 @@ class Trainer:
                  densify_grad_thresh: float = 0.0002, densify_size_thresh: float = 0.01,
                  stop_screen_size_at: int = 4000, split_screen_size: float = 0.05,
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
-                 resolution_schedule: int = 3000, sh_degree_interval: int = 1000):
+                 resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
+                 reference_alpha_reset: bool = False):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -89,12 +102,22 @@ class Trainer:
         # neighbours in space become neighbours in memory (binning scatter and the per-Gaussian
         # kernels gain locality: +1..3 % per iteration at 1 M Gaussians)
         self.morton_order = morton_order
+        # Alpha reset (model.cpp:464-479).  The reference builds a zeroed AdamParamState but never
+        # installs it, and re-binds `opacities` to a tensor the optimiser does not know: until the
+        # next refinement re-registers it (addToOptimizer / removeFromOptimizer, :253-309) neither
+        # the opacities nor their moments are updated.  False (default): the evident intent —
+        # opacities stay trainable, their moments are zeroed.  True: the reference's actual
+        # behaviour step for step (KNOWN PARITY DEVIATION switch).
+        self.reference_alpha_reset = reference_alpha_reset
+        self._opacity_frozen = False
+        self._visible = True
         self._stats = None          # (xysGradNorm, visCounts, max2DSize); None = cleared
         self.step_count = 0
         self.means_lr = self.LR["means"]
         self._shape = None
         self.world = torch.distributed.get_world_size() if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
 
     def degrees_to_use(self, step: int) -> int:
         """model.cpp:178: one more SH degree every sh_degree_interval steps."""
@@ -158,6 +181,9 @@ class Trainer:
             f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
+        # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
+        # no gradient and afterTrain returns at once (model.cpp:315)
+        self._visible = b.num_isects > 0
         self._ctx = (gcam, cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
         return f["img_clamped"]
 
@@ -178,7 +204,7 @@ class Trainer:
         names = [("v_means", "means"), ("v_scales", "scales"), ("v_quats", "quats"),
                  ("v_dc", "features_dc"), ("v_rest", "features_rest"), ("v_opacity", "opacities")]
         return [(P.views[v], G.views[v], M.views[v], V.views[v], lr[n]) for v, n in names
-                if P.views[v].numel() > 0]
+                if P.views[v].numel() > 0 and not (n == "opacities" and self._opacity_frozen)]
 
     def optimizer_step(self):
         """Model::optimizersStep + schedulersStep (model.cpp:236-247)."""
@@ -208,11 +234,19 @@ class Trainer:
         step refined the Gaussian set, else None."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
         N, dev = self.N, self.dev
+        if not self._visible and self.world == 1:   # model.cpp:315 (with a batch, another rank's
+            return None                             # camera may see Gaussians: the step counts)
         if step < self.stop_split_at:   # model.cpp:317-337
             first = self._stats is None
             if first:
-                self._stats = tuple(torch.empty(N, device=dev, dtype=torch.float32) for _ in range(3))
-            cabi.densify_stats(self.rgrads["v_xy"], p["radii"], float(max(H, W)), first, *self._stats)
+                self._stats = tuple(torch.zeros(N, device=dev, dtype=torch.float32) for _ in range(3))
+            # A batch of `world` cameras is merged (in _refine) into what ONE rank would have
+            # accumulated had it seen the cameras one after the other: only rank 0's first camera
+            # takes the "first iteration" branch (every Gaussian counted once, visible or not,
+            # model.cpp:321-323); the other ranks start from zero accumulators and count visible
+            # Gaussians only (:325-326).  Sums / maxima over ranks then equal the sequential result.
+            cabi.densify_stats(self.rgrads["v_xy"], p["radii"], float(max(H, W)),
+                               first and self.rank == 0, *self._stats)
         counts = None
         if step % self.refine_every == 0 and step > self.warmup_length and self._stats is not None:
             reset_interval = self.reset_alpha_every * self.refine_every
@@ -221,10 +255,15 @@ class Trainer:
             if do_densify:
                 counts = self._refine(step, W, H)
             if step < self.stop_split_at and step % reset_interval == self.refine_every:
-                # the reference clamps but never installs the zeroed optimiser state (model.cpp:
-                # 475-477); the intended behaviour — reset the moments too — is what runs here
-                cabi.reset_opacity(self.params.v_opacity, 0.2, self.exp_avg.v_opacity,
-                                   self.exp_avg_sq.v_opacity)
+                if self.reference_alpha_reset:
+                    # what model.cpp:464-479 really does: clamp, leave the optimiser state alone,
+                    # and the re-bound tensor is unknown to the optimiser until the next refinement
+                    cabi.reset_opacity(self.params.v_opacity, 0.2, None, None)
+                    self._opacity_frozen = True
+                else:
+                    # the intended behaviour: keep the opacities trainable, zero their moments
+                    cabi.reset_opacity(self.params.v_opacity, 0.2, self.exp_avg.v_opacity,
+                                       self.exp_avg_sq.v_opacity)
             self._stats = None           # model.cpp:482-484
         return counts
 
@@ -232,14 +271,14 @@ class Trainer:
         gn, vc, m2 = self._stats
         if self.world > 1:
             # one camera per rank: merge the ranks' statistics so that every replica takes the
-            # same decisions (sum of norms, sum of counts minus the extra initial ones, max size)
+            # same decisions (sum of norms, sum of counts, max size — see after_train)
             torch.distributed.all_reduce(gn)
             torch.distributed.all_reduce(vc)
-            vc -= float(self.world - 1)
             torch.distributed.all_reduce(m2, op=torch.distributed.ReduceOp.MAX)
         cfg = cabi.densify_config(W, H, self.densify_grad_thresh, self.densify_size_thresh,
                                   step < self.stop_screen_size_at, self.split_screen_size,
                                   step > self.refine_every * self.reset_alpha_every)
+        cfg = rank_merged_config(cfg, self.world)
         gen = torch.Generator(device=self.dev).manual_seed(1_000_003 * step)  # same on every rank
         samples_fn = lambda n: torch.randn((2 * n, 3), device=self.dev, generator=gen)
         new = {}
@@ -252,6 +291,10 @@ class Trainer:
                                        self._param_list(self.exp_avg),
                                        self._param_list(self.exp_avg_sq), gn, vc, m2, samples_fn,
                                        alloc)
+        if counts["new_n"] <= 0:
+            raise RuntimeError("densification at step %d culled every Gaussian (new_n = 0): nothing "
+                               "left to train" % step)
+        self._opacity_frozen = False     # the refinement re-registers the opacities (model.cpp:253-309)
         if self.morton_order and counts["new_n"] > 1:
             perm = morton_permutation(new["params"].v_means)
             for buf in new.values():

@@ -270,3 +270,56 @@ def test_morton_reorder_at_refinement_renders_the_same_image():
     d_sorted = (m[1:] - m[:-1]).norm(dim=1).mean().item()
     d_given = (T.means[1:] - T.means[:-1]).norm(dim=1).mean().item()
     assert d_sorted < 0.3 * d_given
+
+
+def test_rank_merged_statistics_take_the_single_camera_decisions():
+    """with one camera per rank each rank's cotangent is scaled by 1/world, so the merged
+    statistics must be judged against world x half_max_side (train.rank_merged_config).  Two cameras
+    processed (a) by ONE rank in two iterations with unscaled gradients and (b) by TWO ranks with
+    gradients scaled by 1/2 — rank 0 taking the "first iteration" branch, rank 1 starting from zero
+    accumulators, merged by sum / sum / max as Trainer._refine does — must lead to the SAME plan."""
+    import ctypes as C
+
+    import torch
+
+    from opensplat_amd import cabi
+    from opensplat_amd.train import rank_merged_config
+
+    prob = scenes.densify_problem(20000, K=4, seed=5)
+    N, W, H = prob["N"], prob["width"], prob["height"]
+    rs = np.random.RandomState(9)
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    radii = [t((rs.randint(1, 40, N) * (rs.rand(N) < 0.7)).astype(np.int32)) for _ in range(2)]
+    mag = 10.0 ** rs.uniform(-5.5, -2.0, (N, 1))
+    v_xy = [t((mag * rs.standard_normal((N, 2)) / (0.5 * max(W, H))).astype(np.float32)) for _ in range(2)]
+    for g, r in zip(v_xy, radii):
+        g[r == 0] = 0.0                      # an invisible Gaussian receives no gradient
+
+    def stats(grads, rads, firsts):
+        acc = tuple(torch.zeros(N, device=dev) for _ in range(3))
+        for g, r, first in zip(grads, rads, firsts):
+            cabi.densify_stats(g, r, float(max(H, W)), first, *acc)
+        return acc
+
+    def plan(cfg, acc):
+        need = cabi.lib().gs_densify_workspace_bytes(N)
+        ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        counts = torch.zeros(8, dtype=torch.int32).pin_memory()
+        cabi._check(cabi.lib().gs_densify_plan(
+            C.c_int(N), C.byref(cfg), cabi._p(acc[0]), cabi._p(acc[1]), cabi._p(acc[2]),
+            cabi._p(t(prob["params"][1])), cabi._p(t(prob["params"][3]).reshape(-1)),
+            C.c_void_p(counts.data_ptr()), cabi._p(ws), C.c_size_t(need), cabi._stream()), "plan")
+        torch.cuda.synchronize()
+        return dict(zip(cabi.COUNT_NAMES, [int(x) for x in counts]))
+
+    one = plan(cabi.densify_config(W, H), stats(v_xy, radii, [True, False]))
+    r0 = stats([0.5 * v_xy[0]], [radii[0]], [True])
+    r1 = stats([0.5 * v_xy[1]], [radii[1]], [False])
+    merged_acc = (r0[0] + r1[0], r0[1] + r1[1], torch.maximum(r0[2], r1[2]))
+    merged = plan(rank_merged_config(cabi.densify_config(W, H), 2), merged_acc)
+    assert merged == one, (merged, one)
+    assert one["n_splits"] > 100 and one["n_dups"] > 100 and one["culled"] > 0
+    # without the correction the scaled gradients would hardly ever pass the threshold
+    unscaled = plan(cabi.densify_config(W, H), merged_acc)
+    assert unscaled["n_splits"] + unscaled["n_dups"] < 0.8 * (one["n_splits"] + one["n_dups"])
