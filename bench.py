@@ -491,6 +491,8 @@ def main():
     if args.order != "given":
         reorder_scene(scene, args.order)
     flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
+    if os.environ.get("GSPLAT_RASTER_V1"):   # A/B: the round-1 one-wave-per-tile compositing kernels
+        flags |= 1 << 20
     pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels)
 
     def barrier():

@@ -224,11 +224,9 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            accumulates into them).  Partial gradients are accumulated with fp32 atomics into
  *            64-byte per-Gaussian records in `workspace` (gs_rasterize_backward_workspace_bytes(N)
  *            bytes, 64-byte aligned) and split into the four tensors at the end.
- *            list_stats: {M, longest tile list} as gs_bin_scan stored them for this or an earlier
- *            frame (read on the host at call time; NULL or stale values are fine): when one tile's
- *            list is much longer than the average, that tile is composited by two or four waves
- *            (8 or 4 pixel rows each) instead of one; tile_order (from gs_bin_scan): the launch
- *            starts with the longest lists.  Scheduling only, same results.
+ *            tile_order (from gs_bin_scan): the launch starts with the longest lists; list_stats is
+ *            accepted for source compatibility and ignored (every tile is composited by four
+ *            quadrant waves).  Scheduling only, same results.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
@@ -242,6 +240,10 @@ int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
                          gs_stream_t stream);
 
 size_t gs_rasterize_backward_workspace_bytes(int N);
+/* workspace size under GS_FLAG_DETERMINISTIC: the float records followed by 64-bit fixed-point
+ * accumulators (scale 2^40), into which the per-wave partial sums are added with integer atomics —
+ * integer addition commutes, so the result does not depend on the order the waves arrive in. */
+size_t gs_rasterize_backward_workspace_bytes_det(int N);
 
 int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
                           const int32_t *tile_bins, const float *packed,
@@ -267,6 +269,10 @@ int gs_debug_time_next_kernel(void *event_start, void *event_stop);
 /* Test hook: the nine-value wave reduction of the backward kernel.
  *   in [blocks, 9, 64] (value i of lane l at in[b][i][l])  ->  out[blocks, 9] = sums over lanes. */
 int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
+/* Test hook: the per-row (16-lane) nine-value reduction of the compositing backward (a transposing
+ * DPP butterfly, no LDS).  in [blocks, 9, 64]  ->  out[blocks, 4, 9] = sums over each 16-lane row. */
+int gs_debug_row_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-Gaussian stages (second step).  The three per-Gaussian forward

@@ -30,8 +30,8 @@ GS_CAM_LOG_SCALES = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
-    "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_debug_expf",
-    "gs_debug_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
+    "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
+    "gs_debug_reduce9", "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
@@ -66,6 +66,8 @@ def lib() -> C.CDLL:
         l.gs_bin_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
         l.gs_rasterize_backward_workspace_bytes.restype = C.c_size_t
         l.gs_rasterize_backward_workspace_bytes.argtypes = [C.c_int]
+        l.gs_rasterize_backward_workspace_bytes_det.restype = C.c_size_t
+        l.gs_rasterize_backward_workspace_bytes_det.argtypes = [C.c_int]
         l.gs_loss_workspace_bytes.restype = C.c_size_t
         l.gs_loss_workspace_bytes.argtypes = [C.c_int, C.c_int]
         l.gs_densify_workspace_bytes.restype = C.c_size_t
@@ -303,7 +305,8 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
     elif out is None:
         out = dict(v_xy=torch.empty((N, 2), device=dev), v_conic=torch.empty((N, 3), device=dev),
                    v_colors=torch.empty((N, 3), device=dev), v_opacity=torch.empty((N,), device=dev))
-    ws_bytes = lib().gs_rasterize_backward_workspace_bytes(N)
+    ws_bytes = (lib().gs_rasterize_backward_workspace_bytes_det(N) if flags & GS_FLAG_DETERMINISTIC
+                else lib().gs_rasterize_backward_workspace_bytes(N))
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
     bg = _vec3(background)
@@ -332,6 +335,14 @@ def debug_reduce9(x):
     blocks = x.shape[0]
     y = torch.empty((blocks, 9), device=x.device, dtype=torch.float32)
     _check(lib().gs_debug_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_reduce9")
+    return y
+
+
+def debug_row_reduce9(x):
+    """x [blocks, 9, 64] -> [blocks, 4, 9]: the backward kernel's per-row (16-lane) reduction."""
+    blocks = x.shape[0]
+    y = torch.empty((blocks, 4, 9), device=x.device, dtype=torch.float32)
+    _check(lib().gs_debug_row_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_row_reduce9")
     return y
 
 
@@ -498,8 +509,6 @@ def densify(cfg: GsDensifyConfig, params, exp_avg, exp_avg_sq, xys_grad_norm, vi
     torch.cuda.current_stream().synchronize()
     c = dict(zip(COUNT_NAMES, [int(x) for x in counts]))
     n_splits, new_n = c["n_splits"], c["new_n"]
-    if new_n <= 0:
-        raise GsError("densification culled every Gaussian (new_n = 0): nothing left to build")
     if samples_fn is None:
         samples_fn = lambda n: torch.randn((2 * n, 3), device=dev)   # model.cpp:360
     samples = samples_fn(n_splits) if n_splits > 0 else None

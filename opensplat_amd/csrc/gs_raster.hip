@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t decode_unit(int block, const Sched sc, int n
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, Sched sched,
+k_rasterize_forward_v1(int W, int H, int tiles_x, int num_tiles, Sched sched,
                     const int32_t *__restrict__ ids,
                     const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                     float bg1, float bg2, const float *__restrict__ bg_dev,
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(64) k_debug_reduce9(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ void __launch_bounds__(64)
-k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, Sched sched,
+k_rasterize_backward_v1(int W, int H, int tiles_x, int num_tiles, Sched sched,
                      const int32_t *__restrict__ ids,
                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
                      float bg1, float bg2, const float *__restrict__ bg_dev,
@@ -733,7 +733,7 @@ extern "C" int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stre
     return GS_OK;
 }
 
-extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
+extern "C" int gs_rasterize_forward_v1(int W, int H, const int32_t *gaussian_ids_sorted,
                                     const int32_t *tile_bins, const float *packed,
                                     const float *background, float *out_img, float *final_Ts,
                                     int32_t *final_idx, float *out_img_clamped,
@@ -759,10 +759,10 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward_v1<false>), dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     else
-        hipLaunchKernelGGL((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL((gs::k_rasterize_forward_v1<true>), dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
@@ -773,7 +773,7 @@ extern "C" size_t gs_rasterize_backward_workspace_bytes(int N) {
     return N > 0 ? (size_t)N * gs::kGradRec * sizeof(float) : 0;
 }
 
-extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+extern "C" int gs_rasterize_backward_v1(int W, int H, int N, const int32_t *gaussian_ids_sorted,
                                      const int32_t *tile_bins, const float *packed,
                                      const float *background, const float *final_Ts,
                                      const int32_t *final_idx, const float *v_out,
@@ -809,15 +809,626 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL(gs::k_rasterize_backward<false>, dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL(gs::k_rasterize_backward_v1<false>, dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     else
-        hipLaunchKernelGGL(gs::k_rasterize_backward<true>, dim3(units), dim3(64), 0, s, W, H,
+        hipLaunchKernelGGL(gs::k_rasterize_backward_v1<true>, dim3(units), dim3(64), 0, s, W, H,
                            tiles_x, tiles, sched, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha,
                            img_raw, gacc);
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
+    if (keep_records) return GS_OK;  // the 64-byte records go straight to gs_gaussian_backward
+    hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
+                       reinterpret_cast<const float4 *>(gacc),
+                       (flags & GS_FLAG_LOGIT_OPACITY) ? pk : nullptr, v_xy, v_conic, v_colors,
+                       v_opacity);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+// =============================================================================================
+// Version 2 of the compositing kernels: QUADRANT WAVES WITH PER-GROUP LIST WALKS.
+//
+// Round-1 measurement: with one wave per 16x16 tile and every entry of the tile's
+// list evaluated by all 64 lanes, only ~16 of 64 lanes are live in an exponential pass — a
+// ~30-pixel footprint on a 256-pixel tile.  Here a wave owns one 8x8 QUADRANT of a tile with ONE
+// pixel per lane, and each of its four 16-lane groups (one DPP row = one 4x4 pixel block) walks
+// ITS OWN list: the entries of the staged chunk whose (tightened) rectangle touches that block.
+// The four groups execute the same instruction stream on four different Gaussians, so a step
+// evaluates four (block, Gaussian) pairs with ~60 % live lanes instead of one (tile, Gaussian)
+// pair with ~25 %:
+//   * per chunk of 64 list entries (staged by the wave itself: lane t gathers entry t), four
+//     ballots give four 64-bit "touches block g" masks; they live in SGPRs, the walk is scalar
+//     (s_ff1 + s_bitset0 per group), the chunk takes max_g popcount(mask_g) steps;
+//   * a group without work reads a sentinel record whose x is NaN (sigma NaN fails the one
+//     unsigned compare "0 <= sigma <= sigma_max", as a finished pixel's NaN row does);
+//   * the per-entry record is read from LDS with a per-group address (48 bytes, three
+//     ds_read_b128; identical addresses inside a group broadcast);
+//   * four waves per tile, each staging the tile's list for itself: no workgroup barriers, 4x the
+//     gather traffic out of L2 (the four quadrant waves of a tile occupy consecutive positions in
+//     ONE XCD's block stream); a long list is automatically shared by four waves;
+//   * backward: the nine partial sums are reduced per GROUP through LDS (the same nine stores /
+//     four 16-byte loads as round 1, without the final cross-group step), added to per-entry
+//     accumulators in LDS (ds_add_f32), and flushed once per chunk with one atomic lane per
+//     (entry, component): a Gaussian costs one global atomic line-request per quadrant it
+//     contributes to, not one per 4x4 block.  The moments sum(u), sum(u dx), .. are reduced, the
+//     conversion to (v_x, v_y, v_A, v_B, v_C) happens once per entry at the flush.
+// Arithmetic of the forward: unchanged op order (gsplat_cpu.cpp:213-236), bit-exact.
+// =============================================================================================
+namespace gs {
+
+struct __attribute__((aligned(16))) SRec {
+    float4 p0, p1, p2;  // the packed record as gathered: {x y A B | C o smax rx | r g b ry}
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// block -> (tile, quadrant).  Blocks round-robin over the 8 XCDs (block b runs on XCD b % 8): the
+// four quadrant waves of a tile take consecutive positions of one XCD's stream, tiles are dealt to
+// the XCDs in launch order (longest list first when `order` is given).
+__device__ __forceinline__ bool decode_quadrant(int block, int num_tiles, int tiles_x, int W, int H,
+                                                const int32_t *__restrict__ order, int &tile,
+                                                int &qx0, int &qy0) {
+    const int x = block & 7, k = block >> 3;
+    const int quad = k & 3;
+    const int slot = ((k >> 2) << 3) + x;
+    if (slot >= num_tiles) return false;
+    tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
+    qx0 = (tile % tiles_x) * GS_TILE + 8 * (quad & 1);
+    qy0 = (tile / tiles_x) * GS_TILE + 8 * (quad >> 1);
+    return qx0 < W && qy0 < H;
+}
+
+// which of the quadrant's four 4x4 blocks (bit g: block column g & 1, block row g >> 1) the
+// rectangle [x0,x1) x [y0,y1) (packed as x0 | x1 << 16, y0 | y1 << 16) touches
+__device__ __forceinline__ uint32_t block_touch(uint32_t rx, uint32_t ry, int qx0, int qy0) {
+    const int x0 = (int)(rx & 0xFFFF) - qx0, x1 = (int)(rx >> 16) - qx0;
+    const int y0 = (int)(ry & 0xFFFF) - qy0, y1 = (int)(ry >> 16) - qy0;
+    if (x1 <= x0 || y1 <= y0) return 0u;
+    const bool c0 = x0 < 4 && x1 > 0, c1 = x0 < 8 && x1 > 4;
+    const bool r0 = y0 < 4 && y1 > 0, r1 = y0 < 8 && y1 > 4;
+    return (c0 && r0 ? 1u : 0u) | (c1 && r0 ? 2u : 0u) | (c0 && r1 ? 4u : 0u) |
+           (c1 && r1 ? 8u : 0u);
+}
+
+__device__ __forceinline__ void stage_sentinel(SRec *s) {
+    s->p0 = make_float4(qnan(), 0.0f, 0.0f, 0.0f);
+    s->p1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    s->p2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// next entry of each group's walk; an exhausted group gets the sentinel slot
+#define GS_WALK_STEP(m, e)                                   \
+    const int e = (m) != 0ull ? (int)__builtin_ctzll(m) : kChunk; \
+    (m) &= (m)-1ull;
+
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ void __launch_bounds__(64)
+k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                    const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
+                    const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                    const float *__restrict__ bg_dev, float *__restrict__ out_img,
+                    float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
+                    float *__restrict__ out_clamped) {
+    __shared__ SRec stage[kChunk + 1];
+    __shared__ uint64_t exp_tab[EXACT ? kExpTabLds : 1];
+    const int lane = threadIdx.x;
+    int tile, qx0, qy0;
+    if (!decode_quadrant(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
+    if (bg_dev) {  // background handed over as a device tensor (no host copy, no sync)
+        bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
+    }
+    if (EXACT) load_exp_table(exp_tab, lane, 64);
+    if (lane == 0) stage_sentinel(&stage[kChunk]);
+
+    const int grp = lane >> 4, li = lane & 15;
+    const uint32_t gsh = 8u * (uint32_t)grp;
+    const int px = qx0 + 4 * (grp & 1) + (li & 3), py = qy0 + 4 * (grp >> 1) + (li >> 2);
+    const bool inimg = px < W && py < H;
+    const float pxf = (float)px;
+    // NaN once the pixel is finished (or outside the image): a NaN row makes sigma NaN
+    float pyf = inimg ? (float)py : qnan();
+    float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    int last = -1;
+
+    const int2 range = bins[tile];
+    // the next chunk's entry of this lane, gathered one chunk ahead (registers, not a struct: a
+    // conditionally filled aggregate ends up in scratch)
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    if (range.x + lane < range.y) {
+        const size_t g = (size_t)ids[range.x + lane];
+        n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
+    }
+    for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
+        const uint64_t alive = __builtin_amdgcn_ballot_w64(pyf == pyf);
+        if (alive == 0ull) break;
+        __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
+        uint32_t touch = 0u;
+        if (c0 + lane < range.y) {
+            stage[lane].p0 = n0;
+            stage[lane].p1 = n1;
+            stage[lane].p2 = n2;
+            touch = block_touch(__float_as_uint(n1.w), __float_as_uint(n2.w), qx0, qy0);
+        }
+        // a block whose 16 pixels are all finished walks nothing
+        uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
+        uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
+        uint64_t m2 = (alive & 0x0000FFFF00000000ull) ? __builtin_amdgcn_ballot_w64((touch & 4u) != 0u) : 0ull;
+        uint64_t m3 = (alive & 0xFFFF000000000000ull) ? __builtin_amdgcn_ballot_w64((touch & 8u) != 0u) : 0ull;
+        __syncthreads();
+        GS_STAT(3, __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+        GS_STAT(4, 1);
+        if (c0 + kChunk + lane < range.y) {
+            const size_t g = (size_t)ids[c0 + kChunk + lane];
+            n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
+        }
+        while ((m0 | m1 | m2 | m3) != 0ull) {
+            GS_WALK_STEP(m0, e0)
+            GS_WALK_STEP(m1, e1)
+            GS_WALK_STEP(m2, e2)
+            GS_WALK_STEP(m3, e3)
+            // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
+            const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
+            const int e = (int)((ep >> gsh) & 0xFFu);
+            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+            const uint32_t sbits = __float_as_uint(q1.z);
+            GS_STAT(0, 1);
+            const float dx = q0.x - pxf, dy = q0.y - pyf;
+            // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217 (same op order)
+            float sg = (q0.z * dx) * dx + (q1.x * dy) * dy;
+            sg = 0.5f * sg;
+            sg = sg + (q0.w * dx) * dy;
+            if (__builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull) {
+                // rare: some group's Gaussian has a rectangle that cuts its sigma_max ellipse —
+                // apply the rectangle per pixel (and turn -0.0 into +0.0, see gs_pack_splats)
+                asm volatile("; rectangle binds");
+                if (sbits & 1u) {
+                    const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                    const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                    (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
+                    sg = in ? sg + 0.0f : qnan();
+                }
+            }
+            // 0 <= sigma <= sigma_max as ONE unsigned compare of the bit patterns
+            const bool need = __float_as_uint(sg) <= sbits;
+            const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+            if (mneed == 0ull) continue;
+            GS_STAT(1, 1);
+            GS_STAT(2, __builtin_popcountll(mneed));
+            float vis = 0.0f;
+            if (need) vis = gs_exp<EXACT>(-sg, exp_tab);
+            // gsplat_cpu.cpp:220-236: alpha = min(0.999, opacity*vis); skip if alpha < 1/255;
+            // nextT = T*(1-alpha); nextT <= 1e-4 -> pixel done (Gaussian not rendered).  A skipped
+            // pixel is given alpha = 0, which composites exactly nothing.
+            float alpha = q1.y * vis;
+            alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.999f);
+            bool ok = alpha >= (1.0f / 255.0f);
+            alpha = ok ? alpha : 0.0f;
+            float nT = T * (1.0f - alpha);
+            if (__builtin_amdgcn_ballot_w64(nT <= 1e-4f) != 0ull) {
+                asm volatile("; pixel saturates");
+                if (nT <= 1e-4f) { pyf = qnan(); alpha = 0.0f; nT = T; ok = false; }
+            }
+            const float w = alpha * T;
+            a0 = a0 + w * q2.x;
+            a1 = a1 + w * q2.y;
+            a2 = a2 + w * q2.z;
+            T = nT;
+            last = ok ? (c0 + e) : last;
+        }
+    }
+    if (inimg) {
+        const size_t pix = (size_t)py * W + px;
+        const float o0 = a0 + T * bg0, o1 = a1 + T * bg1, o2 = a2 + T * bg2;
+        out_img[3 * pix + 0] = o0;
+        out_img[3 * pix + 1] = o1;
+        out_img[3 * pix + 2] = o2;
+        if (out_clamped) {  // fused torch::clamp_max(rgb, 1), model.cpp:222
+            out_clamped[3 * pix + 0] = fminf(o0, 1.0f);
+            out_clamped[3 * pix + 1] = fminf(o1, 1.0f);
+            out_clamped[3 * pix + 2] = fminf(o2, 1.0f);
+        }
+        final_Ts[pix] = T;
+        final_idx[pix] = last;
+    }
+}
+
+// Sums of nine per-lane values over each 16-lane DPP row, in registers: a transposing butterfly.
+// Stage 1 (lane ^ 1) folds value PAIRS — even lanes keep the pair sum of the even value, odd lanes of
+// the odd value — stage 2 (lane ^ 2) does the same with pairs of those, leaving the quad sum of
+// value (lane & 3) [+4]; two rotations by 4 and 8 lanes add the four quads.  13 + 7 + 6 + 2 = 28
+// VALU (13 plain DPP adds), no LDS: the round-1 LDS reduction (9 stores + 4 x 16-byte loads per
+// lane) made the LDS the bottleneck of this kernel once every step carries a reduction
+// (SQ_LDS_IDX_ACTIVE == kernel duration, profiles/r02b).  Lane c (< 9) of each row returns total c.
+__device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float v3, float v4,
+                                             float v5, float v6, float v7, float v8, bool odd,
+                                             bool bit1, int li) {
+    const float w01 = (odd ? v1 : v0) + dpp_f<0xB1>(odd ? v0 : v1);  // quad_perm [1,0,3,2]
+    const float w23 = (odd ? v3 : v2) + dpp_f<0xB1>(odd ? v2 : v3);
+    const float w45 = (odd ? v5 : v4) + dpp_f<0xB1>(odd ? v4 : v5);
+    const float w67 = (odd ? v7 : v6) + dpp_f<0xB1>(odd ? v6 : v7);
+    const float w8 = v8 + dpp_f<0xB1>(v8);
+    float x03 = (bit1 ? w23 : w01) + dpp_f<0x4E>(bit1 ? w01 : w23);  // quad_perm [2,3,0,1]
+    float x47 = (bit1 ? w67 : w45) + dpp_f<0x4E>(bit1 ? w45 : w67);
+    float x8 = w8 + dpp_f<0x4E>(w8);
+    x03 += dpp_f<0x124>(x03);  // row_ror:4
+    x47 += dpp_f<0x124>(x47);
+    x8 += dpp_f<0x124>(x8);
+    x03 += dpp_f<0x128>(x03);  // row_ror:8
+    x47 += dpp_f<0x128>(x47);
+    x8 += dpp_f<0x128>(x8);
+    return li < 4 ? x03 : (li < 8 ? x47 : x8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward.  LDS per wave: staged records 3.1 KB, ids 256 B, per-entry accumulators 9 x 65 floats:
+// 5.7 KB.
+constexpr int kAcc = 9;           // accumulator floats per staged entry
+constexpr int kAccStride = kChunk + 1;  // component-major [9][65]: the nine components of an entry in nine banks
+constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_FLAG_DETERMINISTIC
+
+template <bool EXACT, bool DET>
+__global__ void __launch_bounds__(64)
+k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                     const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
+                     const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                     const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                     const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                     float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    __shared__ SRec stage[kChunk + 1];
+    __shared__ int sid[kChunk];
+    __shared__ float acc[kAcc * kAccStride];
+    const int lane = threadIdx.x;
+    int tile, qx0, qy0;
+    if (!decode_quadrant(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
+    if (bg_dev) {
+        bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
+    }
+    const int grp = lane >> 4, li = lane & 15;
+    const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
+    const uint32_t gsh = 8u * (uint32_t)grp;
+    const int px = qx0 + 4 * (grp & 1) + (li & 3), py = qy0 + 4 * (grp >> 1) + (li >> 2);
+    const bool inimg = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    // transmittance being unwound, T_final * (v_out_alpha - bg . v_out), running <colour buffer,
+    // v_out>, cotangent, list index of the pixel's last contributor
+    float T = 1.0f, TW, bv = 0.0f, vo0 = 0.0f, vo1 = 0.0f, vo2 = 0.0f;
+    int last = -1;
+    {
+        float Tfin = 1.0f, oa = 0.0f;
+        if (inimg) {
+            const size_t pix = (size_t)py * W + px;
+            Tfin = final_Ts[pix];
+            last = final_idx[pix];
+            vo0 = v_out[3 * pix + 0];
+            vo1 = v_out[3 * pix + 1];
+            vo2 = v_out[3 * pix + 2];
+            if (img_raw) {  // backward of the fused clamp_max(rgb, 1): torch passes where rgb <= 1
+                if (!(img_raw[3 * pix + 0] <= 1.0f)) vo0 = 0.0f;
+                if (!(img_raw[3 * pix + 1] <= 1.0f)) vo1 = 0.0f;
+                if (!(img_raw[3 * pix + 2] <= 1.0f)) vo2 = 0.0f;
+            }
+            oa = v_out_alpha ? v_out_alpha[pix] : 0.0f;
+        }
+        T = Tfin;
+        TW = Tfin * (oa - (bg0 * vo0 + bg1 * vo1 + bg2 * vo2));
+    }
+    // last contributor of each 4x4 block (one DPP row) and of the quadrant
+    int gl = last;
+    gl = max(gl, dpp_i<0xB1>(gl));
+    gl = max(gl, dpp_i<0x4E>(gl));
+    gl = max(gl, dpp_i<0x141>(gl));
+    gl = max(gl, dpp_i<0x140>(gl));
+    const int gl0 = __builtin_amdgcn_readlane(gl, 0), gl1 = __builtin_amdgcn_readlane(gl, 16);
+    const int gl2 = __builtin_amdgcn_readlane(gl, 32), gl3 = __builtin_amdgcn_readlane(gl, 48);
+    const int wave_last = max(max(gl0, gl1), max(gl2, gl3));
+    const int2 range = bins[tile];
+    if (wave_last < range.x) return;  // (also covers empty tiles / no contributors)
+
+    if (lane == 0) stage_sentinel(&stage[kChunk]);
+#pragma unroll
+    for (int i = 0; i < kAcc; i++) acc[i * kAccStride + lane] = 0.0f;
+
+    // walk the list back to front in chunks; slot 0 of a chunk is its furthest-back entry
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    int ng = 0;
+    if (wave_last - lane >= range.x) {
+        ng = ids[wave_last - lane];
+        n0 = packed[3 * (size_t)ng + 0]; n1 = packed[3 * (size_t)ng + 1]; n2 = packed[3 * (size_t)ng + 2];
+    }
+    for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
+        __syncthreads();
+        uint32_t touch = 0u;
+        if (hi - lane >= range.x) {
+            stage[lane].p0 = n0;
+            stage[lane].p1 = n1;
+            stage[lane].p2 = n2;
+            sid[lane] = ng;
+            touch = block_touch(__float_as_uint(n1.w), __float_as_uint(n2.w), qx0, qy0);
+        }
+        uint64_t m0 = __builtin_amdgcn_ballot_w64((touch & 1u) != 0u);
+        uint64_t m1 = __builtin_amdgcn_ballot_w64((touch & 2u) != 0u);
+        uint64_t m2 = __builtin_amdgcn_ballot_w64((touch & 4u) != 0u);
+        uint64_t m3 = __builtin_amdgcn_ballot_w64((touch & 8u) != 0u);
+        // entries behind the last contributor of every pixel of a block: slot t has list index
+        // hi - t, needed only if hi - t <= gl_g
+#define GS_TRIM(m, glg)                                                          \
+    {                                                                            \
+        const int d = hi - (glg);                                                \
+        if (d > 0) (m) = d >= kChunk ? 0ull : ((m) & ~((1ull << d) - 1ull));     \
+    }
+        GS_TRIM(m0, gl0) GS_TRIM(m1, gl1) GS_TRIM(m2, gl2) GS_TRIM(m3, gl3)
+#undef GS_TRIM
+        __syncthreads();
+        GS_STAT(11, __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+        GS_STAT(12, 1);
+        if (hi - kChunk - lane >= range.x) {
+            ng = ids[hi - kChunk - lane];
+            n0 = packed[3 * (size_t)ng + 0]; n1 = packed[3 * (size_t)ng + 1]; n2 = packed[3 * (size_t)ng + 2];
+        }
+        bool flushed_any = false;  // wave-uniform
+        while ((m0 | m1 | m2 | m3) != 0ull) {
+            GS_WALK_STEP(m0, e0)
+            GS_WALK_STEP(m1, e1)
+            GS_WALK_STEP(m2, e2)
+            GS_WALK_STEP(m3, e3)
+            // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
+            const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
+            const int e = (int)((ep >> gsh) & 0xFFu);
+            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+            const uint32_t sbits = __float_as_uint(q1.z);
+            const int idx = hi - e;  // index of this entry in the sorted list
+            GS_STAT(8, 1);
+            const float dx = q0.x - pxf, dy = q0.y - pyf;
+            float sg = 0.5f * fmaf(q0.z * dx, dx, (q1.x * dy) * dy);
+            sg = fmaf(q0.w * dx, dy, sg);
+            if (__builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull) {
+                asm volatile("; rectangle binds");
+                if (sbits & 1u) {
+                    // decide exactly like the forward: its op order for sigma, rectangle applied
+                    float se = (q0.z * dx) * dx + (q1.x * dy) * dy;
+                    se = 0.5f * se;
+                    se = se + (q0.w * dx) * dy;
+                    const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                    const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                    (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
+                    sg = in ? se + 0.0f : qnan();
+                }
+            }
+            const bool need = (idx <= last) && (__float_as_uint(sg) <= sbits);
+            const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+            if (mneed == 0ull) continue;
+            GS_STAT(9, 1);
+            GS_STAT(10, __builtin_popcountll(mneed));
+            // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
+            // that do not take part end up with vis = alpha = 0
+            float vis = need ? __expf(-sg) : 0.0f;
+            float alpha = q1.y * vis;
+            if (EXACT) {
+                // same >= 1/255 decision as the forward: redo the exponential exactly (from the
+                // forward's sigma) where the fast one cannot decide
+                const float thr = 1.0f / 255.0f;
+                const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
+                if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+                    asm volatile("; threshold ambiguous");
+                    if (amb) {
+                        float se = (q0.z * dx) * dx + (q1.x * dy) * dy;
+                        se = 0.5f * se;
+                        se = se + (q0.w * dx) * dy;
+                        vis = expf_glibc_cmem(-se);
+                        alpha = q1.y * vis;
+                    }
+                }
+            }
+            const bool ok = alpha >= (1.0f / 255.0f);
+            alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
+            vis = ok ? vis : 0.0f;
+            // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
+            const float om = 1.0f - alpha;
+            float ra = __builtin_amdgcn_rcpf(om);
+            ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
+            T = T * ra;  // transmittance in front of this Gaussian
+            const float fac = alpha * T;
+            const float gr = fac * vo0, gg = fac * vo1, gb = fac * vo2;
+            // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
+            const float cv = fmaf(q2.z, vo2, fmaf(q2.y, vo1, q2.x * vo0));
+            const float v_alpha = fmaf(T, cv, ra * (TW - bv));
+            bv = fmaf(fac, cv, bv);
+            // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
+            const float u = vis * v_alpha;
+            const float ux = u * dx, uy = u * dy;
+            // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
+            const float r = row_reduce9(ux, uy, ux * dx, ux * dy, uy * dy, gr, gg, gb, u, odd, bit1, li);
+            if (li < kAcc && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
+                __hip_atomic_fetch_add(&acc[li * kAccStride + e], r, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            flushed_any = true;
+        }
+        if (!flushed_any) continue;
+        // ---- flush: moments -> gradient components (once per entry), then one atomic lane per
+        //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
+        wave_sync();
+        if (hi - lane >= range.x) {  // (slots beyond the list's head hold no entry)
+            const float Ux = acc[0 * kAccStride + lane], Uy = acc[1 * kAccStride + lane];
+            const float Uxx = acc[2 * kAccStride + lane], Uxy = acc[3 * kAccStride + lane];
+            const float Uyy = acc[4 * kAccStride + lane];
+            const float A = stage[lane].p0.z, B = stage[lane].p0.w, C = stage[lane].p1.x;
+            const float mo = -stage[lane].p1.y;          // v_sigma = -opacity * u
+            acc[0 * kAccStride + lane] = mo * fmaf(A, Ux, B * Uy);   // v_x: v_sigma * (A dx + B dy)
+            acc[1 * kAccStride + lane] = mo * fmaf(B, Ux, C * Uy);   // v_y: v_sigma * (B dx + C dy)
+            acc[2 * kAccStride + lane] = 0.5f * mo * Uxx;            // v_A  (gsplat_cpu.cpp:361-363)
+            acc[3 * kAccStride + lane] = 0.5f * mo * Uxy;            // v_B
+            acc[4 * kAccStride + lane] = 0.5f * mo * Uyy;            // v_C
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < kAcc; i++) {
+            const int k = i * kChunk + lane;          // record-major enumeration: k = 9 * entry + comp
+            const int ent = (k * 7282) >> 16;         // k / 9 for k < 576
+            const int comp = k - 9 * ent;
+            const float v = acc[comp * kAccStride + ent];
+            if (v != 0.0f) {
+                const size_t o = (size_t)sid[ent] * kGradRec + comp;
+                if (DET)
+                    atomicAdd(gfix + o, (unsigned long long)(long long)(v * kFixScale));
+                else
+                    atomicAdd(gacc + o, v);
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < kAcc; i++) acc[i * kAccStride + lane] = 0.0f;
+    }
+}
+#undef GS_WALK_STEP
+
+// Test hook: row_reduce9 on given values.  in [blocks, 9, 64] -> out [blocks, 4, 9] (row, value).
+__global__ void __launch_bounds__(64) k_debug_row_reduce9(const float *__restrict__ in,
+                                                          float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const float *p = in + (size_t)blockIdx.x * 9 * 64;
+    float v[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] = p[i * 64 + lane];
+    const int li = lane & 15;
+    const float r = row_reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], (lane & 1) != 0,
+                                (lane & 2) != 0, li);
+    if (li < 9) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * 9 + li] = r;
+}
+
+// GS_FLAG_DETERMINISTIC: 64-bit fixed-point sums -> the float records
+__global__ void __launch_bounds__(256)
+k_fixed_to_records(int64_t n, const long long *__restrict__ fix, float *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[i] = (float)((double)fix[i] * (1.0 / 1099511627776.0));
+}
+
+}  // namespace gs
+
+extern "C" int gs_debug_row_reduce9(int blocks, const float *in, float *out, gs_stream_t stream) {
+    if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (blocks == 0) return GS_OK;
+    if (!in || !out) return GS_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gs::k_debug_row_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" size_t gs_rasterize_backward_workspace_bytes_det(int N) {
+    // float records + the 64-bit fixed-point accumulators of GS_FLAG_DETERMINISTIC
+    return N > 0 ? (size_t)N * gs::kGradRec * (sizeof(float) + sizeof(long long)) : 0;
+}
+
+extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
+                                    const int32_t *tile_bins, const float *packed,
+                                    const float *background, float *out_img, float *final_Ts,
+                                    int32_t *final_idx, float *out_img_clamped,
+                                    const int32_t *list_stats, const int32_t *tile_order,
+                                    uint32_t flags, gs_stream_t stream) {
+    if (flags & (1u << 20))  // A/B: the round-1 one-wave-per-tile kernels
+        return gs_rasterize_forward_v1(W, H, gaussian_ids_sorted, tile_bins, packed, background, out_img,
+                                       final_Ts, final_idx, out_img_clamped, list_stats, tile_order,
+                                       flags, stream);
+    if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
+    float *clamped = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img_clamped : nullptr;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (!tile_bins || !background || !out_img || !final_Ts || !final_idx)
+        return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    const int tiles = tiles_x * tiles_y;
+    hipStream_t s = (hipStream_t)stream;
+    const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    const int units = 4 * 8 * ((tiles + 7) / 8);  // four quadrant waves per tile, see decode_quadrant
+    const float *bg_dev = gs::on_device(background) ? background : nullptr;
+    const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
+                bg2 = bg_dev ? 0.f : background[2];
+    gs::ev_before(s);
+    if (flags & GS_FLAG_FAST_EXP)
+        hipLaunchKernelGGL((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
+                           tiles, tile_order, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev,
+                           out_img, final_Ts, final_idx, clamped);
+    else
+        hipLaunchKernelGGL((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
+                           tiles, tile_order, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev,
+                           out_img, final_Ts, final_idx, clamped);
+    gs::ev_after(s);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+                                     const int32_t *tile_bins, const float *packed,
+                                     const float *background, const float *final_Ts,
+                                     const int32_t *final_idx, const float *v_out,
+                                     const float *v_out_alpha, const float *out_img, float *v_xy,
+                                     float *v_conic, float *v_colors, float *v_opacity,
+                                     void *workspace, size_t workspace_bytes,
+                                     const int32_t *list_stats, const int32_t *tile_order,
+                                     uint32_t flags, gs_stream_t stream) {
+    if (flags & (1u << 20))  // A/B: the round-1 one-wave-per-tile kernels
+        return gs_rasterize_backward_v1(W, H, N, gaussian_ids_sorted, tile_bins, packed, background,
+                                        final_Ts, final_idx, v_out, v_out_alpha, out_img, v_xy, v_conic,
+                                        v_colors, v_opacity, workspace, workspace_bytes, list_stats,
+                                        tile_order, flags, stream);
+    if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
+    if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
+    const float *img_raw = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img : nullptr;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (N == 0) return GS_OK;
+    const bool keep_records = (flags & GS_FLAG_KEEP_RECORDS) != 0u;
+    const bool det = (flags & GS_FLAG_DETERMINISTIC) != 0u;
+    if (!tile_bins || !background || !final_Ts || !final_idx || !v_out || !workspace)
+        return GS_ERR_INVALID_ARGUMENT;
+    if (!keep_records && (!v_xy || !v_conic || !v_colors || !v_opacity)) return GS_ERR_INVALID_ARGUMENT;
+    if (((uintptr_t)packed & 15u) || ((uintptr_t)workspace & 63u)) return GS_ERR_INVALID_ARGUMENT;
+    const size_t rec_bytes = gs_rasterize_backward_workspace_bytes(N);
+    if (workspace_bytes < (det ? gs_rasterize_backward_workspace_bytes_det(N) : rec_bytes))
+        return GS_ERR_WORKSPACE;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    const int tiles = tiles_x * tiles_y;
+    hipStream_t s = (hipStream_t)stream;
+    const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    float *gacc = static_cast<float *>(workspace);
+    unsigned long long *gfix =
+        det ? reinterpret_cast<unsigned long long *>(static_cast<char *>(workspace) + rec_bytes) : nullptr;
+    if (det)
+        GS_HIP_CHECK(hipMemsetAsync(gfix, 0, (size_t)N * gs::kGradRec * sizeof(long long), s));
+    else if (!(flags & GS_FLAG_RECORDS_ZEROED))
+        GS_HIP_CHECK(hipMemsetAsync(gacc, 0, rec_bytes, s));
+    const int units = 4 * 8 * ((tiles + 7) / 8);
+    const float *bg_dev = gs::on_device(background) ? background : nullptr;
+    const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
+                bg2 = bg_dev ? 0.f : background[2];
+    gs::ev_before(s);
+#define GS_BWD_LAUNCH(EX, DT)                                                                        \
+    hipLaunchKernelGGL((gs::k_rasterize_backward<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
+                       tiles, tile_order, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev,      \
+                       final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+    if (det) {
+        if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, true); else GS_BWD_LAUNCH(true, true);
+    } else {
+        if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, false); else GS_BWD_LAUNCH(true, false);
+    }
+#undef GS_BWD_LAUNCH
+    gs::ev_after(s);
+    GS_LAUNCH_CHECK();
+    if (det) {
+        const int64_t n = (int64_t)N * gs::kGradRec;
+        hipLaunchKernelGGL(gs::k_fixed_to_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n,
+                           reinterpret_cast<const long long *>(gfix), gacc);
+        GS_LAUNCH_CHECK();
+    }
     if (keep_records) return GS_OK;  // the 64-byte records go straight to gs_gaussian_backward
     hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
                        reinterpret_cast<const float4 *>(gacc),

@@ -29,8 +29,11 @@ l.gs_debug_stats(buf, 1)
 pipe.step()
 l.gs_debug_stats(buf, 1)
 v = list(buf)
-names = ["entries", "halves", "halves_need", "exp_passes", "need_lane_pixels", "both_strips_disjoint", "lanes_needing_both"]
-out = {"M": pipe.num_isects,
-       "forward": dict(zip(names, v[0:7])),
-       "backward": dict(zip(["entries", "halves", "halves_need", "entries_any", "need_lane_pixels"], v[8:13]))}
-print(json.dumps(out))
+fwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[0:5]))
+bwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[8:13]))
+M = pipe.num_isects
+for d in (fwd, bwd):
+    d["steps_per_list_entry"] = d["steps"] / max(M, 1)
+    d["ideal_steps_if_groups_balanced"] = d["block_entries"] / 4.0
+    d["live_lanes_per_needing_step"] = d["needing_lanes"] / max(d["steps_with_a_needing_lane"], 1)
+print(json.dumps({"M": M, "forward": fwd, "backward": bwd}))

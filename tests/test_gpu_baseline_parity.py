@@ -22,7 +22,8 @@ Tolerances (also DESIGN.md §3).  Compositing forward on identical 2-D inputs: b
 chain: the device projection differs from the oracle's by fp32 round-off (xys 2e-6 relative), which
 can flip an alpha >= 1/255 or T <= 1e-4 decision for a handful of pixels: at most max(4, 2e-5 P)
 pixels may differ by more than 1e-5, and every gradient tensor must satisfy
-max|d| / max|ref| < 2e-3 (measured values are written to gpurun_out/parity_r02.json).
+max|d| / max|ref| < 2e-5 (measured: 0 flipped pixels and 3e-7 .. 2e-6 on every configuration,
+profiles/parity_r02.json; the tests rewrite gpurun_out/parity_r02.json).
 """
 import json
 import os
@@ -138,7 +139,7 @@ def image_flips(got, want, tol=1e-5):
     return int((d > tol).sum()), float(d.max())
 
 
-def check_chain(name, s, pipe, ref, grad_tol=2e-3, sel=None):
+def check_chain(name, s, pipe, ref, grad_tol=2e-5, sel=None):
     """Image flips + the six parameter gradients of the timed path against the oracle chain."""
     P = s.W * s.H
     img = np_(pipe.fwd["img"])
@@ -232,9 +233,9 @@ def test_splat_render_matches_oracle_with_numpy_glue(K, deg, restated):
         if n == "features_rest" and K == 1:
             continue
         errs[n] = rel_err(np_(leaf.grad), w.reshape(np_(leaf.grad).shape))
-        assert errs[n] < 2e-3, (n, errs[n])
+        assert errs[n] < 2e-5, (n, errs[n])
     errs["xys"] = rel_err(np_(xys_grad), ref["v_xy"])
-    assert errs["xys"] < 2e-3
+    assert errs["xys"] < 2e-5
     _report("splat_render_K%d" % K, image_flipped_pixels=flips, image_max_abs_err=dmax,
             **{"rel_" + k: v for k, v in errs.items()})
 
@@ -336,7 +337,7 @@ def _window_check(name, O, s, pipe, d, o, sh, win):
             **{"rel2d_" + k: v for k, v in e2d.items()}, **{"rel_" + k: v for k, v in errs.items()})
     assert flips <= max(4, 2e-5 * P), (name, flips, dmax)
     for k, e in errs.items():
-        assert e < 2e-3, (name, k, e)
+        assert e < 2e-5, (name, k, e)
 
 
 def _densest_tile_window(pipe, s, w=256, h=160):
@@ -412,5 +413,5 @@ def test_c1_gradients_within_1e4_of_the_compiled_reference():
         rep["maxabs_" + k] = float(np.abs(a - ref).max())
         rep["rel_" + k] = rel_err(a, ref)
         assert rep["maxabs_" + k] < 1e-4, (k, rep["maxabs_" + k])       # the literal bound
-        assert rep["rel_" + k] < 1e-3, (k, rep["rel_" + k])             # and relative to max|g|
+        assert rep["rel_" + k] < 5e-5, (k, rep["rel_" + k])             # and relative to max|g|
     _report("c1_vs_compiled_reference", **rep)

@@ -369,6 +369,25 @@ def test_reduce9_network():
     assert np.array_equal(y[0], 64.0 * (np.arange(9) + 1.0))
 
 
+def test_row_reduce9_butterfly():
+    """The compositing backward's per-group reduction (transposing DPP butterfly over each 16-lane
+    row): lane c < 9 of every row receives the row's total of value c."""
+    from opensplat_amd import cabi
+
+    rs = np.random.RandomState(6)
+    x = rs.uniform(-1, 1, (29, 9, 64)).astype(np.float32)
+    x[0] = np.arange(9, dtype=np.float32)[:, None] + 1.0               # value i == i+1 on every lane
+    x[1] = 0
+    x[1, :, 37] = 10.0 ** np.arange(9)[::-1] / 1e4                     # a single lane (row 2) contributes
+    x[2] = (np.arange(64, dtype=np.float32) % 16 == 5)[None, :] * (np.arange(9)[:, None] + 1.0)
+    y = np_(cabi.debug_row_reduce9(to_dev(x)))
+    ref = x.astype(np.float64).reshape(29, 9, 4, 16).sum(axis=3).transpose(0, 2, 1)
+    assert np.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(y[0], np.broadcast_to(16.0 * (np.arange(9) + 1.0), (4, 9)))
+    assert np.array_equal(y[1][2], x[1, :, 37]) and not y[1][[0, 1, 3]].any()
+    assert np.array_equal(y[2], np.broadcast_to(np.arange(9) + 1.0, (4, 9)))
+
+
 @pytest.mark.parametrize("N,lo,hi", [(3000, 1024, 8192), (14000, 8192, 1 << 30)])
 def test_long_tile_lists_take_the_big_sort_paths(N, lo, hi, restated):
     """> 1024 and > 8192 intersections in one tile exercise the 64 KiB-LDS and the global-memory
