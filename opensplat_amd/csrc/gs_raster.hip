@@ -1072,8 +1072,53 @@ __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float
 constexpr int kAcc = 9;           // accumulator floats per staged entry
 constexpr int kAccStride = kChunk + 1;  // component-major [9][65]: the nine components of an entry in nine banks
 constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_FLAG_DETERMINISTIC
+constexpr int kBackwardPixelsPerLane = 2;      // default WaveGeom of the backward (measured)
 
-template <bool EXACT, bool DET>
+// Wave geometry of the backward kernel, by pixels per lane PX (1, 2 or 4).  A 16-lane group owns a
+// block of BW x BH pixels — lane (li % LW, li / LW) holds the PX pixels of its column at rows
+// r, r + LH, .. (one column per lane: xCam is shared by a lane's pixels) — and a wave owns 2 x 2
+// blocks:  PX = 1: 4x4 blocks, 8x8 wave, four waves per tile;  PX = 2: 4x8 blocks, 8x16 wave, two per
+// tile;  PX = 4: 8x8 blocks, 16x16 wave, one per tile.  More pixels per lane amortise the per-step
+// costs (walk, record read, the nine-value reduction, the LDS atomic) over more pixels; fewer
+// pixels per lane skip more of the pixels a Gaussian cannot reach.
+template <int PX>
+struct WaveGeom {
+    static constexpr int BW = PX == 4 ? 8 : 4, BH = PX == 1 ? 4 : 8;
+    static constexpr int LW = BW, LH = 16 / LW;          // lanes of a group: LW columns x LH rows
+    static constexpr int WW = 2 * BW, WH = 2 * BH;       // pixels of a wave
+    static constexpr int PER_TILE = (GS_TILE / WW) * (GS_TILE / WH);
+};
+
+template <int PX>
+__device__ __forceinline__ bool decode_wave(int block, int num_tiles, int tiles_x, int W, int H,
+                                            const int32_t *__restrict__ order, int &tile, int &wx0,
+                                            int &wy0) {
+    using G = WaveGeom<PX>;
+    const int x = block & 7, k = block >> 3;
+    const int part = k % G::PER_TILE;
+    const int slot = ((k / G::PER_TILE) << 3) + x;
+    if (slot >= num_tiles) return false;
+    tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
+    constexpr int PX_COLS = GS_TILE / G::WW;
+    wx0 = (tile % tiles_x) * GS_TILE + G::WW * (part % PX_COLS);
+    wy0 = (tile / tiles_x) * GS_TILE + G::WH * (part / PX_COLS);
+    return wx0 < W && wy0 < H;
+}
+
+// which of the wave's 2 x 2 blocks the rectangle touches (bit g: block column g & 1, row g >> 1)
+template <int PX>
+__device__ __forceinline__ uint32_t block_touch_g(uint32_t rx, uint32_t ry, int wx0, int wy0) {
+    using G = WaveGeom<PX>;
+    const int x0 = (int)(rx & 0xFFFF) - wx0, x1 = (int)(rx >> 16) - wx0;
+    const int y0 = (int)(ry & 0xFFFF) - wy0, y1 = (int)(ry >> 16) - wy0;
+    if (x1 <= x0 || y1 <= y0) return 0u;
+    const bool c0 = x0 < G::BW && x1 > 0, c1 = x0 < 2 * G::BW && x1 > G::BW;
+    const bool r0 = y0 < G::BH && y1 > 0, r1 = y0 < 2 * G::BH && y1 > G::BH;
+    return (c0 && r0 ? 1u : 0u) | (c1 && r0 ? 2u : 0u) | (c0 && r1 ? 4u : 0u) |
+           (c1 && r1 ? 8u : 0u);
+}
+
+template <bool EXACT, bool DET, int PX>
 __global__ void __launch_bounds__(64)
 k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                      const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
@@ -1082,46 +1127,54 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                      const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                      float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    using G = WaveGeom<PX>;
     __shared__ SRec stage[kChunk + 1];
     __shared__ int sid[kChunk];
     __shared__ float acc[kAcc * kAccStride];
     const int lane = threadIdx.x;
-    int tile, qx0, qy0;
-    if (!decode_quadrant(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
+    int tile, wx0, wy0;
+    if (!decode_wave<PX>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
     const int grp = lane >> 4, li = lane & 15;
     const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
     const uint32_t gsh = 8u * (uint32_t)grp;
-    const int px = qx0 + 4 * (grp & 1) + (li & 3), py = qy0 + 4 * (grp >> 1) + (li >> 2);
-    const bool inimg = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    // transmittance being unwound, T_final * (v_out_alpha - bg . v_out), running <colour buffer,
-    // v_out>, cotangent, list index of the pixel's last contributor
-    float T = 1.0f, TW, bv = 0.0f, vo0 = 0.0f, vo1 = 0.0f, vo2 = 0.0f;
-    int last = -1;
-    {
+    const int px = wx0 + G::BW * (grp & 1) + (li % G::LW);
+    const int py0 = wy0 + G::BH * (grp >> 1) + (li / G::LW);   // pixel p of the lane: row py0 + p * LH
+    const float pxf = (float)px;
+    // per pixel: row, transmittance being unwound, T_final * (v_out_alpha - bg . v_out), running
+    // <colour buffer, v_out>, cotangent, list index of the last contributor
+    float pyf[PX], T[PX], TW[PX], bv[PX], vo0[PX], vo1[PX], vo2[PX];
+    int last[PX];
+    int gl = -1;
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const int py = py0 + p * G::LH;
         float Tfin = 1.0f, oa = 0.0f;
-        if (inimg) {
+        vo0[p] = vo1[p] = vo2[p] = 0.0f;
+        last[p] = -1;
+        if (px < W && py < H) {
             const size_t pix = (size_t)py * W + px;
             Tfin = final_Ts[pix];
-            last = final_idx[pix];
-            vo0 = v_out[3 * pix + 0];
-            vo1 = v_out[3 * pix + 1];
-            vo2 = v_out[3 * pix + 2];
+            last[p] = final_idx[pix];
+            vo0[p] = v_out[3 * pix + 0];
+            vo1[p] = v_out[3 * pix + 1];
+            vo2[p] = v_out[3 * pix + 2];
             if (img_raw) {  // backward of the fused clamp_max(rgb, 1): torch passes where rgb <= 1
-                if (!(img_raw[3 * pix + 0] <= 1.0f)) vo0 = 0.0f;
-                if (!(img_raw[3 * pix + 1] <= 1.0f)) vo1 = 0.0f;
-                if (!(img_raw[3 * pix + 2] <= 1.0f)) vo2 = 0.0f;
+                if (!(img_raw[3 * pix + 0] <= 1.0f)) vo0[p] = 0.0f;
+                if (!(img_raw[3 * pix + 1] <= 1.0f)) vo1[p] = 0.0f;
+                if (!(img_raw[3 * pix + 2] <= 1.0f)) vo2[p] = 0.0f;
             }
             oa = v_out_alpha ? v_out_alpha[pix] : 0.0f;
         }
-        T = Tfin;
-        TW = Tfin * (oa - (bg0 * vo0 + bg1 * vo1 + bg2 * vo2));
+        pyf[p] = (float)py;
+        T[p] = Tfin;
+        TW[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
+        bv[p] = 0.0f;
+        gl = max(gl, last[p]);
     }
-    // last contributor of each 4x4 block (one DPP row) and of the quadrant
-    int gl = last;
+    // last contributor of each block (one DPP row) and of the wave
     gl = max(gl, dpp_i<0xB1>(gl));
     gl = max(gl, dpp_i<0x4E>(gl));
     gl = max(gl, dpp_i<0x141>(gl));
@@ -1151,7 +1204,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             stage[lane].p1 = n1;
             stage[lane].p2 = n2;
             sid[lane] = ng;
-            touch = block_touch(__float_as_uint(n1.w), __float_as_uint(n2.w), qx0, qy0);
+            touch = block_touch_g<PX>(__float_as_uint(n1.w), __float_as_uint(n2.w), wx0, wy0);
         }
         uint64_t m0 = __builtin_amdgcn_ballot_w64((touch & 1u) != 0u);
         uint64_t m1 = __builtin_amdgcn_ballot_w64((touch & 2u) != 0u);
@@ -1186,66 +1239,84 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             const uint32_t sbits = __float_as_uint(q1.z);
             const int idx = hi - e;  // index of this entry in the sorted list
             GS_STAT(8, 1);
-            const float dx = q0.x - pxf, dy = q0.y - pyf;
-            float sg = 0.5f * fmaf(q0.z * dx, dx, (q1.x * dy) * dy);
-            sg = fmaf(q0.w * dx, dy, sg);
-            if (__builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull) {
-                asm volatile("; rectangle binds");
-                if (sbits & 1u) {
-                    // decide exactly like the forward: its op order for sigma, rectangle applied
-                    float se = (q0.z * dx) * dx + (q1.x * dy) * dy;
-                    se = 0.5f * se;
-                    se = se + (q0.w * dx) * dy;
-                    const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
-                    const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
-                                    (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
-                    sg = in ? se + 0.0f : qnan();
-                }
-            }
-            const bool need = (idx <= last) && (__float_as_uint(sg) <= sbits);
-            const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
-            if (mneed == 0ull) continue;
-            GS_STAT(9, 1);
-            GS_STAT(10, __builtin_popcountll(mneed));
-            // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
-            // that do not take part end up with vis = alpha = 0
-            float vis = need ? __expf(-sg) : 0.0f;
-            float alpha = q1.y * vis;
-            if (EXACT) {
-                // same >= 1/255 decision as the forward: redo the exponential exactly (from the
-                // forward's sigma) where the fast one cannot decide
-                const float thr = 1.0f / 255.0f;
-                const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
-                if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
-                    asm volatile("; threshold ambiguous");
-                    if (amb) {
-                        float se = (q0.z * dx) * dx + (q1.x * dy) * dy;
+            const float dx = q0.x - pxf;
+            const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
+            // rectangle test data of the rare entries whose rectangle cuts the sigma_max ellipse
+            const bool any_binds = __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
+            float su = 0.0f, suy = 0.0f, suyy = 0.0f, gr = 0.0f, gg = 0.0f, gb = 0.0f;
+            bool any = false;  // wave-uniform
+#pragma unroll
+            for (int p = 0; p < PX; p++) {
+                const float dy = q0.y - pyf[p];
+                float sg = 0.5f * fmaf(q1.x * dy, dy, Adxdx);
+                sg = fmaf(Bdx, dy, sg);
+                if (any_binds) {
+                    asm volatile("; rectangle binds");
+                    if (sbits & 1u) {
+                        // decide exactly like the forward: its op order for sigma, rectangle applied
+                        float se = Adxdx + (q1.x * dy) * dy;
                         se = 0.5f * se;
-                        se = se + (q0.w * dx) * dy;
-                        vis = expf_glibc_cmem(-se);
-                        alpha = q1.y * vis;
+                        se = se + Bdx * dy;
+                        const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                        const uint32_t pyu = (uint32_t)(py0 + p * G::LH);
+                        const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                        pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
+                        sg = in ? se + 0.0f : qnan();
                     }
                 }
+                const bool need = (idx <= last[p]) && (__float_as_uint(sg) <= sbits);
+                const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+                if (mneed == 0ull) continue;
+                any = true;
+                GS_STAT(9, 1);
+                GS_STAT(10, __builtin_popcountll(mneed));
+                // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
+                // that do not take part end up with vis = alpha = 0
+                float vis = need ? __expf(-sg) : 0.0f;
+                float alpha = q1.y * vis;
+                if (EXACT) {
+                    // same >= 1/255 decision as the forward: redo the exponential exactly (from the
+                    // forward's sigma) where the fast one cannot decide
+                    const float thr = 1.0f / 255.0f;
+                    const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
+                    if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+                        asm volatile("; threshold ambiguous");
+                        if (amb) {
+                            float se = Adxdx + (q1.x * dy) * dy;
+                            se = 0.5f * se;
+                            se = se + Bdx * dy;
+                            vis = expf_glibc_cmem(-se);
+                            alpha = q1.y * vis;
+                        }
+                    }
+                }
+                const bool ok = alpha >= (1.0f / 255.0f);
+                alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
+                vis = ok ? vis : 0.0f;
+                // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
+                const float om = 1.0f - alpha;
+                float ra = __builtin_amdgcn_rcpf(om);
+                ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
+                T[p] = T[p] * ra;  // transmittance in front of this Gaussian
+                const float fac = alpha * T[p];
+                gr = fmaf(fac, vo0[p], gr);
+                gg = fmaf(fac, vo1[p], gg);
+                gb = fmaf(fac, vo2[p], gb);
+                // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
+                const float cv = fmaf(q2.z, vo2[p], fmaf(q2.y, vo1[p], q2.x * vo0[p]));
+                const float v_alpha = fmaf(T[p], cv, ra * (TW[p] - bv[p]));
+                bv[p] = fmaf(fac, cv, bv[p]);
+                // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
+                const float u = vis * v_alpha;
+                const float uy = u * dy;
+                su += u;
+                suy += uy;
+                suyy = fmaf(uy, dy, suyy);
             }
-            const bool ok = alpha >= (1.0f / 255.0f);
-            alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
-            vis = ok ? vis : 0.0f;
-            // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
-            const float om = 1.0f - alpha;
-            float ra = __builtin_amdgcn_rcpf(om);
-            ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
-            T = T * ra;  // transmittance in front of this Gaussian
-            const float fac = alpha * T;
-            const float gr = fac * vo0, gg = fac * vo1, gb = fac * vo2;
-            // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
-            const float cv = fmaf(q2.z, vo2, fmaf(q2.y, vo1, q2.x * vo0));
-            const float v_alpha = fmaf(T, cv, ra * (TW - bv));
-            bv = fmaf(fac, cv, bv);
-            // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
-            const float u = vis * v_alpha;
-            const float ux = u * dx, uy = u * dy;
+            if (!any) continue;
             // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
-            const float r = row_reduce9(ux, uy, ux * dx, ux * dy, uy * dy, gr, gg, gb, u, odd, bit1, li);
+            const float ux = su * dx;
+            const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1, li);
             if (li < kAcc && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
                 __hip_atomic_fetch_add(&acc[li * kAccStride + e], r, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1406,20 +1477,30 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         GS_HIP_CHECK(hipMemsetAsync(gfix, 0, (size_t)N * gs::kGradRec * sizeof(long long), s));
     else if (!(flags & GS_FLAG_RECORDS_ZEROED))
         GS_HIP_CHECK(hipMemsetAsync(gacc, 0, rec_bytes, s));
-    const int units = 4 * 8 * ((tiles + 7) / 8);
+    // pixels per lane of the backward (WaveGeom): flag bits 21..22 select 1 / 2 / 4 for experiments
+    int px_per_lane = gs::kBackwardPixelsPerLane;
+    if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
+    const int units = (px_per_lane == 1 ? 4 : (px_per_lane == 2 ? 2 : 1)) * 8 * ((tiles + 7) / 8);
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
-#define GS_BWD_LAUNCH(EX, DT)                                                                        \
-    hipLaunchKernelGGL((gs::k_rasterize_backward<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
-                       tiles, tile_order, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev,      \
+#define GS_BWD_LAUNCH3(EX, DT, PXN)                                                                       \
+    hipLaunchKernelGGL((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
+                       tiles, tile_order, gaussian_ids_sorted, bins, pk, bg0, bg1, bg2, bg_dev,           \
                        final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+#define GS_BWD_LAUNCH(EX, DT)                                      \
+    do {                                                           \
+        if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);           \
+        else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);      \
+        else GS_BWD_LAUNCH3(EX, DT, 4);                            \
+    } while (0)
     if (det) {
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, true); else GS_BWD_LAUNCH(true, true);
     } else {
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, false); else GS_BWD_LAUNCH(true, false);
     }
+#undef GS_BWD_LAUNCH3
 #undef GS_BWD_LAUNCH
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
