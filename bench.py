@@ -491,8 +491,6 @@ def main():
     if args.order != "given":
         reorder_scene(scene, args.order)
     flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
-    if os.environ.get("GSPLAT_RASTER_V1"):   # A/B: the round-1 one-wave-per-tile compositing kernels
-        flags |= 1 << 20
     if os.environ.get("GSPLAT_BWD_PX"):      # A/B: pixels per lane of the compositing backward (1, 2, 4)
         flags |= ({"1": 1, "2": 2, "4": 3}[os.environ["GSPLAT_BWD_PX"]]) << 21
     pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels)

@@ -266,9 +266,6 @@ int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags, gs_stream
  * calling thread (the compositing kernel alone), then disarms itself. */
 int gs_debug_time_next_kernel(void *event_start, void *event_stop);
 
-/* Test hook: the nine-value wave reduction of the backward kernel.
- *   in [blocks, 9, 64] (value i of lane l at in[b][i][l])  ->  out[blocks, 9] = sums over lanes. */
-int gs_debug_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
 /* Test hook: the per-row (16-lane) nine-value reduction of the compositing backward (a transposing
  * DPP butterfly, no LDS).  in [blocks, 9, 64]  ->  out[blocks, 4, 9] = sums over each 16-lane row. */
 int gs_debug_row_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);

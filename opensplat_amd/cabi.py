@@ -31,7 +31,7 @@ SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
-    "gs_debug_reduce9", "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
+    "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
@@ -327,14 +327,6 @@ def debug_expf(x, flags=0):
     y = torch.empty_like(x)
     _check(lib().gs_debug_expf(C.c_int64(x.numel()), _p(x), _p(y), C.c_uint32(flags), _stream()),
            "gs_debug_expf")
-    return y
-
-
-def debug_reduce9(x):
-    """x [blocks, 9, 64] -> [blocks, 9]: the backward kernel's transposing wave reduction."""
-    blocks = x.shape[0]
-    y = torch.empty((blocks, 9), device=x.device, dtype=torch.float32)
-    _check(lib().gs_debug_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_reduce9")
     return y
 
 

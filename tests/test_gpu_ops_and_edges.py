@@ -352,23 +352,6 @@ def test_c2_crop_matches_oracle(c2_run, restated):
     assert np.abs(got - f["img"]).max() < 2e-3
 
 
-def test_reduce9_network():
-    """The backward kernel's wave reduction (through LDS + a DPP quad step) sums each of the nine
-    values over the 64 lanes and delivers total i at the lane that scatters component i."""
-    from opensplat_amd import cabi
-
-    rs = np.random.RandomState(5)
-    x = rs.uniform(-1, 1, (37, 9, 64)).astype(np.float32)
-    x[0] = 0
-    x[0, :, :] = np.arange(9, dtype=np.float32)[:, None] + 1.0      # value i == i+1 on every lane
-    x[1] = 0
-    x[1, :, 17] = 10.0 ** np.arange(9)[::-1] / 1e4                   # a single lane contributes
-    y = np_(cabi.debug_reduce9(to_dev(x)))
-    ref = x.astype(np.float64).sum(axis=2)
-    assert np.allclose(y, ref, rtol=1e-5, atol=1e-5)
-    assert np.array_equal(y[0], 64.0 * (np.arange(9) + 1.0))
-
-
 def test_row_reduce9_butterfly():
     """The compositing backward's per-group reduction (transposing DPP butterfly over each 16-lane
     row): lane c < 9 of every row receives the row's total of value c."""
@@ -478,49 +461,34 @@ def test_speculative_binning_survives_a_too_small_id_buffer():
     assert np.array_equal(np_(b.gaussian_ids_sorted), np_(ref["binned"].gaussian_ids_sorted))
 
 
-@pytest.mark.parametrize("force", [1, 2, 3])
-def test_tiles_shared_by_one_two_or_four_waves_render_the_same(force, restated):
-    """Scheduling only: whether a tile is composited by 1, 2 (8 rows each) or 4 (4 rows each) waves
-    must not change a bit of the forward outputs, nor the gradients beyond summation order."""
-    import torch
-
-    from opensplat_amd import cabi
-
+def test_hot_spot_scene_matches_oracle(restated):
+    """30 % of the Gaussians in a 40-px window: a few tiles with very long lists (their four / two
+    waves walk them chunk by chunk).  Forward bit-exact, backward within summation order."""
     s = scenes.camera_scene(9000, 203, 117, K=0, seed=67, znear=1.0, zfar=100.0, sigma_px=(1.0, 6.0),
                             hot=(0.3, 40))
     base = hip_pipeline(s, backward=True)
-    b = base["binned"]
-    fl = force << 16
-    f = cabi.rasterize_forward(s.W, s.H, b, s.background, fl)
-    g = cabi.rasterize_backward(s.W, s.H, s.N, b, s.background, f["final_Ts"], f["final_idx"],
-                                to_dev(s.v_out), fl)
-    torch.cuda.synchronize()
-    for k in ["img", "final_Ts", "final_idx"]:
-        assert np.array_equal(np_(f[k]), np_(base[k])), k
+    fo, go = oracle_raster(restated, s, np_(base["xys"]), np_(base["conics"]), np_(base["colors"]),
+                           np_(base["cov2d"]), np_(base["depths"]), s.v_out)
+    assert np.array_equal(np_(base["img"]), fo["img"])
+    assert np.array_equal(np_(base["final_Ts"]), fo["final_Ts"])
     for k in ["v_xy", "v_conic", "v_colors", "v_opacity"]:
-        assert rel_err(np_(g[k]), np_(base[k])) < 1e-5, k
-    fo, _ = oracle_raster(restated, s, np_(base["xys"]), np_(base["conics"]), np_(base["colors"]),
-                          np_(base["cov2d"]), np_(base["depths"]))
-    assert np.array_equal(np_(f["img"]), fo["img"])
+        assert rel_err(np_(base[k]), go[k].reshape(np_(base[k]).shape)) < 2e-5, k
 
 
-def test_long_lists_switch_the_launch_to_several_waves_per_tile():
-    """A hot spot (30 % of the Gaussians in a 40-px window) makes gs_bin_scan report a longest list
-    far above the average; the compositing launches then use 2-4 blocks per tile."""
-    from opensplat_amd import cabi
-
+def test_bin_scan_reports_the_list_statistics():
+    """gs_bin_scan stores {M, longest tile list} in pinned host memory (the sort picks its
+    long-segment launches from the previous frame's values)."""
     s = scenes.camera_scene(30000, 320, 200, K=0, seed=71, znear=1.0, zfar=100.0, hot=(0.3, 40))
     out = hip_pipeline(s, backward=False)
     st = out["binned"].list_stats
     tiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
     lens = np_(out["binned"].tile_bins)
     assert st[0] == out["binned"].num_isects and st[1] == int((lens[:, 1] - lens[:, 0]).max())
-    assert st[1] > 6 * max(st[0] // tiles, 64) + 512          # -> four blocks per tile
+    assert st[1] > 6 * max(st[0] // tiles, 64) + 512
 
 
 def test_stale_list_statistics_only_cost_time():
-    """The sort skips its long-segment launches and the compositing picks its waves-per-tile from
-    the PREVIOUS frame's {M, longest list}.  A frame that suddenly has 10x longer lists must still
+    """The sort skips its long-segment launches according to the PREVIOUS frame's {M, longest list}.  A frame that suddenly has 10x longer lists must still
     come out right (the short-segment kernel then sorts the long ones itself)."""
     import torch
 
