@@ -18,9 +18,10 @@ ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["gs_api.hip", "gs_project.hip", "gs_sh.hip", "gs_bin.hip", "gs_raster.hip",
-               "gs_loss.hip", "gs_adam.hip", "gs_densify.hip", "gs_fused.hip"]
+               "gs_loss.hip", "gs_adam.hip", "gs_densify.hip", "gs_fused.hip", "gs_compat.hip"]
 HIP_HEADERS = ["gs_device.h", "gs_gaussian.h", os.path.join(INCLUDE, "gsplat_hip.h"),
-               os.path.join(INCLUDE, "gsplat_train.h"), os.path.join(INCLUDE, "gsplat_densify.h")]
+               os.path.join(INCLUDE, "gsplat_train.h"), os.path.join(INCLUDE, "gsplat_densify.h"),
+               os.path.join(INCLUDE, "gsplat_compat.h")]
 HIP_LIB = os.path.join(CSRC, "libgsplat_hip.so")
 TORCH_LIB = os.path.join(CSRC, "libgsplat_torch.so")
 
@@ -55,7 +56,9 @@ def build_torch(force: bool = False) -> str:
 
     tdir = os.path.dirname(torch.__file__)
     src = os.path.join(CSRC, "torch_ops.cpp")
-    deps = [src, os.path.join(CSRC, "gsplat_ops.hpp"), os.path.join(INCLUDE, "gsplat_hip.h"), HIP_LIB]
+    launcher = os.path.join(CSRC, "bindings_hip_native.cpp")   # the eight *_tensor launchers
+    deps = [src, launcher, os.path.join(CSRC, "bindings_hip_native.h"), os.path.join(CSRC, "gsplat_ops.hpp"),
+            os.path.join(INCLUDE, "gsplat_hip.h"), os.path.join(INCLUDE, "gsplat_compat.h"), HIP_LIB]
     if force or _stale(TORCH_LIB, deps):
         _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w",
               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
@@ -63,7 +66,7 @@ def build_torch(force: bool = False) -> str:
               "-I" + os.path.join(tdir, "include"),
               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
               "-I/opt/rocm/include",
-              "torch_ops.cpp", "-o", TORCH_LIB,
+              "torch_ops.cpp", "bindings_hip_native.cpp", "-o", TORCH_LIB,
               "-L" + CSRC, "-lgsplat_hip",
               "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
               "-lc10_hip", "-Wl,-rpath,$ORIGIN"])

@@ -116,3 +116,34 @@ def test_fused_stage_argument_validation_without_gpu():
     assert bwd(10, 16, 3, 10 * 64 - 1) == -3       # record workspace too small
     assert bwd(10, 16, 3, 640, records=ctypes.c_void_p(4100)) == -1   # 64-byte aligned records
     assert bwd(10, 7, 0, 640) == -1
+
+
+def test_every_header_under_include_is_exported():
+    """All four C-ABI headers (path, training step, densification, launcher-level compatibility):
+    every declared function is exported by libgsplat_hip.so."""
+    l = ctypes.CDLL(_build.HIP_LIB)
+    for header in ("gsplat_hip.h", "gsplat_train.h", "gsplat_densify.h", "gsplat_compat.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names = sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+        assert names, header
+        missing = [n for n in names if not hasattr(l, n)]
+        assert not missing, (header, missing)
+    # argument validation of the compatibility launchers (no device work)
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(64)
+    assert l.gs_compat_tiles_hit(-1, one, one, 4, 4, one, null) == -1
+    assert l.gs_compat_tiles_hit(0, null, null, 4, 4, null, null) == 0
+    assert l.gs_compat_map_intersects(5, one, one, one, null, 4, 4, one, one, null) == -1
+    assert l.gs_compat_tile_bin_edges(ctypes.c_int64(0), null, null, null) == 0
+
+
+def test_launcher_level_functions_are_registered():
+    import torch
+
+    from opensplat_amd import ops  # noqa: F401
+
+    for name in ["launcher_project_gaussians_forward", "launcher_project_gaussians_backward",
+                 "launcher_compute_sh_forward", "launcher_compute_sh_backward",
+                 "launcher_map_gaussian_to_intersects", "launcher_get_tile_bin_edges",
+                 "launcher_rasterize_forward", "launcher_rasterize_backward"]:
+        assert hasattr(torch.ops.opensplat_amd, name), name

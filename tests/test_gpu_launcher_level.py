@@ -1,0 +1,106 @@
+"""-m gpu: the LAUNCHER-LEVEL binding (opensplat_amd/csrc/bindings_hip_native.cpp): the eight
+`*_tensor` functions of rasterizer/gsplat/bindings.h, driven exactly as OpenSplat's own operator
+files drive them (rasterize_gaussians.cpp:6-37,56-75: cumsum -> map_gaussian_to_intersects_tensor ->
+torch::sort -> gather -> get_tile_bin_edges_tensor -> rasterize_forward_tensor; :100-124
+rasterize_backward_tensor), compared with the native path of this repo.
+
+At this level tiles are assigned by the GPU reference's radius square (forward.cu:86-94), natively by
+the tightened CPU pixel rectangle; a Gaussian whose rectangle reaches a tile its radius square does not
+(~1 in 10^4 pixel-Gaussian pairs) is taken out of the scene (opacity 0), after which
+both paths composite the same contributor lists and must agree BIT FOR BIT in the forward."""
+import numpy as np
+import pytest
+
+from opensplat_amd import scenes
+from tests.util import np_, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _glue_bin_and_sort(T, xys, depths, radii, num_tiles_hit, tiles_x, tiles_y):
+    """rasterize_gaussians.cpp:6-37,62-66 with torch ops, as the reference runs it."""
+    import torch
+
+    cum = torch.cumsum(num_tiles_hit, 0, dtype=torch.int32)
+    M = int(cum[-1].item())
+    ids, gids = T.launcher_map_gaussian_to_intersects(M, xys, depths, radii, cum, tiles_x, tiles_y)
+    ids_sorted, order = torch.sort(ids)
+    gids_sorted = torch.gather(gids, 0, order)
+    bins = T.launcher_get_tile_bin_edges(M, ids_sorted)
+    return M, ids_sorted, gids_sorted.contiguous(), bins
+
+
+@pytest.mark.parametrize("W,H,N", [(320, 200, 6000), (203, 117, 3000)])
+def test_reference_operator_glue_on_the_launcher_functions(W, H, N):
+    import torch
+
+    from opensplat_amd import cabi, ops  # noqa: F401  (loads libgsplat_torch.so)
+
+    T = torch.ops.opensplat_amd
+    s = scenes.camera_scene(N, W, H, K=16, seed=61, znear=1.0, zfar=100.0, yaw_deg=3.0, sigma_px=(0.6, 5.0))
+    tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
+    means, scales, quats = to_dev(s.means), to_dev(s.scales), to_dev(s.quats)
+    vm, pm = to_dev(s.viewmat), to_dev(s.projmat)
+    cov3d, xys, depths, radii, conics, tiles_hit = T.launcher_project_gaussians_forward(
+        means, scales, 1.0, quats, vm, pm, s.fx, s.fy, s.cx, s.cy, H, W, tiles_x, tiles_y, 0.01)
+    cam = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, W, H)
+    p = cabi.project_forward(cam, means, scales, quats)
+    for a, b in ((xys, p["xys"]), (depths, p["depths"]), (radii, p["radii"]), (conics, p["conics"]),
+                 (cov3d, p["cov3d"])):
+        assert torch.equal(a, b)
+    dirs, coeffs = to_dev(s.dirs), to_dev(s.sh_coeffs)
+    sh = T.launcher_compute_sh_forward(3, s.degrees_to_use, dirs, coeffs)
+    assert torch.equal(sh, cabi.sh_forward(s.degrees_to_use, dirs, coeffs))
+    colors = torch.clamp_min(sh + 0.5, 0.0)
+    opac = to_dev(s.opacities.reshape(-1, 1)).clone()
+
+    # Gaussians whose tightened rectangle reaches a tile outside their radius square: out of the scene
+    nat = cabi.bin_and_sort(W, H, xys, depths, radii, conics, colors, opac.reshape(-1).contiguous(), None)
+    pk = np_(nat.packed).view(np.uint32)
+    rx, ry = pk[:, 7], pk[:, 11]
+    x0, x1, y0, y1 = rx & 0xFFFF, rx >> 16, ry & 0xFFFF, ry >> 16
+    c, r = np_(xys), np_(radii).astype(np.float32)
+    trunc = lambda v: np.trunc(v).astype(np.int64)
+    sx0 = np.clip(trunc(c[:, 0] / 16 - r / 16), 0, tiles_x); sx1 = np.clip(trunc(c[:, 0] / 16 + r / 16 + 1), 0, tiles_x)
+    sy0 = np.clip(trunc(c[:, 1] / 16 - r / 16), 0, tiles_y); sy1 = np.clip(trunc(c[:, 1] / 16 + r / 16 + 1), 0, tiles_y)
+    empty = (x1 <= x0) | (y1 <= y0)
+    inside = (x0 // 16 >= sx0) & ((x1 + 15) // 16 <= sx1) & (y0 // 16 >= sy0) & ((y1 + 15) // 16 <= sy1)
+    bad = ~(inside | empty)
+    assert bad.mean() < 0.2
+    opac[torch.from_numpy(bad).cuda()] = 0.0
+
+    # ---- launcher level, driven like rasterize_gaussians.cpp ----
+    M, ids_sorted, gids_sorted, bins = _glue_bin_and_sort(T, xys, depths, radii, tiles_hit, tiles_x, tiles_y)
+    assert M == int(tiles_hit.sum()) and M > N
+    k = np_(ids_sorted)
+    assert (np.diff(k) >= 0).all()
+    tile_of = (k >> 32).astype(np.int64)
+    b = np_(bins)[: tiles_x * tiles_y]
+    for t in np.unique(tile_of)[:40]:          # [start, end) of every tile's run
+        assert (tile_of[b[t, 0]:b[t, 1]] == t).all() and (b[t, 1] - b[t, 0]) == (tile_of == t).sum()
+    bg = to_dev(s.background)
+    img, Ts, fidx = T.launcher_rasterize_forward(tiles_x, tiles_y, W, H, gids_sorted, bins, xys, conics, colors,
+                                                 opac, bg)
+    v_out = to_dev(s.v_out)
+    g = T.launcher_rasterize_backward(H, W, gids_sorted, bins, xys, conics, colors, opac, bg, Ts, fidx, v_out,
+                                      torch.zeros((H, W), device="cuda"))
+
+    # ---- native path on the same 2-D inputs (rectangle derived from the conics, like the launcher's) ----
+    nat = cabi.bin_and_sort(W, H, xys, depths, radii, conics, colors, opac.reshape(-1).contiguous(), None)
+    f = cabi.rasterize_forward(W, H, nat, s.background)
+    gn = cabi.rasterize_backward(W, H, N, nat, s.background, f["final_Ts"], f["final_idx"], v_out)
+    torch.cuda.synchronize()
+    assert torch.equal(img, f["img"]) and torch.equal(Ts, f["final_Ts"])
+    for a, name in zip(g, ("v_xy", "v_conic", "v_colors", "v_opacity")):
+        assert rel_err(np_(a).reshape(np_(gn[name]).shape), np_(gn[name])) < 2e-5, name
+    assert tuple(g[3].shape) == (N, 1)                      # bindings.cu:596: v_opacity [N, 1]
+
+    # ---- the remaining two launchers against the stage kernels ----
+    v_coeffs = T.launcher_compute_sh_backward(3, s.degrees_to_use, dirs, g[2].contiguous())
+    assert torch.equal(v_coeffs, cabi.sh_backward(s.degrees_to_use, 16, dirs, g[2].contiguous()))
+    pb = T.launcher_project_gaussians_backward(means, scales, 1.0, quats, vm, pm, s.fx, s.fy, s.cx, s.cy, H, W,
+                                               cov3d, radii, conics, g[0], torch.zeros(N, device="cuda"), g[1])
+    ref = cabi.project_backward(cam, means, scales, quats, radii, g[0].contiguous(), g[1].contiguous(),
+                                torch.zeros(N, device="cuda"))
+    assert torch.equal(pb[2], ref["v_means"]) and torch.equal(pb[3], ref["v_scales"]) and torch.equal(pb[4], ref["v_quats"])
+    assert not pb[0].any() and not pb[1].any()              # v_cov2d / v_cov3d: unused scratch outputs
