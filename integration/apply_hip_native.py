@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Patches an OpenSplat checkout so that its OWN call sites (model.cpp:114-222,
+simple_trainer.cpp:152-192) build against the MI355X-native operators of libgsplat_torch.so while the
+CPU classes (ProjectGaussiansCPU / RasterizeGaussiansCPU / SphericalHarmonicsCPU) stay exactly
+where they are — both are used in the same translation unit (model.cpp:123-135,182,195-206).
+
+    python integration/apply_hip_native.py /path/to/OpenSplat [--out DIR]
+
+Edits (all under a new macro USE_HIP_NATIVE, so every other configuration is untouched; nothing is
+copied out of the checkout, the seven files are edited in place or into --out):
+
+  project_gaussians.hpp / rasterize_gaussians.hpp / spherical_harmonics.hpp
+      the `#if defined(USE_HIP) || defined(USE_CUDA) || defined(USE_MPS)` block that DECLARES the GPU
+      class (and binAndSortGaussians) becomes
+          #ifdef USE_HIP_NATIVE
+          #include "gsplat_ops.hpp"        // this repo: same class names / argument order
+          #else  <the original block>  #endif
+      the CPU class declarations below it are not touched.
+  project_gaussians.cpp / rasterize_gaussians.cpp / spherical_harmonics.cpp
+      the same guard around the GPU class DEFINITIONS gets `&& !defined(USE_HIP_NATIVE)` (they call
+      rasterizer/gsplat's CUDA launchers); the CPU definitions below stay.
+  gsplat.hpp
+      `#include <gsplat/bindings.h>` (pulls forward.cuh / glm) is skipped under USE_HIP_NATIVE.
+
+CMake (print with --cmake): a GPU_RUNTIME value HIP_NATIVE that defines USE_HIP USE_HIP_NATIVE, adds
+this repo's opensplat_amd/csrc to the include path and links libgsplat_torch.so + libgsplat_hip.so
+instead of building rasterizer/gsplat.
+
+tests/test_integration_build.py applies this script to a scratch copy of the reference and builds +
+runs a translation unit shaped like Model::forward against the result.
+"""
+import argparse
+import os
+import re
+import shutil
+import sys
+
+GUARD = "#if defined(USE_HIP) || defined(USE_CUDA) || defined(USE_MPS)"
+HEADERS = ["project_gaussians.hpp", "rasterize_gaussians.hpp", "spherical_harmonics.hpp"]
+SOURCES = ["project_gaussians.cpp", "rasterize_gaussians.cpp", "spherical_harmonics.cpp"]
+
+CMAKE_SNIPPET = r'''
+# ---- OpenSplat CMakeLists.txt: MI355X-native rasterizer (GPU_RUNTIME=HIP_NATIVE) -----------------
+elseif(GPU_RUNTIME STREQUAL "HIP_NATIVE")
+    set(GSPLAT_AMD_DIR "" CACHE PATH "opensplat_amd/csrc of the MI355X rasterizer repo")
+    find_library(GSPLAT_HIP   gsplat_hip   HINTS ${GSPLAT_AMD_DIR} REQUIRED)   # hand-written gfx950 kernels
+    find_library(GSPLAT_TORCH gsplat_torch HINTS ${GSPLAT_AMD_DIR} REQUIRED)   # libtorch operators
+    add_library(gsplat_cpu rasterizer/gsplat-cpu/gsplat_cpu.cpp)               # unchanged
+    set(GSPLAT_LIBS gsplat_cpu ${GSPLAT_TORCH} ${GSPLAT_HIP})                  # rasterizer/gsplat is NOT built
+    add_compile_definitions(USE_HIP USE_HIP_NATIVE __HIP_PLATFORM_AMD__)
+    include_directories(${GSPLAT_AMD_DIR})                                     # gsplat_ops.hpp
+'''
+
+
+def patch_header(text: str, name: str) -> str:
+    if "USE_HIP_NATIVE" in text:
+        return text
+    i = text.find(GUARD)
+    if i < 0:
+        raise SystemExit("%s: GPU-class guard not found (different OpenSplat version?)" % name)
+    j = text.find("#endif", i)
+    if j < 0:
+        raise SystemExit("%s: unterminated guard" % name)
+    j += len("#endif")
+    block = text[i:j]
+    new = ("#ifdef USE_HIP_NATIVE\n"
+           "// MI355X-native GPU operators (libgsplat_torch.so): same class names, argument order and\n"
+           "// return order as the declarations in the #else branch\n"
+           "#include \"gsplat_ops.hpp\"\n"
+           "#else\n" + block + "\n#endif")
+    return text[:i] + new + text[j:]
+
+
+def patch_source(text: str, name: str) -> str:
+    if "USE_HIP_NATIVE" in text:
+        return text
+    if GUARD not in text:
+        raise SystemExit("%s: GPU-definition guard not found" % name)
+    return text.replace(GUARD, "#if (defined(USE_HIP) || defined(USE_CUDA) || defined(USE_MPS)) && "
+                               "!defined(USE_HIP_NATIVE)", 1)
+
+
+def patch_gsplat_hpp(text: str) -> str:
+    if "USE_HIP_NATIVE" in text:
+        return text
+    pat = re.compile(r"#if defined\(USE_HIP\) \|\| defined\(USE_CUDA\)\s*\n(\s*#include <gsplat/bindings.h>)")
+    if not pat.search(text):
+        raise SystemExit("gsplat.hpp: bindings.h include not found")
+    return pat.sub(r"#if (defined(USE_HIP) || defined(USE_CUDA)) && !defined(USE_HIP_NATIVE)\n\1", text, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("checkout", nargs="?", help="root of the OpenSplat source tree")
+    ap.add_argument("--out", help="write the patched files here instead of editing in place")
+    ap.add_argument("--cmake", action="store_true", help="print the CMakeLists.txt snippet and exit")
+    a = ap.parse_args()
+    if a.cmake or not a.checkout:
+        print(CMAKE_SNIPPET)
+        return
+    out = a.out or a.checkout
+    os.makedirs(out, exist_ok=True)
+    jobs = [(h, patch_header) for h in HEADERS] + [(s, patch_source) for s in SOURCES]
+    for name, fn in jobs:
+        text = open(os.path.join(a.checkout, name)).read()
+        open(os.path.join(out, name), "w").write(fn(text, name))
+    text = open(os.path.join(a.checkout, "gsplat.hpp")).read()
+    open(os.path.join(out, "gsplat.hpp"), "w").write(patch_gsplat_hpp(text))
+    if a.out:   # the untouched headers the patched ones include
+        shutil.copy(os.path.join(a.checkout, "tile_bounds.hpp"), out)
+    print("patched: %s" % ", ".join(HEADERS + SOURCES + ["gsplat.hpp"]), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""The reference-side binding of INTEGRATION.md §1, proven by a build.
+
+`integration/apply_hip_native.py` patches OpenSplat's three operator headers / sources and gsplat.hpp
+(new macro USE_HIP_NATIVE); `tests/integration/model_forward_tu.cpp` is a translation unit shaped like
+Model::forward (model.cpp:114-222: CPU classes in the `device == kCPU` branch, GPU classes in the
+other, reference argument types).  `__graft_entry__.build()` compiles that TU against a scratch copy
+of the patched reference (only in the container that has /root/reference) and links it with the
+reference's own operator files (CPU parts), gsplat_cpu.cpp and libgsplat_torch.so + libgsplat_hip.so
+into oracle/_ref/model_forward_shim.  Here: the patch script's effect, and the built program."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "oracle", "_ref", "model_forward_shim")
+REF = "/root/reference"
+
+
+def _lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
+def test_patch_script_guards_only_the_gpu_declarations(tmp_path):
+    r = subprocess.run(["python3", os.path.join(ROOT, "integration", "apply_hip_native.py"), REF, "--out",
+                        str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name, cpu_class in (("project_gaussians.hpp", "class ProjectGaussiansCPU"),
+                            ("rasterize_gaussians.hpp", "class RasterizeGaussiansCPU"),
+                            ("spherical_harmonics.hpp", "class SphericalHarmonicsCPU")):
+        new = open(tmp_path / name).read()
+        old = open(os.path.join(REF, name)).read()
+        assert '#include "gsplat_ops.hpp"' in new and new.count("USE_HIP_NATIVE") == 1
+        # the CPU class declaration and everything after the GPU block is byte-identical
+        assert new[new.index(cpu_class):] == old[old.index(cpu_class):]
+        # without the macro the header is the original one: removing the inserted lines restores it
+        restored = new.replace('#ifdef USE_HIP_NATIVE\n// MI355X-native GPU operators (libgsplat_torch.so): same '
+                               'class names, argument order and\n// return order as the declarations in the #else '
+                               'branch\n#include "gsplat_ops.hpp"\n#else\n', "", 1)
+        i = restored.index("#endif", restored.index("#if defined(USE_HIP)"))
+        restored = restored[:i + len("#endif")] + restored[i + len("#endif") + len("\n#endif"):]
+        assert restored == old
+    for name in ("project_gaussians.cpp", "rasterize_gaussians.cpp", "spherical_harmonics.cpp"):
+        new, old = open(tmp_path / name).read(), open(os.path.join(REF, name)).read()
+        assert new.replace(" && !defined(USE_HIP_NATIVE)", "").replace(
+            "#if (defined(USE_HIP) || defined(USE_CUDA) || defined(USE_MPS))",
+            "#if defined(USE_HIP) || defined(USE_CUDA) || defined(USE_MPS)") == old
+    # idempotent
+    r2 = subprocess.run(["python3", os.path.join(ROOT, "integration", "apply_hip_native.py"), str(tmp_path)],
+                        capture_output=True, text=True)
+    assert r2.returncode == 0
+    assert open(tmp_path / "gsplat.hpp").read().count("USE_HIP_NATIVE") == 1
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/model_forward_shim not built "
+                                                     "(python -c 'import __graft_entry__ as g; g.build()')")
+def test_model_forward_shaped_unit_runs_its_cpu_branch():
+    """Both branches were COMPILED in one TU against the patched headers (that is the build); the CPU
+    branch runs here: ProjectGaussiansCPU -> SphericalHarmonicsCPU -> RasterizeGaussiansCPU with
+    libtorch autograd, linked next to libgsplat_torch.so."""
+    r = subprocess.run([SHIM, "--cpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _lines(r.stdout)
+    assert out[0]["device"] == "cpu" and out[0]["finite"] and out[0]["visible"] > 1000
+    assert out[0]["sh_bases_of_16"] == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/model_forward_shim not built")
+def test_model_forward_shaped_unit_runs_both_branches_on_the_gpu_box():
+    r = subprocess.run([SHIM, "--gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    out = _lines(r.stdout)
+    assert [o.get("device") for o in out[:2]] == ["cpu", "gpu"]
+    assert out[1]["finite"] and out[1]["visible"] == out[0]["visible"]
+    assert abs(out[1]["loss"] - out[0]["loss"]) < 0.02 and out[2]["mean_abs_diff_cpu_gpu"] < 0.05
