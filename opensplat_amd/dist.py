@@ -93,6 +93,36 @@ def allreduce_all_async(buf: GradBuffer):
     return dist.all_reduce(buf.flat, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def bucket_bounds(numel: int, n_buckets: int, align: int = 1024) -> list[tuple[int, int]]:
+    """[lo, hi) element ranges that tile a flat buffer of `numel` floats into at most n_buckets
+    pieces with boundaries on multiples of `align` (16-byte aligned slices keep gs_adam_step on its
+    128-bit path)."""
+    n_buckets = max(1, int(n_buckets))
+    per = -(-numel // n_buckets)
+    per = -(-per // align) * align
+    out, lo = [], 0
+    while lo < numel:
+        hi = min(lo + per, numel)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def allreduce_buckets_async(buf: GradBuffer, n_buckets: int = 4):
+    """The flat gradient buffer as a few large collectives instead of one: [(lo, hi, work)] in issue
+    order.  RCCL runs them back to back on its own stream; a consumer that waits for bucket k only
+    (work.wait() makes the CURRENT stream wait for that collective) overlaps its work on bucket k —
+    the Adam step of those parameters — with the transfer of bucket k + 1.  A handful of 30-60 MB
+    messages still runs at the large-message bandwidth of the xGMI ring / direct algorithm."""
+    bounds = bucket_bounds(buf.flat.numel(), n_buckets)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    out = []
+    for lo, hi in bounds:
+        w = dist.all_reduce(buf.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) if multi else None
+        out.append((lo, hi, w))
+    return out
+
+
 def wait_all(*works) -> None:
     for w in works:
         if w is not None:

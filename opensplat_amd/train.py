@@ -72,7 +72,7 @@ class Trainer:
                  stop_screen_size_at: int = 4000, split_screen_size: float = 0.05,
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
-                 reference_alpha_reset: bool = False):
+                 reference_alpha_reset: bool = False, grad_buckets: int = 4):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -109,6 +109,12 @@ class Trainer:
         # opacities stay trainable, their moments are zeroed.  True: the reference's actual
         # behaviour step for step (KNOWN PARITY DEVIATION switch).
         self.reference_alpha_reset = reference_alpha_reset
+        # gradient exchange of a camera batch (one camera per rank): the flat buffer goes out as
+        # `grad_buckets` collectives and the Adam step of a bucket's parameters runs as soon as ITS
+        # collective has finished, while the next bucket is still on the wire
+        self.grad_buckets = max(1, int(grad_buckets))
+        self.bucket_single_rank = False   # tests: take the bucketed path without a process group
+        self._pending = None
         self._opacity_frozen = False
         self._visible = True
         self._stats = None          # (xysGradNorm, visCounts, max2DSize); None = cleared
@@ -196,20 +202,39 @@ class Trainer:
         cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
                                cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws, self.gout, flags,
                                v_xy=self.v_xy)
-        dist.wait_all(dist.allreduce_all_async(self.grads))
+        # start the exchange; optimizer_step() consumes it bucket by bucket
+        self._pending = dist.allreduce_buckets_async(self.grads, self.grad_buckets) \
+            if (self.world > 1 or self.bucket_single_rank) else None
 
-    def adam_groups(self):
+    def adam_groups(self, lo: int = 0, hi: int | None = None):
+        """The six Adam groups (model.cpp:61-66) as slices of the flat buffers, restricted to the
+        element range [lo, hi) of the flat layout (a gradient bucket)."""
         P, G, M, V = self.params, self.grads, self.exp_avg, self.exp_avg_sq
+        hi = P.flat.numel() if hi is None else hi
         lr = dict(self.LR, means=self.means_lr)
-        names = [("v_means", "means"), ("v_scales", "scales"), ("v_quats", "quats"),
-                 ("v_dc", "features_dc"), ("v_rest", "features_rest"), ("v_opacity", "opacities")]
-        return [(P.views[v], G.views[v], M.views[v], V.views[v], lr[n]) for v, n in names
-                if P.views[v].numel() > 0 and not (n == "opacities" and self._opacity_frozen)]
+        names = [("v_rest", "features_rest"), ("v_dc", "features_dc"), ("v_means", "means"),
+                 ("v_scales", "scales"), ("v_quats", "quats"), ("v_opacity", "opacities")]   # flat order
+        out, o = [], 0
+        for v, n in names:
+            cnt = P.views[v].numel()
+            a, b = max(lo, o), min(hi, o + cnt)
+            if a < b and not (n == "opacities" and self._opacity_frozen):
+                out.append((P.flat[a:b], G.flat[a:b], M.flat[a:b], V.flat[a:b], lr[n]))
+            o += cnt
+        return out
 
     def optimizer_step(self):
         """Model::optimizersStep + schedulersStep (model.cpp:236-247)."""
         self.step_count += 1
-        cabi.adam_step(self.adam_groups(), self.step_count)
+        if self._pending is None:
+            cabi.adam_step(self.adam_groups(), self.step_count)
+        else:
+            for lo, hi, work in self._pending:      # Adam of bucket k overlaps the transfer of k + 1
+                dist.wait_all(work)
+                groups = self.adam_groups(lo, hi)
+                if groups:
+                    cabi.adam_step(groups, self.step_count)
+            self._pending = None
         # OptimScheduler::step(step) sets the lr the NEXT optimiser step uses (opensplat.cpp:168-169)
         self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps,
                                       self.step_count)

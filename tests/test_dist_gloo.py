@@ -118,3 +118,13 @@ def test_bench_refuses_a_world_that_does_not_match():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "rank" in (r.stderr + r.stdout)
+
+
+def test_bucket_bounds_tile_the_buffer():
+    from opensplat_amd.dist import bucket_bounds
+
+    for numel, nb in ((59_000_000, 4), (1000, 4), (1025, 3), (5, 8), (4096, 1)):
+        b = bucket_bounds(numel, nb)
+        assert b[0][0] == 0 and b[-1][1] == numel and len(b) <= nb
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(lo < hi for lo, hi in b)
+        assert all(lo % 1024 == 0 for lo, _ in b)

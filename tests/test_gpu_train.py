@@ -331,3 +331,32 @@ def test_adam_step_operator_against_torch_optim():
         # torch's GPU kernels round a few operations differently (no fused multiply-adds where
         # ATen's CPU kernels have them): a couple of ulps of max(|p|, update)
         assert np.all(np.abs(a - b) <= 4 * np.spacing(np.maximum(np.abs(b), np.float32(4 * lr))))
+
+
+def test_bucketed_adam_equals_the_single_launch():
+    """The multi-rank exchange hands the Adam step one gradient bucket at a time (so that it overlaps
+    the next bucket's all-reduce); bucket boundaries cut through the six parameter groups.  On the
+    same gradients the update must be the same bits as the one-launch step."""
+    import torch
+
+    from opensplat_amd import dist as gdist
+    from opensplat_amd.train import Trainer
+
+    s = scenes.camera_scene(5003, 160, 96, K=16, seed=81, znear=1.0, zfar=100.0)
+    raw = scenes.raw_parameters(s)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    results = []
+    for buckets in (None, 5, 64):
+        T = Trainer(*raw, device=torch.device("cuda", 0), grad_buckets=buckets or 1)
+        gen.manual_seed(5)
+        for it in range(3):
+            T.grads.flat.copy_(torch.randn(T.grads.flat.numel(), device="cuda", generator=gen) * 1e-3)
+            T._pending = gdist.allreduce_buckets_async(T.grads, T.grad_buckets) if buckets else None
+            T.optimizer_step()
+        torch.cuda.synchronize()
+        results.append((T.params.flat.clone(), T.exp_avg.flat.clone(), T.exp_avg_sq.flat.clone(), T.means_lr))
+    for other in results[1:]:
+        for a, b in zip(results[0][:3], other[:3]):
+            assert torch.equal(a, b)
+        assert other[3] == results[0][3]
+    assert len(gdist.bucket_bounds(T.grads.flat.numel(), 5)) == 5
