@@ -19,6 +19,12 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+GATHER_FACTOR = 1.18            # profiles/calib_r02.json: counter_to_moved_factor of the 48-B gather
+GATHER_KERNELS = ("k_rasterize_forward", "k_rasterize_backward")
+
+
+def read_factor(kernel_name: str) -> float:
+    return GATHER_FACTOR if any(g in kernel_name for g in GATHER_KERNELS) else 2.0
 
 
 def short(name: str) -> str:
@@ -70,7 +76,9 @@ def main():
         d = {c: sum(v) / len(v) for c, v in ctrs.items()}
         d["launches_sampled"] = max(len(v) for v in ctrs.values())
         if "FETCH_SIZE" in d:
-            d["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 1024 * 2
+            d["hbm_read_factor"] = read_factor(k)
+            d["hbm_read_bytes_corrected"] = d["FETCH_SIZE"] * 1024 * read_factor(k)
+            d["hbm_read_bytes_x2_upper_bound"] = d["FETCH_SIZE"] * 1024 * 2
         if "WRITE_SIZE" in d:
             d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
         out[k[:200]] = d
@@ -83,7 +91,7 @@ def main():
     lines = [f"# rocprofv3 summary, tag {tag}", "",
              "Source: `scripts/profile.sh` on one MI355X (gpurun), summarised by "
              "`scripts/summarize_profile.py`.", "",
-             "| kernel | calls | avg µs | % | HBM read MB (FETCH_SIZE×2) | HBM write MB | VALU insts/wave-avg | "
+             "| kernel | calls | avg µs | % | HBM read MB (FETCH_SIZE × 2, × 1.18 for the gather kernels) | HBM write MB | VALU insts/wave-avg | "
              "VALU busy (ACTIVE_INST_VALU/BUSY_CYCLES) | LDS insts | wait_any/wave_cycles |",
              "|---|---|---|---|---|---|---|---|---|---|"]
     pct = {r["Name"]: r["Percentage"] for r in stats}
@@ -113,7 +121,8 @@ def main():
         m = re.search(r"gs::(k_\w+)", name)
         if m and "hbm_read_bytes_corrected" in d and "hbm_write_bytes" in d:
             traffic[m.group(1)] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
-    traffic["_source"] = f"profiles/{tag}_pmc.json (FETCH_SIZE x 2 KiB-units corrected + WRITE_SIZE)"
+    traffic["_source"] = (f"profiles/{tag}_pmc.json (FETCH_SIZE KiB x 2 for streaming kernels, x {GATHER_FACTOR} for "
+                          "k_rasterize_* per profiles/calib_r02.json, + WRITE_SIZE)")
     # the row-f2 kernels (scripts/profile_f2.sh, tags f2*) keep their own file
     # ... and so do profiles of the non-default configurations (tags like r01i_c3)
     tname = "traffic_f2.json" if tag.startswith("f2") else \
