@@ -615,8 +615,9 @@ def main():
                          "note": "HIP events around the kernel launch itself; the compositing kernels "
                                  "are VALU-issue-bound, not HBM-bound (no dense contraction, no MFMA; "
                                  "SURVEY.md §8d, DESIGN.md §4) — the HBM fraction is reported as "
-                                 "required; traffic = rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch "
-                                 "from profiles/"},
+                                 "required; traffic = rocprofv3 FETCH_SIZE x 1.18 (factor calibrated on "
+                                 "48-byte record gathers, profiles/calib_r02.json) + WRITE_SIZE per "
+                                 "launch from profiles/"},
             "kernel_ms": kernel_ms,
             # pixel x Gaussian evaluations per second of the compositing kernels, counted
             # as 256 pixels per (tile, Gaussian) list entry (the upper bound both kernels are sized by)

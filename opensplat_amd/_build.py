@@ -58,7 +58,8 @@ def build_torch(force: bool = False) -> str:
     src = os.path.join(CSRC, "torch_ops.cpp")
     launcher = os.path.join(CSRC, "bindings_hip_native.cpp")   # the eight *_tensor launchers
     deps = [src, launcher, os.path.join(CSRC, "bindings_hip_native.h"), os.path.join(CSRC, "gsplat_ops.hpp"),
-            os.path.join(INCLUDE, "gsplat_hip.h"), os.path.join(INCLUDE, "gsplat_compat.h"), HIP_LIB]
+            os.path.join(INCLUDE, "gsplat_hip.h"), os.path.join(INCLUDE, "gsplat_compat.h"),
+            os.path.join(INCLUDE, "gsplat_dist.h"), HIP_LIB, DIST_LIB]
     if force or _stale(TORCH_LIB, deps):
         _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w",
               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
@@ -67,10 +68,29 @@ def build_torch(force: bool = False) -> str:
               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
               "-I/opt/rocm/include",
               "torch_ops.cpp", "bindings_hip_native.cpp", "-o", TORCH_LIB,
-              "-L" + CSRC, "-lgsplat_hip",
+              "-L" + CSRC, "-lgsplat_hip", "-lgsplat_dist",
               "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
               "-lc10_hip", "-Wl,-rpath,$ORIGIN"])
     return TORCH_LIB
+
+
+DIST_LIB = os.path.join(CSRC, "libgsplat_dist.so")
+
+
+def build_dist(force: bool = False) -> str:
+    """csrc/libgsplat_dist.so: the gradient exchange on RCCL behind include/gsplat_dist.h (g++;
+    links the RCCL libtorch-ROCm ships, so that a process never holds two RCCLs)."""
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    src = os.path.join(CSRC, "gs_dist.cpp")
+    deps = [src, os.path.join(INCLUDE, "gsplat_dist.h"), os.path.join(INCLUDE, "gsplat_hip.h")]
+    if force or _stale(DIST_LIB, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1",
+              "-I/opt/rocm/include", "gs_dist.cpp", "-o", DIST_LIB,
+              "-L" + os.path.join(tdir, "lib"), "-lrccl", "-L/opt/rocm/lib", "-lamdhip64",
+              "-Wl,-rpath," + os.path.join(tdir, "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    return DIST_LIB
 
 
 EXAMPLE_SRC = os.path.join(ROOT, "examples", "simple_trainer_hip.cpp")
@@ -91,7 +111,7 @@ def build_example(force: bool = False) -> str:
               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
               EXAMPLE_SRC, "-o", EXAMPLE_BIN,
               "-Wl,--no-as-needed",   # keep the torch libraries as direct dependencies of the program
-              "-L" + CSRC, "-lgsplat_torch", "-lgsplat_hip",
+              "-L" + CSRC, "-lgsplat_torch", "-lgsplat_hip", "-lgsplat_dist",
               "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
               "-lc10_hip", "-Wl,--disable-new-dtags",   # RPATH, so that it also serves libgsplat_torch.so's deps
               "-Wl,-rpath," + CSRC, "-Wl,-rpath," + os.path.join(tdir, "lib")])
@@ -100,6 +120,7 @@ def build_example(force: bool = False) -> str:
 
 def build_all(force: bool = False) -> None:
     build_hip(force)
+    build_dist(force)
     build_torch(force)
     build_example(force)
 

@@ -78,6 +78,27 @@ def lib() -> C.CDLL:
     return _lib
 
 
+# every symbol include/gsplat_dist.h declares (libgsplat_dist.so: the gradient exchange on RCCL)
+DIST_SYMBOLS = ["gs_dist_unique_id", "gs_dist_init", "gs_dist_allreduce_sum", "gs_dist_allreduce_sum_buckets",
+                "gs_dist_world_size", "gs_dist_rank", "gs_dist_destroy", "gs_dist_last_error"]
+_dist_lib = None
+
+
+def dist_lib() -> C.CDLL:
+    """libgsplat_dist.so (loaded after torch: the process then holds torch's RCCL only)."""
+    global _dist_lib
+    if _dist_lib is None:
+        if not os.path.exists(_build.DIST_LIB):
+            raise ImportError("libgsplat_dist.so is not built: run `python -m opensplat_amd._build`")
+        l = C.CDLL(_build.DIST_LIB)
+        l.gs_dist_last_error.restype = C.c_char_p
+        l.gs_dist_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.gs_dist_allreduce_sum_buckets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                                    C.c_void_p]
+        _dist_lib = l
+    return _dist_lib
+
+
 class GsError(RuntimeError):
     pass
 

@@ -15,7 +15,9 @@
 
 #include <torch/torch.h>
 
+#include <cstdint>
 #include <tuple>
+#include <vector>
 
 typedef std::tuple<int, int, int> TileBounds;
 
@@ -162,6 +164,29 @@ DensifyResult densify(const std::vector<torch::Tensor> &params, const std::vecto
 void resetOpacity(torch::Tensor &opacities, float resetValue,
                   c10::optional<torch::Tensor> expAvg = c10::nullopt,
                   c10::optional<torch::Tensor> expAvgSq = c10::nullopt);
+
+// SURVEY.md §8e — the one exchange step of the camera-per-rank path for a C++ caller: a sum
+// all-reduce of the flat gradient buffer (RCCL over xGMI, include/gsplat_dist.h) enqueued on the
+// current torch HIP stream, i.e. right behind the backward kernels that filled the buffer.
+// Bootstrap like ncclUniqueId: rank 0 calls uniqueId() and ships the bytes to the other ranks.
+class GradExchange {
+public:
+    static std::vector<uint8_t> uniqueId();
+    GradExchange(int worldSize, int rank, const std::vector<uint8_t> &id, int device);
+    ~GradExchange();
+    GradExchange(const GradExchange &) = delete;
+    GradExchange &operator=(const GradExchange &) = delete;
+    // in place; flat: contiguous float32 GPU tensor (e.g. the gradients of the six parameter
+    // tensors viewed as slices of one buffer, or each tensor in turn)
+    void allReduce(torch::Tensor flat);
+    // as nBuckets collectives; returns nothing to wait for: consumers are ordered by the stream
+    void allReduceBuckets(torch::Tensor flat, int nBuckets);
+    int worldSize() const;
+    int rank() const;
+
+private:
+    void *comm_ = nullptr;
+};
 
 // Process-wide switch for the compositing kernels' exponential: false (default) = glibc-bit-exact
 // expf (contributor sets identical to gsplat-cpu); true = hardware v_exp_f32 (GS_FLAG_FAST_EXP).

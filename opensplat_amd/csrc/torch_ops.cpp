@@ -21,6 +21,7 @@
 #include "../../include/gsplat_hip.h"
 #include "../../include/gsplat_train.h"
 #include "../../include/gsplat_densify.h"
+#include "../../include/gsplat_dist.h"
 
 using torch::Tensor;
 using torch::autograd::AutogradContext;
@@ -795,7 +796,51 @@ void op_adam_step(std::vector<Tensor> params, std::vector<Tensor> grads, std::ve
 
 }  // namespace
 
+// ---- GradExchange (include/gsplat_dist.h) --------------------------------------------------------
+static void check_dist(int rc, const char *what) {
+    TORCH_CHECK(rc == GS_OK, what, " failed: ", gs_strerror(rc), " — ", gs_dist_last_error());
+}
+std::vector<uint8_t> GradExchange::uniqueId() {
+    std::vector<uint8_t> id(GS_DIST_ID_BYTES);
+    check_dist(gs_dist_unique_id(id.data()), "gs_dist_unique_id");
+    return id;
+}
+GradExchange::GradExchange(int worldSize, int rank, const std::vector<uint8_t> &id, int device) {
+    TORCH_CHECK(id.size() == GS_DIST_ID_BYTES, "GradExchange: id must hold ", GS_DIST_ID_BYTES, " bytes");
+    GsDistComm *c = nullptr;
+    check_dist(gs_dist_init(&c, worldSize, rank, id.data(), device), "gs_dist_init");
+    comm_ = c;
+}
+GradExchange::~GradExchange() { (void)gs_dist_destroy(static_cast<GsDistComm *>(comm_)); }
+int GradExchange::worldSize() const { return gs_dist_world_size(static_cast<const GsDistComm *>(comm_)); }
+int GradExchange::rank() const { return gs_dist_rank(static_cast<const GsDistComm *>(comm_)); }
+void GradExchange::allReduce(Tensor flat) {
+    GS_CHECK_DEV(flat);
+    GS_CHECK_F32(flat);
+    TORCH_CHECK(flat.is_contiguous(), "GradExchange: contiguous buffer required");
+    c10::DeviceGuard guard(flat.device());
+    check_dist(gs_dist_allreduce_sum(static_cast<GsDistComm *>(comm_), flat.data_ptr<float>(),
+                                     (size_t)flat.numel(), current_stream()), "gs_dist_allreduce_sum");
+}
+void GradExchange::allReduceBuckets(Tensor flat, int nBuckets) {
+    GS_CHECK_DEV(flat);
+    GS_CHECK_F32(flat);
+    TORCH_CHECK(flat.is_contiguous(), "GradExchange: contiguous buffer required");
+    c10::DeviceGuard guard(flat.device());
+    check_dist(gs_dist_allreduce_sum_buckets(static_cast<GsDistComm *>(comm_), flat.data_ptr<float>(),
+                                             (size_t)flat.numel(), nBuckets, nullptr, current_stream()),
+               "gs_dist_allreduce_sum_buckets");
+}
+// self-test op: a one-rank communicator through the whole C++ / C-ABI / RCCL stack
+static Tensor op_grad_exchange_selftest(Tensor flat, int64_t buckets) {
+    GradExchange ex(1, 0, GradExchange::uniqueId(), flat.device().index());
+    if (buckets > 1) ex.allReduceBuckets(flat, (int)buckets); else ex.allReduce(flat);
+    TORCH_CHECK(ex.worldSize() == 1 && ex.rank() == 0);
+    return flat;
+}
+
 TORCH_LIBRARY(opensplat_amd, m) {
+    m.def("grad_exchange_selftest(Tensor(a!) flat, int buckets) -> Tensor(a!)", &op_grad_exchange_selftest);
     m.def("project_gaussians(Tensor means, Tensor scales, float glob_scale, Tensor quats, "
           "Tensor viewmat, Tensor projmat, float fx, float fy, float cx, float cy, int img_height, "
           "int img_width, float clip_thresh=0.01) -> Tensor[]",

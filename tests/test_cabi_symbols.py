@@ -147,3 +147,24 @@ def test_launcher_level_functions_are_registered():
                  "launcher_map_gaussian_to_intersects", "launcher_get_tile_bin_edges",
                  "launcher_rasterize_forward", "launcher_rasterize_backward"]:
         assert hasattr(torch.ops.opensplat_amd, name), name
+
+
+def test_dist_library_exports_its_header():
+    """include/gsplat_dist.h (the gradient exchange on RCCL) <-> libgsplat_dist.so; argument checks
+    that need no device."""
+    import torch  # noqa: F401  (loads torch's RCCL first)
+
+    text = open(os.path.join(ROOT, "include", "gsplat_dist.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gs_dist_[a-z0-9_]+)\s*\(", text)))
+    assert sorted(cabi.DIST_SYMBOLS) == names
+    l = cabi.dist_lib()
+    assert not [n for n in names if not hasattr(l, n)]
+    null = ctypes.c_void_p(0)
+    assert l.gs_dist_unique_id(null) == -1
+    comm = ctypes.c_void_p(0)
+    ident = (ctypes.c_uint8 * 128)()
+    assert l.gs_dist_init(ctypes.byref(comm), 0, 0, ident, 0) == -1       # world < 1
+    assert l.gs_dist_init(ctypes.byref(comm), 2, 2, ident, 0) == -1       # rank out of range
+    assert l.gs_dist_allreduce_sum(null, null, 0, null) == -1
+    assert l.gs_dist_world_size(null) == 0 and l.gs_dist_rank(null) == -1 and l.gs_dist_destroy(null) == 0
