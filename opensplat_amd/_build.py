@@ -93,6 +93,17 @@ def build_dist(force: bool = False) -> str:
     return DIST_LIB
 
 
+IMAGE_LIB = os.path.join(CSRC, "libgsplat_image.so")
+
+
+def build_image(force: bool = False) -> str:
+    """csrc/libgsplat_image.so: the baseline JPEG decoder of include/gsplat_image.h (plain host C)."""
+    src = os.path.join(CSRC, "gs_image.c")
+    if force or _stale(IMAGE_LIB, [src, os.path.join(INCLUDE, "gsplat_image.h")]):
+        _run(["gcc", "-std=c11", "-O2", "-fPIC", "-shared", "-Wall", "gs_image.c", "-o", IMAGE_LIB])
+    return IMAGE_LIB
+
+
 EXAMPLE_SRC = os.path.join(ROOT, "examples", "simple_trainer_hip.cpp")
 EXAMPLE_BIN = os.path.join(ROOT, "examples", "simple_trainer_hip")
 
@@ -120,6 +131,7 @@ def build_example(force: bool = False) -> str:
 
 def build_all(force: bool = False) -> None:
     build_hip(force)
+    build_image(force)
     build_dist(force)
     build_torch(force)
     build_example(force)

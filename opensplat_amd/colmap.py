@@ -322,13 +322,55 @@ def _decode_png(blob: bytes) -> np.ndarray:
     return out.reshape(h, w, bpp)[:, :, :3]
 
 
+_image_lib = None
+
+
+def image_lib():
+    """libgsplat_image.so (include/gsplat_image.h): the baseline JPEG decoder, plain host C."""
+    global _image_lib
+    if _image_lib is None:
+        import ctypes as C
+
+        from . import _build
+
+        if not os.path.exists(_build.IMAGE_LIB):
+            raise ImportError("libgsplat_image.so is not built: run `python -m opensplat_amd._build`")
+        l = C.CDLL(_build.IMAGE_LIB)
+        l.gs_image_strerror.restype = C.c_char_p
+        l.gs_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]
+        l.gs_jpeg_decode_rgb.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _image_lib = l
+    return _image_lib
+
+
+def decode_jpeg(blob: bytes) -> np.ndarray:
+    """[H, W, 3] uint8 RGB of a baseline JPEG: the pixels libjpeg (hence cv::imread, cv_utils.cpp:3-14)
+    produces, bit for bit (tests/test_image.py)."""
+    import ctypes as C
+
+    l = image_lib()
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    rc = l.gs_jpeg_info(blob, len(blob), C.byref(w), C.byref(h), C.byref(c))
+    if rc != 0:
+        raise ValueError("JPEG: " + l.gs_image_strerror(rc).decode())
+    out = np.empty((h.value, w.value, 3), np.uint8)
+    rc = l.gs_jpeg_decode_rgb(blob, len(blob), out.ctypes.data_as(C.c_void_p), out.size)
+    if rc != 0:
+        raise ValueError("JPEG: " + l.gs_image_strerror(rc).decode())
+    return out
+
+
 def read_image_u8(path: str) -> np.ndarray:
-    """[H, W, 3] uint8 RGB from .npy (uint8 or float in [0, 1]), binary PPM (P6) or PNG."""
+    """[H, W, 3] uint8 RGB from baseline JPEG, PNG, binary PPM (P6) or .npy (uint8 or float in
+    [0, 1]) — imreadRGB (cv_utils.cpp:3-14) without OpenCV."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
         a = np.load(path)
         return a if a.dtype == np.uint8 else np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
     blob = open(path, "rb").read()
+    if ext in (".jpg", ".jpeg", ".jpe") or blob[:2] == b"\xff\xd8":
+        return decode_jpeg(blob)
     if ext == ".png":
         return _decode_png(blob)
     if ext in (".ppm", ".pnm") and blob[:2] == b"P6":
@@ -354,26 +396,197 @@ def downscale_area(img_u8: np.ndarray, factor: int) -> np.ndarray:
     """Integer-factor box average (what cv::INTER_AREA computes for integer factors), uint8 out."""
     if factor <= 1:
         return img_u8
-    h, w = (img_u8.shape[0] // factor) * factor, (img_u8.shape[1] // factor) * factor
-    a = img_u8[:h, :w].astype(np.uint32).reshape(h // factor, factor, w // factor, factor, 3).sum((1, 3))
-    area = factor * factor
-    return ((a + area // 2) // area).astype(np.uint8)
+    return resize_area(img_u8, int(round(img_u8.shape[1] / factor)), int(round(img_u8.shape[0] / factor)),
+                       scale=float(factor))
+
+
+def _area_table(ssize: int, dsize: int, scale: float):
+    """1-D INTER_AREA decomposition: for every destination index the source indices it covers and
+    their weights (cell [d * scale, (d + 1) * scale), partial pixels weighted by their overlap)."""
+    idx, wts = [], []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = min(f1 + scale, float(ssize))
+        cell = min(scale, ssize - f1)
+        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+        s2 = min(s2, ssize - 1) if s2 >= ssize else s2
+        s1 = min(s1, s2)
+        ii, ww = [], []
+        if s1 - f1 > 1e-3:
+            ii.append(s1 - 1); ww.append((s1 - f1) / cell)
+        for sx in range(s1, s2):
+            ii.append(sx); ww.append(1.0 / cell)
+        if f2 - s2 > 1e-3 and s2 < ssize:
+            ii.append(s2); ww.append(min(min(f2 - s2, 1.0), cell) / cell)
+        idx.append(ii); wts.append(ww)
+    return idx, wts
+
+
+def resize_area(img_u8: np.ndarray, dst_w: int, dst_h: int, scale: float | None = None) -> np.ndarray:
+    """cv::resize(..., INTER_AREA) for down-scaling ([H, W, C] uint8).  scale = source pixels per
+    destination pixel (both axes); default src / dst per axis, as cv::resize derives it from dsize.
+
+    Integer scales: the mean of the scale x scale box — (sum + 2) >> 2 for 2 x 2 boxes, round-to-nearest-
+    even of sum / area otherwise (the two code paths of OpenCV's ResizeAreaFast for 8-bit images);
+    other scales: area-weighted mean in float32.  PARITY UNPINNED: written from OpenCV's documented
+    behaviour, no OpenCV in this environment to generate fixtures from."""
+    sh, sw = img_u8.shape[:2]
+    sx = scale if scale is not None else sw / float(dst_w)
+    sy = scale if scale is not None else sh / float(dst_h)
+    ix, iy = int(round(sx)), int(round(sy))
+    src = img_u8.astype(np.float32)
+    if abs(sx - ix) < 1e-9 and abs(sy - iy) < 1e-9 and ix >= 1 and iy >= 1:
+        fw, fh = min(dst_w, sw // ix), min(dst_h, sh // iy)
+        out = np.zeros((dst_h, dst_w, img_u8.shape[2]), np.uint8)
+        box = img_u8[:fh * iy, :fw * ix].astype(np.uint32).reshape(fh, iy, fw, ix, -1).sum((1, 3))
+        if ix == 2 and iy == 2:
+            out[:fh, :fw] = ((box + 2) >> 2).astype(np.uint8)
+        else:
+            out[:fh, :fw] = np.rint(box.astype(np.float32) * np.float32(1.0 / (ix * iy))).astype(np.uint8)
+        # a last partial row / column (source size not a multiple of the factor): mean of what is left
+        for dy in range(dst_h):
+            for dx in range(dst_w):
+                if dy < fh and dx < fw:
+                    continue
+                blk = src[dy * iy:min((dy + 1) * iy, sh), dx * ix:min((dx + 1) * ix, sw)]
+                if blk.size:
+                    out[dy, dx] = np.rint(blk.reshape(-1, blk.shape[-1]).sum(0) / np.float32(blk.shape[0] * blk.shape[1]))
+        return out
+    xi, xw = _area_table(sw, dst_w, sx)
+    yi, yw = _area_table(sh, dst_h, sy)
+    rows = np.zeros((sh, dst_w, img_u8.shape[2]), np.float32)
+    for d in range(dst_w):
+        for i, w in zip(xi[d], xw[d]):
+            rows[:, d] += src[:, i] * np.float32(w)
+    out = np.zeros((dst_h, dst_w, img_u8.shape[2]), np.float32)
+    for d in range(dst_h):
+        for i, w in zip(yi[d], yw[d]):
+            out[d] += rows[i] * np.float32(w)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+# ---- lens undistortion (cv::getOptimalNewCameraMatrix + cv::undistort, input_data.cpp:66-80) ----------
+def _distort(x, y, dist):
+    """Brown-Conrady model OpenCV uses: normalised pinhole (x, y) -> distorted normalised coordinates.
+    dist = (k1, k2, p1, p2, k3)."""
+    k1, k2, p1, p2, k3 = dist
+    r2 = x * x + y * y
+    kr = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+    yd = y * kr + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    return xd, yd
+
+
+def undistort_points(u, v, K, dist, newK=None, iters: int = 5):
+    """cv::undistortPoints: distorted pixel coordinates -> ideal pixel coordinates of camera newK
+    (normalised coordinates when newK is None); fixed-point iteration, 5 rounds like OpenCV."""
+    k1, k2, p1, p2, k3 = dist
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    x0 = (np.asarray(u, np.float64) - cx) / fx
+    y0 = (np.asarray(v, np.float64) - cy) / fy
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+        dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+        x = (x0 - dx) * icdist
+        y = (y0 - dy) * icdist
+    if newK is None:
+        return x, y
+    return x * newK[0, 0] + newK[0, 2], y * newK[1, 1] + newK[1, 2]
+
+
+def _inner_outer_rect(K, dist, newK, W, H, n: int = 9):
+    """icvGetRectangles: the 9 x 9 grid of image points undistorted; inner = largest rectangle inside
+    the undistorted border, outer = its bounding box.  (x, y, w, h) each."""
+    gx, gy = np.meshgrid(np.arange(n) * (W / (n - 1.0)), np.arange(n) * (H / (n - 1.0)))
+    px, py = undistort_points(gx, gy, K, dist, newK)
+    ix0, ix1 = px[:, 0].max(), px[:, -1].min()
+    iy0, iy1 = py[0, :].max(), py[-1, :].min()
+    ox0, ox1, oy0, oy1 = px.min(), px.max(), py.min(), py.max()
+    return (ix0, iy0, ix1 - ix0, iy1 - iy0), (ox0, oy0, ox1 - ox0, oy1 - oy0)
+
+
+def optimal_new_camera_matrix(K, dist, W: int, H: int, alpha: float = 0.0):
+    """cv::getOptimalNewCameraMatrix(K, dist, (W, H), alpha, (W, H), &roi): the camera matrix whose
+    image shows (alpha = 0) only valid pixels of the undistorted image, and the valid-pixel ROI
+    (x, y, w, h).  PARITY UNPINNED (see resize_area)."""
+    K = np.asarray(K, np.float64)
+    inner, outer = _inner_outer_rect(K, dist, None, W, H)
+    fx0, fy0 = (W - 1) / inner[2], (H - 1) / inner[3]
+    cx0, cy0 = -fx0 * inner[0], -fy0 * inner[1]
+    fx1, fy1 = (W - 1) / outer[2], (H - 1) / outer[3]
+    cx1, cy1 = -fx1 * outer[0], -fy1 * outer[1]
+    newK = np.eye(3)
+    newK[0, 0] = fx0 * (1 - alpha) + fx1 * alpha
+    newK[1, 1] = fy0 * (1 - alpha) + fy1 * alpha
+    newK[0, 2] = cx0 * (1 - alpha) + cx1 * alpha
+    newK[1, 2] = cy0 * (1 - alpha) + cy1 * alpha
+    inner2, _ = _inner_outer_rect(K, dist, newK, W, H)
+    x, y = int(np.ceil(inner2[0])), int(np.ceil(inner2[1]))
+    w, h = int(np.floor(inner2[2])), int(np.floor(inner2[3]))
+    x0, y0 = max(x, 0), max(y, 0)
+    x1, y1 = min(x + w, W), min(y + h, H)
+    roi = (x0, y0, max(x1 - x0, 0), max(y1 - y0, 0))
+    return newK.astype(np.float32), roi
+
+
+def undistort_image(img_u8: np.ndarray, K, dist, newK) -> np.ndarray:
+    """cv::undistort(src, dst, K, dist, newK): for every pixel of the ideal camera newK the source
+    position under the distortion model, sampled bilinearly with the source coordinates quantised
+    to 1/32 pixel (OpenCV's fixed-point remap) and a zero border.  PARITY UNPINNED."""
+    H, W = img_u8.shape[:2]
+    K = np.asarray(K, np.float64)
+    newK = np.asarray(newK, np.float64)
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    x = (uu - newK[0, 2]) / newK[0, 0]
+    y = (vv - newK[1, 2]) / newK[1, 1]
+    xd, yd = _distort(x, y, dist)
+    su = K[0, 0] * xd + K[0, 2]
+    sv = K[1, 1] * yd + K[1, 2]
+    iu = np.rint(np.clip(su, -4.0, W + 4.0) * 32.0).astype(np.int64)     # INTER_TAB_SIZE = 32
+    iv = np.rint(np.clip(sv, -4.0, H + 4.0) * 32.0).astype(np.int64)
+    x0, y0, fxq, fyq = iu >> 5, iv >> 5, iu & 31, iv & 31
+    src = np.zeros((H + 2, W + 2, img_u8.shape[2]), np.int64)            # zero border
+    src[1:-1, 1:-1] = img_u8
+
+    def tap(yy, xx):
+        ok = (yy >= -1) & (yy <= H) & (xx >= -1) & (xx <= W)
+        return src[np.clip(yy + 1, 0, H + 1), np.clip(xx + 1, 0, W + 1)] * ok[..., None]
+    w00 = ((32 - fxq) * (32 - fyq))[..., None]
+    w01 = (fxq * (32 - fyq))[..., None]
+    w10 = ((32 - fxq) * fyq)[..., None]
+    w11 = (fxq * fyq)[..., None]
+    acc = tap(y0, x0) * w00 + tap(y0, x0 + 1) * w01 + tap(y0 + 1, x0) * w10 + tap(y0 + 1, x0 + 1) * w11
+    return ((acc + 512) >> 10).astype(np.uint8)
 
 
 def load_image(cam: Camera, downscale: float = 1.0, ignore_distortion: bool = False) -> None:
-    """Camera::loadImage (input_data.cpp:40-105) minus the lens undistortion: fills cam.image
-    ([H, W, 3] float32 / 255) and rescales the intrinsics to the loaded image."""
-    if cam.has_distortion() and not ignore_distortion:
-        raise NotImplementedError("lens undistortion needs OpenCV (cv::undistort, input_data.cpp:66-80)")
+    """Camera::loadImage (input_data.cpp:40-105): reads the file, rescales the intrinsics to the image
+    actually found, down-scales (INTER_AREA), undistorts when the camera has distortion parameters
+    (optimal new camera matrix at alpha = 0, crop to the valid ROI) and fills cam.image
+    ([H, W, 3] float32 / 255) and the final intrinsics."""
     img = read_image_u8(cam.file_path)
-    rescale = 1.0
+    f32 = np.float32
+    rescale = f32(1.0)
     if img.shape[0] != cam.height or img.shape[1] != cam.width:
-        rescale = float(img.shape[0]) / float(cam.height)
-    f = int(downscale)
-    if f > 1:
-        img = downscale_area(img, f)
-        rescale *= 1.0 / f
-    for k in ("fx", "fy", "cx", "cy"):
-        setattr(cam, k, float(np.float32(getattr(cam, k)) * np.float32(rescale)))
+        rescale = f32(img.shape[0]) / f32(cam.height)
+    fx, fy, cx, cy = (f32(getattr(cam, k)) * rescale for k in ("fx", "fy", "cx", "cy"))
+    if downscale > 1.0:
+        sf = f32(1.0) / f32(downscale)
+        dw, dh = int(np.rint(img.shape[1] * float(sf))), int(np.rint(img.shape[0] * float(sf)))
+        img = resize_area(img, dw, dh, scale=float(downscale))
+        fx, fy, cx, cy = fx * sf, fy * sf, cx * sf, cy * sf
+    if cam.has_distortion() and not ignore_distortion:
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+        dist = (cam.k1, cam.k2, cam.p1, cam.p2, cam.k3)
+        newK, roi = optimal_new_camera_matrix(K, dist, img.shape[1], img.shape[0])
+        img = undistort_image(img, K, dist, newK)
+        x, y, w, h = roi
+        img = img[y:y + h, x:x + w]
+        fx, fy, cx, cy = newK[0, 0], newK[1, 1], newK[0, 2], newK[1, 2]
+        cam.k1 = cam.k2 = cam.k3 = cam.p1 = cam.p2 = 0.0     # the loaded image is an ideal pinhole view
+    cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
     cam.height, cam.width = int(img.shape[0]), int(img.shape[1])
     cam.image = (img.astype(np.float32) / np.float32(255.0))

@@ -168,3 +168,15 @@ def test_dist_library_exports_its_header():
     assert l.gs_dist_init(ctypes.byref(comm), 2, 2, ident, 0) == -1       # rank out of range
     assert l.gs_dist_allreduce_sum(null, null, 0, null) == -1
     assert l.gs_dist_world_size(null) == 0 and l.gs_dist_rank(null) == -1 and l.gs_dist_destroy(null) == 0
+
+
+def test_image_library_exports_its_header():
+    from opensplat_amd import colmap
+
+    text = open(os.path.join(ROOT, "include", "gsplat_image.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["gs_image_strerror", "gs_jpeg_decode_rgb", "gs_jpeg_info"]
+    l = colmap.image_lib()
+    assert not [n for n in names if not hasattr(l, n)]
+    assert l.gs_image_strerror(0) == b"ok" and b"unsupported" in l.gs_image_strerror(-2)

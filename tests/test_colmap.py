@@ -165,8 +165,9 @@ def test_image_loading_without_opencv(tmp_path):
     assert np.array_equal(np.rint(cam.image * 255).astype(np.uint32), (box + 2) // 4)
     dist = colmap.Camera(id=1, width=64, height=48, fx=70, fy=70, cx=32, cy=24, k1=0.1,
                          file_path=str(tmp_path / "a.npy"))
-    with pytest.raises(NotImplementedError):
-        colmap.load_image(dist)
+    colmap.load_image(dist)        # undistorted and cropped to the valid ROI (tests/test_image.py)
+    assert not dist.has_distortion() and dist.image.shape == (dist.height, dist.width, 3)
+    assert 40 <= dist.width <= 64 and 30 <= dist.height <= 48
     with pytest.raises(ValueError):
         open(tmp_path / "x.jpg", "wb").write(b"\xff\xd8")
         colmap.read_image_u8(str(tmp_path / "x.jpg"))
