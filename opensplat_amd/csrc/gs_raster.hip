@@ -391,13 +391,16 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
         __syncthreads();
         uint32_t touch = 0u;
+        bool binds_t = false;   // this lane's entry needs the per-pixel rectangle test
         if (hi - lane >= range.x) {
             stage[lane].p0 = n0;
             stage[lane].p1 = n1;
             stage[lane].p2 = n2;
             sid[lane] = ng;
             touch = block_touch_g<PX>(__float_as_uint(n1.w), __float_as_uint(n2.w), wx0, wy0);
+            binds_t = (__float_as_uint(n1.z) & 1u) != 0u && touch != 0u;
         }
+        const bool chunk_binds = __builtin_amdgcn_ballot_w64(binds_t) != 0ull;
         uint64_t m0 = __builtin_amdgcn_ballot_w64((touch & 1u) != 0u);
         uint64_t m1 = __builtin_amdgcn_ballot_w64((touch & 2u) != 0u);
         uint64_t m2 = __builtin_amdgcn_ballot_w64((touch & 4u) != 0u);
@@ -419,101 +422,105 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             n0 = packed[3 * (size_t)ng + 0]; n1 = packed[3 * (size_t)ng + 1]; n2 = packed[3 * (size_t)ng + 2];
         }
         bool flushed_any = false;  // wave-uniform
-        while ((m0 | m1 | m2 | m3) != 0ull) {
-            GS_WALK_STEP(m0, e0)
-            GS_WALK_STEP(m1, e1)
-            GS_WALK_STEP(m2, e2)
-            GS_WALK_STEP(m3, e3)
-            // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
-            const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
-            const int e = (int)((ep >> gsh) & 0xFFu);
-            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
-            const uint32_t sbits = __float_as_uint(q1.z);
-            const int idx = hi - e;  // index of this entry in the sorted list
-            GS_STAT(8, 1);
-            const float dx = q0.x - pxf;
-            const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
-            // rectangle test data of the rare entries whose rectangle cuts the sigma_max ellipse
-            const bool any_binds = __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
-            float su = 0.0f, suy = 0.0f, suyy = 0.0f, gr = 0.0f, gg = 0.0f, gb = 0.0f;
-            bool any = false;  // wave-uniform
-#pragma unroll
-            for (int p = 0; p < PX; p++) {
-                const float dy = q0.y - pyf[p];
-                float sg = 0.5f * fmaf(q1.x * dy, dy, Adxdx);
-                sg = fmaf(Bdx, dy, sg);
-                if (any_binds) {
-                    asm volatile("; rectangle binds");
-                    if (sbits & 1u) {
-                        // decide exactly like the forward: its op order for sigma, rectangle applied
-                        float se = Adxdx + (q1.x * dy) * dy;
-                        se = 0.5f * se;
-                        se = se + Bdx * dy;
-                        const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
-                        const uint32_t pyu = (uint32_t)(py0 + p * G::LH);
-                        const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
-                                        pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
-                        sg = in ? se + 0.0f : qnan();
-                    }
-                }
-                const bool need = (idx <= last[p]) && (__float_as_uint(sg) <= sbits);
-                const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
-                if (mneed == 0ull) continue;
-                any = true;
-                GS_STAT(9, 1);
-                GS_STAT(10, __builtin_popcountll(mneed));
-                // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
-                // that do not take part end up with vis = alpha = 0
-                float vis = need ? __expf(-sg) : 0.0f;
-                float alpha = q1.y * vis;
-                if (EXACT) {
-                    // same >= 1/255 decision as the forward: redo the exponential exactly (from the
-                    // forward's sigma) where the fast one cannot decide
-                    const float thr = 1.0f / 255.0f;
-                    const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
-                    if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
-                        asm volatile("; threshold ambiguous");
-                        if (amb) {
+        auto walk = [&](auto binds_tag) {
+            constexpr bool BINDS = decltype(binds_tag)::value;
+            while ((m0 | m1 | m2 | m3) != 0ull) {
+                GS_WALK_STEP(m0, e0)
+                GS_WALK_STEP(m1, e1)
+                GS_WALK_STEP(m2, e2)
+                GS_WALK_STEP(m3, e3)
+                // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
+                const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
+                const int e = (int)((ep >> gsh) & 0xFFu);
+                const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+                const uint32_t sbits = __float_as_uint(q1.z);
+                const int idx = hi - e;  // index of this entry in the sorted list
+                GS_STAT(8, 1);
+                const float dx = q0.x - pxf;
+                const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
+                // rectangle test data of the rare entries whose rectangle cuts the sigma_max ellipse
+                const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
+                float su = 0.0f, suy = 0.0f, suyy = 0.0f, gr = 0.0f, gg = 0.0f, gb = 0.0f;
+                bool any = false;  // wave-uniform
+    #pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    const float dy = q0.y - pyf[p];
+                    float sg = 0.5f * fmaf(q1.x * dy, dy, Adxdx);
+                    sg = fmaf(Bdx, dy, sg);
+                    if (any_binds) {
+                        asm volatile("; rectangle binds");
+                        if (sbits & 1u) {
+                            // decide exactly like the forward: its op order for sigma, rectangle applied
                             float se = Adxdx + (q1.x * dy) * dy;
                             se = 0.5f * se;
                             se = se + Bdx * dy;
-                            vis = expf_glibc_cmem(-se);
-                            alpha = q1.y * vis;
+                            const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                            const uint32_t pyu = (uint32_t)(py0 + p * G::LH);
+                            const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                            pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
+                            sg = in ? se + 0.0f : qnan();
                         }
                     }
+                    const bool need = (idx <= last[p]) && (__float_as_uint(sg) <= sbits);
+                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+                    if (mneed == 0ull) continue;
+                    any = true;
+                    GS_STAT(9, 1);
+                    GS_STAT(10, __builtin_popcountll(mneed));
+                    // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
+                    // that do not take part end up with vis = alpha = 0
+                    float vis = need ? __expf(-sg) : 0.0f;
+                    float alpha = q1.y * vis;
+                    if (EXACT) {
+                        // same >= 1/255 decision as the forward: redo the exponential exactly (from the
+                        // forward's sigma) where the fast one cannot decide
+                        const float thr = 1.0f / 255.0f;
+                        const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
+                        if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+                            asm volatile("; threshold ambiguous");
+                            if (amb) {
+                                float se = Adxdx + (q1.x * dy) * dy;
+                                se = 0.5f * se;
+                                se = se + Bdx * dy;
+                                vis = expf_glibc_cmem(-se);
+                                alpha = q1.y * vis;
+                            }
+                        }
+                    }
+                    const bool ok = alpha >= (1.0f / 255.0f);
+                    alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
+                    vis = ok ? vis : 0.0f;
+                    // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
+                    const float om = 1.0f - alpha;
+                    float ra = __builtin_amdgcn_rcpf(om);
+                    ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
+                    T[p] = T[p] * ra;  // transmittance in front of this Gaussian
+                    const float fac = alpha * T[p];
+                    gr = fmaf(fac, vo0[p], gr);
+                    gg = fmaf(fac, vo1[p], gg);
+                    gb = fmaf(fac, vo2[p], gb);
+                    // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
+                    const float cv = fmaf(q2.z, vo2[p], fmaf(q2.y, vo1[p], q2.x * vo0[p]));
+                    const float v_alpha = fmaf(T[p], cv, ra * (TW[p] - bv[p]));
+                    bv[p] = fmaf(fac, cv, bv[p]);
+                    // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
+                    const float u = vis * v_alpha;
+                    const float uy = u * dy;
+                    su += u;
+                    suy += uy;
+                    suyy = fmaf(uy, dy, suyy);
                 }
-                const bool ok = alpha >= (1.0f / 255.0f);
-                alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
-                vis = ok ? vis : 0.0f;
-                // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
-                const float om = 1.0f - alpha;
-                float ra = __builtin_amdgcn_rcpf(om);
-                ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
-                T[p] = T[p] * ra;  // transmittance in front of this Gaussian
-                const float fac = alpha * T[p];
-                gr = fmaf(fac, vo0[p], gr);
-                gg = fmaf(fac, vo1[p], gg);
-                gb = fmaf(fac, vo2[p], gb);
-                // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
-                const float cv = fmaf(q2.z, vo2[p], fmaf(q2.y, vo1[p], q2.x * vo0[p]));
-                const float v_alpha = fmaf(T[p], cv, ra * (TW[p] - bv[p]));
-                bv[p] = fmaf(fac, cv, bv[p]);
-                // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
-                const float u = vis * v_alpha;
-                const float uy = u * dy;
-                su += u;
-                suy += uy;
-                suyy = fmaf(uy, dy, suyy);
+                if (!any) continue;
+                // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
+                const float ux = su * dx;
+                const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1, li);
+                if (li < kAcc && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
+                    __hip_atomic_fetch_add(&acc[li * kAccStride + e], r, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                flushed_any = true;
             }
-            if (!any) continue;
-            // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
-            const float ux = su * dx;
-            const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1, li);
-            if (li < kAcc && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
-                __hip_atomic_fetch_add(&acc[li * kAccStride + e], r, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            flushed_any = true;
-        }
+        };
+        if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
         if (!flushed_any) continue;
         // ---- flush: moments -> gradient components (once per entry), then one atomic lane per
         //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
