@@ -135,9 +135,13 @@ k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
                   [&](int tile, uint32_t, int) { atomicAdd(&counts[tile], 1); });
 }
 
+// wg_base[workgroup][tile]: where, inside the tile's segment, the intersections this workgroup will
+// emit start — the value the flush's (returning) atomic hands back.  k_scatter walks the same
+// Gaussians in the same workgroup layout and simply continues from there: it used to recount them
+// and reserve its ranges with a second round of returning atomics (48 -> 33 us at C2).
 __global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
-              int32_t *__restrict__ counts) {
+              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base) {
     extern __shared__ int32_t h[];
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
@@ -154,9 +158,10 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
                       [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
     }
     __syncthreads();
+    int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
         const int32_t c = h[t];
-        if (c) atomicAdd(&counts[t], c);
+        my_base[t] = c ? atomicAdd(&counts[t], c) : 0;
     }
 }
 
@@ -301,33 +306,17 @@ k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict_
     });
 }
 
-// LDS-privatised variant: pass A counts this workgroup's intersections per tile in LDS; the
-// flush reserves a contiguous range per (workgroup, tile) with ONE returning global atomic and
-// turns the LDS counter into the range's start; pass B walks the same Gaussians again and takes
-// slots from the LDS cursors.  Slot order inside a tile is arbitrary — k_sort_tiles fixes it.
+// LDS-privatised variant: the workgroup's cursors start at the tile's segment start plus the offset
+// k_count_tiles reserved for this workgroup (wg_base), and every intersection takes its slot from
+// the LDS cursor.  Slot order inside a tile is arbitrary — the per-tile sort fixes it.  Must be
+// launched with k_count_tiles' grid and block size: the chunk -> workgroup assignment is the same.
 __global__ void __launch_bounds__(kPersistentThreads)
 k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
           const float *__restrict__ depths, const int2 *__restrict__ bins,
-          int32_t *__restrict__ fill, uint64_t *__restrict__ keys) {
+          const int32_t *__restrict__ wg_base, uint64_t *__restrict__ keys) {
     extern __shared__ int32_t h[];
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
-    __syncthreads();
-    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
-    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
-    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
-         chunk += (blockDim.x >> 6) * gridDim.x) {
-        const int n = chunk * 64 + (threadIdx.x & 63);
-        const bool valid = n < N;
-        TileRect r = {0, 0, 0, 0};
-        if (valid) r = tile_rect(packed, n);
-        for_each_tile(r, valid, tiles_x, 0u, 0,
-                      [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
-        const int32_t c = h[t];
-        if (c) h[t] = bins[t].x + atomicAdd(&fill[t], c);
-    }
+    const int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = bins[t].x + my_base[t];
     __syncthreads();
     // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
     // few thousand Gaussians with huge rectangles still keep every CU's waves busy
@@ -681,18 +670,22 @@ static int persistent_blocks(int N) {
     return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 
-// workspace layout: [ counters: tiles i32 | total: 1 i32 (+pad) | keys: capacity u64 ]
-// gs_bin_scan uses the counters as per-tile intersection counts, gs_bin_sort (which zeroes them
-// again) as per-tile fill cursors; nothing in the workspace has to survive between the two calls.
+// workspace layout: [ counters: tiles i32 | total: 1 i32 (+pad) | wg_base: 256 x tiles i32 | keys:
+// capacity u64 ].  gs_bin_scan uses the counters as per-tile intersection counts and leaves the
+// per-(workgroup, tile) offsets in wg_base for the gs_bin_sort that follows: BOTH CALLS MUST BE GIVEN
+// THE SAME WORKSPACE (the offsets of the key array move with the capacity, wg_base does not).
 struct BinLayout {
-    size_t counters, total_dev, keys, total;
+    size_t counters, total_dev, wg_base, keys, total;
 };
 static BinLayout bin_layout(int64_t capacity, int W, int H) {
     const size_t tiles = (size_t)((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     BinLayout L;
     L.counters = 0;
     L.total_dev = L.counters + align_up(tiles * 4);
-    L.keys = L.total_dev + 256;
+    L.wg_base = L.total_dev + 256;
+    // per-(workgroup, tile) offsets handed from the count to the scatter kernel (LDS variants only)
+    const size_t base_bytes = tiles * 4 <= kMaxTileLds ? align_up((size_t)256 * tiles * 4) : 0;
+    L.keys = L.wg_base + base_bytes;
     L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 8) + 256;
     return L;
 }
@@ -746,7 +739,8 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              (int)gs::kMaxTileLds));
             const int blocks = gs::persistent_blocks(N);
             hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
-                               reinterpret_cast<const float4 *>(packed), counts);
+                               reinterpret_cast<const float4 *>(packed), counts,
+                               reinterpret_cast<int32_t *>(base + L.wg_base));
         } else {
             hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
                                tiles_x, reinterpret_cast<const float4 *>(packed), counts);
@@ -787,8 +781,6 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     int32_t *fill = reinterpret_cast<int32_t *>(base + L.counters);
     uint64_t *keys = reinterpret_cast<uint64_t *>(base + L.keys);
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
-    GS_HIP_CHECK(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)tiles, s));
-
     const size_t lds = sizeof(int32_t) * (size_t)tiles;
     if (lds <= gs::kMaxTileLds) {
         GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scatter),
@@ -796,8 +788,10 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                                          (int)gs::kMaxTileLds));
         const int blocks = gs::persistent_blocks(N);
         hipLaunchKernelGGL(gs::k_scatter, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x, capacity,
-                           reinterpret_cast<const float4 *>(packed), depths, bins, fill, keys);
+                           reinterpret_cast<const float4 *>(packed), depths, bins,
+                           reinterpret_cast<const int32_t *>(base + L.wg_base), keys);
     } else {
+        GS_HIP_CHECK(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)tiles, s));
         hipLaunchKernelGGL(gs::k_scatter_global, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
                            capacity, reinterpret_cast<const float4 *>(packed), depths, bins, fill,
                            keys);
