@@ -137,14 +137,9 @@ __device__ __forceinline__ void stage_sentinel(SRec *s) {
 }
 
 // next entry of each group's walk; an exhausted group gets the sentinel slot
-// (s_ff1 gives -1 for an empty mask: as an unsigned number that clamps to kChunk, and as a bit index
-// s_bitset0 takes it modulo 64, clearing a bit of a mask that is zero anyway; one s_bitset0 instead
-// of the add / addc / and that "m &= m - 1" compiles to)
-#define GS_WALK_STEP(m, e)                                                     \
-    int e;                                                                     \
-    asm("s_ff1_i32_b64 %0, %1" : "=s"(e) : "s"(m));                            \
-    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(e));                            \
-    e = (int)min((uint32_t)e, (uint32_t)kChunk);
+#define GS_WALK_STEP(m, e)                                   \
+    const int e = (m) != 0ull ? (int)__builtin_ctzll(m) : kChunk; \
+    (m) &= (m)-1ull;
 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
