@@ -46,7 +46,10 @@ elseif(GPU_RUNTIME STREQUAL "HIP_NATIVE")
     find_library(GSPLAT_HIP   gsplat_hip   HINTS ${GSPLAT_AMD_DIR} REQUIRED)   # hand-written gfx950 kernels
     find_library(GSPLAT_TORCH gsplat_torch HINTS ${GSPLAT_AMD_DIR} REQUIRED)   # libtorch operators
     add_library(gsplat_cpu rasterizer/gsplat-cpu/gsplat_cpu.cpp)               # unchanged
-    set(GSPLAT_LIBS gsplat_cpu ${GSPLAT_TORCH} ${GSPLAT_HIP})                  # rasterizer/gsplat is NOT built
+    # rasterizer/gsplat is NOT built.  libtorch first: with a pip-wheel libtorch-ROCm (which bundles its own
+    # libamdhip64.so / librccl.so) the wheel's runtime must be mapped before libgsplat_hip asks for
+    # "libamdhip64.so.7", or the process ends up with two HIP runtimes
+    set(GSPLAT_LIBS gsplat_cpu ${TORCH_LIBRARIES} ${GSPLAT_TORCH} ${GSPLAT_HIP})
     add_compile_definitions(USE_HIP USE_HIP_NATIVE __HIP_PLATFORM_AMD__)
     include_directories(${GSPLAT_AMD_DIR})                                     # gsplat_ops.hpp
 '''

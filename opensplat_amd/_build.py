@@ -68,9 +68,14 @@ def build_torch(force: bool = False) -> str:
               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
               "-I/opt/rocm/include",
               "torch_ops.cpp", "bindings_hip_native.cpp", "-o", TORCH_LIB,
-              "-L" + CSRC, "-lgsplat_hip", "-lgsplat_dist",
+              # libtorch's libraries FIRST: the loader walks NEEDED entries breadth-first, and the
+              # ROCm runtime the wheel bundles (libamdhip64.so, librccl.so; SONAMEs .so.7 / .so.1)
+              # must be mapped before libgsplat_hip/_dist ask for "libamdhip64.so.7" /
+              # "librccl.so.1" -- a request matches an already-loaded SONAME, not the other way
+              # round, and a process with two HIP runtimes or two RCCLs corrupts its heap at exit.
+              "-Wl,--no-as-needed",
               "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
-              "-lc10_hip", "-Wl,-rpath,$ORIGIN"])
+              "-lc10_hip", "-L" + CSRC, "-lgsplat_hip", "-lgsplat_dist", "-Wl,-rpath,$ORIGIN"])
     return TORCH_LIB
 
 
@@ -121,10 +126,10 @@ def build_example(force: bool = False) -> str:
               "-I" + CSRC, "-I" + os.path.join(tdir, "include"),
               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
               EXAMPLE_SRC, "-o", EXAMPLE_BIN,
-              "-Wl,--no-as-needed",   # keep the torch libraries as direct dependencies of the program
-              "-L" + CSRC, "-lgsplat_torch", "-lgsplat_hip", "-lgsplat_dist",
+              "-Wl,--no-as-needed",   # torch's libraries first and kept: see build_torch on load order
               "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip",
-              "-lc10_hip", "-Wl,--disable-new-dtags",   # RPATH, so that it also serves libgsplat_torch.so's deps
+              "-lc10_hip", "-L" + CSRC, "-lgsplat_torch", "-lgsplat_hip", "-lgsplat_dist",
+              "-Wl,--disable-new-dtags",   # RPATH, so that it also serves libgsplat_torch.so's deps
               "-Wl,-rpath," + CSRC, "-Wl,-rpath," + os.path.join(tdir, "lib")])
     return EXAMPLE_BIN
 

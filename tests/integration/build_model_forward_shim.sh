@@ -23,6 +23,6 @@ for p in $pids; do wait $p; done
 # gsplat_cpu.cpp is untouched by the patch: the object oracle/Makefile built from it is reused
 g++ -o $ROOT/oracle/_ref/model_forward_shim $OUT/model_forward_tu.o $OUT/project_gaussians.o \
   $OUT/rasterize_gaussians.o $OUT/spherical_harmonics.o $ROOT/oracle/_ref/gsplat_cpu.o \
-  -Wl,--no-as-needed -L$CSRC -lgsplat_torch -lgsplat_hip -L$TORCH/lib -ltorch -ltorch_cpu -lc10 -ltorch_hip -lc10_hip \
+  -Wl,--no-as-needed -L$TORCH/lib -ltorch -ltorch_cpu -lc10 -ltorch_hip -lc10_hip -L$CSRC -lgsplat_torch -lgsplat_hip \
   -Wl,--disable-new-dtags -Wl,-rpath,$CSRC -Wl,-rpath,$TORCH/lib
 echo built $ROOT/oracle/_ref/model_forward_shim

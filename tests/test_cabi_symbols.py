@@ -180,3 +180,17 @@ def test_image_library_exports_its_header():
     l = colmap.image_lib()
     assert not [n for n in names if not hasattr(l, n)]
     assert l.gs_image_strerror(0) == b"ok" and b"unsupported" in l.gs_image_strerror(-2)
+
+
+def test_cpp_example_maps_one_hip_runtime_and_one_rccl():
+    """A program linked against the in-tree libraries and libtorch must end up with ONE HIP runtime
+    and ONE RCCL (two of either corrupt the heap at exit and break stream ordering): the link order
+    in _build.build_torch/build_example puts libtorch's bundled ROCm first."""
+    import re
+    import subprocess
+
+    exe = _build.build_example()
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True, timeout=120).stdout
+    for stem in ("libamdhip64", "librccl", "libhsa-runtime64"):
+        found = sorted({m.group(1) for m in re.finditer(r"=> (\S*%s\.so\S*)" % re.escape(stem), out)})
+        assert len(found) == 1, (stem, found)
