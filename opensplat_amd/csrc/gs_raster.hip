@@ -538,9 +538,14 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             acc[4 * kAccStride + lane] = 0.5f * mo * Uyy;            // v_C
         }
         wave_sync();
+        // (the lane id is re-read through an opaque move: otherwise the 18 loop-invariant (entry,
+        // component) addresses below are hoisted out of the chunk loop and, at 96 VGPRs, spilled to
+        // scratch -- 72 B per lane stored per wave and reloaded per chunk, +235 MB of HBM traffic)
+        int fl = lane;
+        asm volatile("" : "+v"(fl));
 #pragma unroll
         for (int i = 0; i < kAcc; i++) {
-            const int k = i * kChunk + lane;          // record-major enumeration: k = 9 * entry + comp
+            const int k = i * kChunk + fl;            // record-major enumeration: k = 9 * entry + comp
             const int ent = (k * 7282) >> 16;         // k / 9 for k < 576
             const int comp = k - 9 * ent;
             const float v = acc[comp * kAccStride + ent];
