@@ -26,8 +26,12 @@ HIP_LIB = os.path.join(CSRC, "libgsplat_hip.so")
 TORCH_LIB = os.path.join(CSRC, "libgsplat_torch.so")
 
 # -ffp-contract=off: the compositing arithmetic must round like the CPU reference (no implicit FMA)
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 operations of the compositing loops into
+# v_pk_* instructions plus the v_mov shuffles that line their operands up; a packed operation issues
+# in ~5 cycles against 2 x 2.9 for the plain ones, the moves eat the difference (measured: backward
+# 386 -> 381 us, k_gaussian_backward 71 -> 67 us at C2, profiles/bench_va_*.json)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+               "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target: str, sources: list[str]) -> bool:

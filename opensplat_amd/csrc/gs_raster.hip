@@ -273,31 +273,54 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     }
 }
 
-// Sums of nine per-lane values over each 16-lane DPP row, in registers: a transposing butterfly.
-// Stage 1 (lane ^ 1) folds value PAIRS — even lanes keep the pair sum of the even value, odd lanes of
-// the odd value — stage 2 (lane ^ 2) does the same with pairs of those, leaving the quad sum of
-// value (lane & 3) [+4]; two rotations by 4 and 8 lanes add the four quads.  13 + 7 + 6 + 2 = 28
-// VALU (13 plain DPP adds), no LDS: the round-1 LDS reduction (9 stores + 4 x 16-byte loads per
-// lane) made the LDS the bottleneck of this kernel once every step carries a reduction
-// (SQ_LDS_IDX_ACTIVE == kernel duration, profiles/r02b).  Lane c (< 9) of each row returns total c.
+// Sums of nine per-lane values over each 16-lane DPP row, in registers: a transposing butterfly that
+// folds the row from the outside in.  The two cross-quad stages use DPP adds whose BANK MASK leaves
+// part of the destination untouched, so two values share a register without any select:
+//   A  r = a + row_mirror(a) everywhere, then r = b + row_mirror(b) in banks 2,3 only: lanes 0-7
+//      hold eight partial sums of a, lanes 8-15 of b                       (4 pairs x 2 + 1 = 9 VALU)
+//   B  s = r01 + row_half_mirror(r01), then banks 1,3 <- r23 + row_half_mirror(r23): the four banks
+//      hold four partial sums each of (a, c, b, d)                                  (2 + 2 + 1 = 5)
+//   C  quad_perm [1,0,3,2] with a lane-parity select folds s0 | s1 into one register, s2 alone  (4)
+//   D  quad_perm [2,3,0,1] with a bit-1 select folds those two                                  (3)
+// 21 VALU (round 2's first version: 28, all stages with selects), no LDS.  The mirrors make the
+// result independent of the rotation direction convention.  Lane li of each row ends with the total
+// of value reduce9_component(li) (or -1: nothing).  The masked adds are inline assembly (the compiler
+// cannot express a partial DPP write), each group behind an s_nop 1 for the VALU-write -> DPP-read
+// hazard the assembler does not see.
+__device__ __forceinline__ int reduce9_component(int li) {
+    const int j = li & 3, b = li >> 2;
+    const int bank_value = ((b & 1) << 1) | (b >> 1);   // banks hold values 0, 2, 1, 3 (+4 for s1)
+    return j == 0 ? bank_value : (j == 1 ? 4 + bank_value : (li == 2 ? 8 : -1));
+}
 __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float v3, float v4,
                                              float v5, float v6, float v7, float v8, bool odd,
-                                             bool bit1, int li) {
-    const float w01 = (odd ? v1 : v0) + dpp_f<0xB1>(odd ? v0 : v1);  // quad_perm [1,0,3,2]
-    const float w23 = (odd ? v3 : v2) + dpp_f<0xB1>(odd ? v2 : v3);
-    const float w45 = (odd ? v5 : v4) + dpp_f<0xB1>(odd ? v4 : v5);
-    const float w67 = (odd ? v7 : v6) + dpp_f<0xB1>(odd ? v6 : v7);
-    const float w8 = v8 + dpp_f<0xB1>(v8);
-    float x03 = (bit1 ? w23 : w01) + dpp_f<0x4E>(bit1 ? w01 : w23);  // quad_perm [2,3,0,1]
-    float x47 = (bit1 ? w67 : w45) + dpp_f<0x4E>(bit1 ? w45 : w67);
-    float x8 = w8 + dpp_f<0x4E>(w8);
-    x03 += dpp_f<0x124>(x03);  // row_ror:4
-    x47 += dpp_f<0x124>(x47);
-    x8 += dpp_f<0x124>(x8);
-    x03 += dpp_f<0x128>(x03);  // row_ror:8
-    x47 += dpp_f<0x128>(x47);
-    x8 += dpp_f<0x128>(x8);
-    return li < 4 ? x03 : (li < 8 ? x47 : x8);
+                                             bool bit1) {
+    // A: fold the row's halves
+    float r01 = v0 + dpp_f<0x140>(v0);  // row_mirror
+    float r23 = v2 + dpp_f<0x140>(v2);
+    float r45 = v4 + dpp_f<0x140>(v4);
+    float r67 = v6 + dpp_f<0x140>(v6);
+    const float r8 = v8 + dpp_f<0x140>(v8);
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_mirror row_mask:0xf bank_mask:0xc"
+                 : "+v"(r01), "+v"(r23), "+v"(r45), "+v"(r67)
+                 : "v"(v1), "v"(v3), "v"(v5), "v"(v7));
+    // B: fold the halves' quads
+    float s0 = r01 + dpp_f<0x141>(r01);  // row_half_mirror
+    float s1 = r45 + dpp_f<0x141>(r45);
+    const float s2 = r8 + dpp_f<0x141>(r8);
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
+                 : "+v"(s0), "+v"(s1)
+                 : "v"(r23), "v"(r67));
+    // C, D: inside the quads
+    const float t = (odd ? s1 : s0) + dpp_f<0xB1>(odd ? s0 : s1);  // quad_perm [1,0,3,2]
+    const float u = s2 + dpp_f<0xB1>(s2);
+    return (bit1 ? u : t) + dpp_f<0x4E>(bit1 ? t : u);            // quad_perm [2,3,0,1]
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,8 +333,11 @@ constexpr int kBackwardPixelsPerLane = 2;      // default WaveGeom of the backwa
 
 // (five waves per SIMD: the compiler keeps the rare exact-exponential / rectangle paths out of the
 // register budget — measured -0.7 % at C2, -4 % at C3 against the unconstrained 116 VGPRs)
+#ifndef GS_BWD_WAVES
+#define GS_BWD_WAVES 5
+#endif
 template <bool EXACT, bool DET, int PX>
-__global__ void __launch_bounds__(64, 5)
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
 k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                      const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
                      const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
@@ -331,6 +357,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     }
     const int grp = lane >> 4, li = lane & 15;
     const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
+    const int rcomp = reduce9_component(li);   // which of the nine sums row_reduce9 leaves in this lane
+    const int fj = (lane * 7282) >> 16;        // flush: lane = 9 * fj + fcomp (lane 63: fj = 7, no work)
+    const int fcomp = lane == 63 ? kAcc : lane - 9 * fj;
     const uint32_t gsh = 8u * (uint32_t)grp;
     const int px = wx0 + G::BW * (grp & 1) + (li % G::LW);
     const int py0 = wy0 + G::BH * (grp >> 1) + (li / G::LW);   // pixel p of the lane: row py0 + p * LH
@@ -461,24 +490,28 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                             sg = in ? se + 0.0f : qnan();
                         }
                     }
-                    const bool need = (idx <= last[p]) && (__float_as_uint(sg) <= sbits);
-                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+                    // lane masks are combined as 64-bit scalars (ballot of each compare, s_and) and turned
+                    // back into a lane predicate with inverse_ballot: a ballot of `a && b` costs a
+                    // v_cndmask + v_cmp pair per use
+                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(idx <= last[p]) &
+                                           __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
                     if (mneed == 0ull) continue;
                     any = true;
                     GS_STAT(9, 1);
                     GS_STAT(10, __builtin_popcountll(mneed));
-                    // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338; lanes
-                    // that do not take part end up with vis = alpha = 0
-                    float vis = need ? __expf(-sg) : 0.0f;
+                    // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338.  Lanes
+                    // that do not need the entry keep whatever the exponential makes of their sigma
+                    // (possibly inf or NaN) until `ok` discards it: they end with vis = alpha = 0
+                    float vis = __expf(-sg);
                     float alpha = q1.y * vis;
                     if (EXACT) {
                         // same >= 1/255 decision as the forward: redo the exponential exactly (from the
                         // forward's sigma) where the fast one cannot decide
                         const float thr = 1.0f / 255.0f;
-                        const bool amb = need && fabsf(alpha - thr) < 1.0e-8f;
-                        if (__builtin_amdgcn_ballot_w64(amb) != 0ull) {
+                        const uint64_t mamb = mneed & __builtin_amdgcn_ballot_w64(fabsf(alpha - thr) < 1.0e-8f);
+                        if (mamb != 0ull) {
                             asm volatile("; threshold ambiguous");
-                            if (amb) {
+                            if (__builtin_amdgcn_inverse_ballot_w64(mamb)) {
                                 float se = Adxdx + (q1.x * dy) * dy;
                                 se = 0.5f * se;
                                 se = se + Bdx * dy;
@@ -487,7 +520,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                             }
                         }
                     }
-                    const bool ok = alpha >= (1.0f / 255.0f);
+                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(
+                        mneed & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)));
                     alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
                     vis = ok ? vis : 0.0f;
                     // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
@@ -513,9 +547,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 if (!any) continue;
                 // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
                 const float ux = su * dx;
-                const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1, li);
-                if (li < kAcc && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
-                    __hip_atomic_fetch_add(&acc[li * kAccStride + e], r, __ATOMIC_RELAXED,
+                const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
+                if (rcomp >= 0 && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
+                    __hip_atomic_fetch_add(&acc[rcomp * kAccStride + e], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 flushed_any = true;
             }
@@ -538,23 +572,24 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             acc[4 * kAccStride + lane] = 0.5f * mo * Uyy;            // v_C
         }
         wave_sync();
-        // (the lane id is re-read through an opaque move: otherwise the 18 loop-invariant (entry,
-        // component) addresses below are hoisted out of the chunk loop and, at 96 VGPRs, spilled to
-        // scratch -- 72 B per lane stored per wave and reloaded per chunk, +235 MB of HBM traffic)
-        int fl = lane;
-        asm volatile("" : "+v"(fl));
+        // record-major: lanes 9 j .. 9 j + 8 carry the nine components of entry 7 i + j (j < 7, lane
+        // 63 idle), so the nine lanes of an entry hit ONE 64-byte record in one instruction and the
+        // only per-lane constants are (j, component): the entry of iteration i is an immediate offset
+        // away.  (Enumerating k = 64 i + lane -> (k / 9, k % 9) instead needs 18 loop-invariant
+        // addresses, which the compiler hoists and -- at 96 VGPRs -- spills: +235 MB of scratch
+        // traffic per launch, profiles/r02_pmc.json.)
 #pragma unroll
-        for (int i = 0; i < kAcc; i++) {
-            const int k = i * kChunk + fl;            // record-major enumeration: k = 9 * entry + comp
-            const int ent = (k * 7282) >> 16;         // k / 9 for k < 576
-            const int comp = k - 9 * ent;
-            const float v = acc[comp * kAccStride + ent];
-            if (v != 0.0f) {
-                const size_t o = (size_t)sid[ent] * kGradRec + comp;
-                if (DET)
-                    atomicAdd(gfix + o, (unsigned long long)(long long)(v * kFixScale));
-                else
-                    atomicAdd(gacc + o, v);
+        for (int i = 0; i < (kChunk + 6) / 7; i++) {
+            const int ent = 7 * i + fj;
+            if (fcomp < kAcc && (7 * i + 6 < kChunk || ent < kChunk)) {
+                const float v = acc[fcomp * kAccStride + ent];
+                if (v != 0.0f) {
+                    const size_t o = (size_t)sid[ent] * kGradRec + fcomp;
+                    if (DET)
+                        atomicAdd(gfix + o, (unsigned long long)(long long)(v * kFixScale));
+                    else
+                        atomicAdd(gacc + o, v);
+                }
             }
         }
         wave_sync();
@@ -612,8 +647,9 @@ __global__ void __launch_bounds__(64) k_debug_row_reduce9(const float *__restric
     for (int i = 0; i < 9; i++) v[i] = p[i * 64 + lane];
     const int li = lane & 15;
     const float r = row_reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], (lane & 1) != 0,
-                                (lane & 2) != 0, li);
-    if (li < 9) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * 9 + li] = r;
+                                (lane & 2) != 0);
+    const int c = reduce9_component(li);
+    if (c >= 0) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * 9 + c] = r;
 }
 
 // GS_FLAG_DETERMINISTIC: 64-bit fixed-point sums -> the float records
