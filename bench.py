@@ -53,6 +53,12 @@ def parse_args():
                     help="c4-sequence: ONE GPU cycling through the 8 C4 cameras, a different camera every "
                          "step (what a training loop does): measures the speculative binning on a moving "
                          "camera (misses = forwards repeated because the id list was too small)")
+    ap.add_argument("--exchange", choices=["auto", "flat", "factored"], default="auto",
+                    help="N > 1: gradient exchange — flat = ONE sum all-reduce of the whole gradient "
+                         "buffer (236 B per Gaussian at K = 16); factored = all-reduce of the geometry "
+                         "block (44 B) + all-gather of the colour cotangents (12 B per camera), SH "
+                         "gradients formed locally (opensplat_amd/dist.py FactoredExchange); auto = "
+                         "factored while cameras_per_rank x ranks <= 32")
     ap.add_argument("--cameras-per-rank", type=int, default=1,
                     help="N > 1 only: cameras each rank renders per gradient exchange (gradients "
                          "accumulated in the flat buffer, ONE all-reduce per c rasterizations); "
@@ -80,7 +86,7 @@ def parse_args():
 class Pipeline:
     """The hot path on one GPU with every buffer preallocated."""
 
-    def __init__(self, scene, device, flags, stage_kernels=False):
+    def __init__(self, scene, device, flags, stage_kernels=False, factored=False, cameras_per_rank=1):
         import torch
 
         from opensplat_amd import cabi, dist
@@ -140,6 +146,9 @@ class Pipeline:
             self.gout = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
                              v_quats=self.grads.v_quats, v_opacity=self.grads.v_opacity,
                              v_dc=self.grads.v_dc, v_rest=self.grads.v_rest)
+        # factored exchange: gs_gaussian_backward hands out the colour cotangent of each local camera
+        # (into the all-gather message) instead of SH gradients
+        self.fx = dist.FactoredExchange(N, K, cameras_per_rank, dev) if (factored and not stage_kernels) else None
 
     def set_camera(self, viewmat, projmat):
         """Another camera over the same Gaussians (intrinsics unchanged)."""
@@ -151,12 +160,12 @@ class Pipeline:
         R, tr = viewmat[:3, :3], viewmat[:3, 3]
         self.cam_pos.copy_(t((-R.T @ tr).astype(np.float32)))
 
-    def step(self, events=None, kernel_events=None, accumulate=False, exchange=True):
+    def step(self, events=None, kernel_events=None, accumulate=False, exchange=True, slot=0):
         """One forward+backward.  events: list that receives the stage-boundary events;
         kernel_events: dict name -> (start, stop) event pairs armed around the two compositing
         kernels alone (gs_debug_time_next_kernel)."""
         if not self.stage_kernels:
-            return self.step_fused(events, kernel_events, accumulate, exchange)
+            return self.step_fused(events, kernel_events, accumulate, exchange, slot)
         assert not accumulate and exchange, "camera batches per rank run on the fused path"
         torch, cabi, s = self.torch, self.cabi, self.s
 
@@ -224,10 +233,11 @@ class Pipeline:
         mark()
 
 
-    def step_fused(self, events=None, kernel_events=None, accumulate=False, exchange=True):
+    def step_fused(self, events=None, kernel_events=None, accumulate=False, exchange=True, slot=0):
         """Same work with gs_gaussian_forward / gs_gaussian_backward around binning + compositing.
         accumulate: add this camera's gradients to the flat buffer (GS_FLAG_ACCUMULATE_GRADS);
-        exchange: all-reduce the flat buffer afterwards (the last camera of a rank's batch)."""
+        exchange: exchange the gradients afterwards (the last camera of a rank's batch);
+        slot: index of this camera in the rank's batch (factored exchange: its message slot)."""
         torch, cabi, s = self.torch, self.cabi, self.s
         # GSPLAT_RECORDS_ZEROED=1: gs_gaussian_backward zeroes the gradient records behind its read
         # and the per-frame memset is skipped — measured SLOWER at C2 (1.27 vs 1.25 ms): the memset
@@ -265,9 +275,14 @@ class Pipeline:
                                     self.v_out, self.flags | KEEP, workspace=self.bwd_ws)
             mark()
             ACC = cabi.GS_FLAG_ACCUMULATE_GRADS if accumulate else 0
+            gout = self.gout
+            if self.fx is not None:
+                gout = dict(self.gout, v_dc=self.fx.v_color(slot), v_rest=None)
+                self.fx.set_cam_pos(slot, self.cam_pos)
+                ACC |= cabi.GS_FLAG_EMIT_VCOLOR
             cabi.gaussian_backward(self.cam, self.means, self.scales, self.quats, self.opac,
                                    self.cam_pos, s.K, s.degrees_to_use, g["radii"], g["rgb_raw"],
-                                   self.bwd_ws, self.gout, ZEROED | ACC, viewmat_dev=self.vm_dev,
+                                   self.bwd_ws, gout, ZEROED | ACC, viewmat_dev=self.vm_dev,
                                    projmat_dev=self.pm_dev)
             mark()
             break
@@ -275,7 +290,11 @@ class Pipeline:
         if events is not None:
             events.extend(ev_local)
         if exchange:
-            self.dist.wait_all(self.dist.allreduce_all_async(self.grads))
+            if self.fx is not None:
+                self.fx.start(self.grads)
+                self.fx.finish(self.grads, self.means, s.degrees_to_use)
+            else:
+                self.dist.wait_all(self.dist.allreduce_all_async(self.grads))
         if events is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -482,7 +501,7 @@ def main():
     else:
         scene = scenes.config_c4(rank * args.cameras_per_rank, args.gaussians)
         workload = ("C4: %d shared Gaussians, %d cameras at 1920x1080 (%d per rank, yaw offsets), "
-                    "SH degree 3, gradients all-reduced (RCCL)" % (args.gaussians,
+                    "SH degree 3, gradients exchanged over RCCL" % (args.gaussians,
                                                                    world * args.cameras_per_rank,
                                                                    args.cameras_per_rank))
     cpr = args.cameras_per_rank if (world > 1 or cfg == "c4") else 1
@@ -493,7 +512,10 @@ def main():
     flags = cabi.GS_FLAG_FAST_EXP if args.fast_exp else 0
     if os.environ.get("GSPLAT_BWD_PX"):      # A/B: pixels per lane of the compositing backward (1, 2, 4)
         flags |= ({"1": 1, "2": 2, "4": 3}[os.environ["GSPLAT_BWD_PX"]]) << 21
-    pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels)
+    factored = world > 1 and not args.stage_kernels and (
+        args.exchange == "factored" or (args.exchange == "auto" and cpr * world <= 32))
+    pipe = Pipeline(scene, dev, flags, stage_kernels=args.stage_kernels, factored=factored,
+                    cameras_per_rank=cpr)
 
     def barrier():
         if world > 1:
@@ -511,7 +533,7 @@ def main():
             if cpr > 1:
                 pipe.set_camera(*cams[(rank * cpr + j) % 8])
             last = j == cpr - 1
-            pipe.step(ev if last else None, kev if last else None, accumulate=j > 0, exchange=last)
+            pipe.step(ev if last else None, kev if last else None, accumulate=j > 0, exchange=last, slot=j)
 
     for _ in range(args.warmup):
         one_step()
@@ -627,7 +649,16 @@ def main():
                               "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stage_ms": stage_ms,
-            "grad_bytes_allreduced": pipe.grads.nbytes if world > 1 else 0,
+            # the gradient exchange: what is all-reduced / all-gathered per step and the xGMI bytes a
+            # rank sends (ring all-reduce 2 (W-1)/W x S, all-gather (W-1) x message)
+            "exchange": ({"mode": "none"} if world == 1 else
+                         {"mode": "factored", "allreduce_bytes": 11 * N * 4,
+                          "allgather_message_bytes": pipe.fx.chunk * 4,
+                          "bytes_moved_per_rank": pipe.fx.bytes_moved_per_rank} if pipe.fx is not None else
+                         {"mode": "flat", "allreduce_bytes": pipe.grads.nbytes,
+                          "bytes_moved_per_rank": int(2 * (world - 1) / world * pipe.grads.nbytes)}),
+            "grad_bytes_allreduced": (0 if world == 1 else 11 * N * 4 if pipe.fx is not None
+                                      else pipe.grads.nbytes),
             "allreduce_ms_rank0": stage_ms.get("allreduce", 0.0),
             # speculative binning: forwards repeated because the id list (sized from the previous
             # call, +12.5 %) was too small — during warm-up / inside the timed region

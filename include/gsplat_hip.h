@@ -84,6 +84,10 @@ typedef struct GsCamera {
                                      partial sums are accumulated as 64-bit fixed point, so two     \
                                      runs are bit-identical; workspace from                         \
                                      gs_rasterize_backward_workspace_bytes_det                      */
+#define GS_FLAG_EMIT_VCOLOR 128u   /* gs_gaussian_backward: write the colour cotangent behind the clamp \
+                                     mask (3 floats per Gaussian) to v_dc and leave v_rest alone:    \
+                                     the factored gradient exchange forms the SH gradients of ALL    \
+                                     cameras with gs_sh_backward_cameras                             */
 
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
@@ -310,6 +314,19 @@ int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_dev, const fl
                          size_t records_bytes, float *v_means, float *v_scales, float *v_quats,
                          float *v_opacity, float *v_dc, float *v_rest, float *v_xy, uint32_t flags,
                          gs_stream_t stream);
+
+/* SH gradients from the colour cotangents of several cameras: v_sh[n][b] = sum_c basis_b(dir(n, c)) *
+ * v_colors[c][n] (spherical_harmonics.cpp:60-77 / backward.cu compute_sh_backward per camera, summed
+ * in camera order).  The camera-per-rank path exchanges v_colors (12 B per Gaussian and camera,
+ * all-gather) instead of all-reducing the 12 K bytes of SH gradients (include/gsplat_dist.h).
+ *   in : means[N,3]; cam_pos_dev: n_cams camera centres on the DEVICE, cam_pos_stride floats apart;
+ *        v_colors: n_cams blocks of [N,3], v_colors_stride floats apart (what gs_gaussian_backward
+ *        wrote to v_dc under GS_FLAG_EMIT_VCOLOR; all-zero rows are skipped)
+ *   out: v_dc[N,3] v_rest[N,K-1,3]; GS_FLAG_ACCUMULATE_GRADS adds instead of overwriting            */
+int gs_sh_backward_cameras(int N, int K, int degrees_to_use, int n_cams, const float *means,
+                           const float *cam_pos_dev, int cam_pos_stride, const float *v_colors,
+                           size_t v_colors_stride, float *v_dc, float *v_rest, uint32_t flags,
+                           gs_stream_t stream);
 
 #ifdef __cplusplus
 }

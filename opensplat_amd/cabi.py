@@ -24,6 +24,7 @@ GS_FLAG_KEEP_RECORDS = 8
 GS_FLAG_RECORDS_ZEROED = 16
 GS_FLAG_ACCUMULATE_GRADS = 32
 GS_FLAG_DETERMINISTIC = 64
+GS_FLAG_EMIT_VCOLOR = 128
 GS_CAM_LOG_SCALES = 1
 
 # every symbol include/gsplat_hip.h declares (tests check they are all exported)
@@ -32,6 +33,7 @@ SYMBOLS = [
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
+    "gs_sh_backward_cameras",
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
@@ -588,6 +590,25 @@ def gaussian_backward(cam: GsCamera, means, scales, quats, opacities, cam_pos, K
                                       _p(records), C.c_size_t(records.numel() * records.element_size()),
                                       _p(out["v_means"]), _p(out["v_scales"]), _p(out["v_quats"]),
                                       _p(out["v_opacity"]), _p(out["v_dc"]),
-                                      _p(out["v_rest"]) if K > 1 else C.c_void_p(0), _p(v_xy),
+                                      _p(out["v_rest"]) if (K > 1 and out.get("v_rest") is not None)
+                                      else C.c_void_p(0), _p(v_xy),
                                       C.c_uint32(flags), _stream()), "gs_gaussian_backward")
     return out
+
+
+def sh_backward_cameras(K, degrees_to_use, means, cam_pos, v_colors, v_dc, v_rest, flags=0,
+                        cam_pos_stride=None, v_colors_stride=None, n_cams=None):
+    """SH gradients from the colour cotangents of several cameras (gs_sh_backward_cameras).
+    cam_pos: device tensor whose camera c starts cam_pos_stride floats after camera c - 1 (default:
+    a [n_cams, >=3] tensor); v_colors: [n_cams, N, 3] (or a flat tensor with v_colors_stride)."""
+    N = means.shape[0]
+    if n_cams is None:
+        n_cams = cam_pos.shape[0] if cam_pos_stride is None else (cam_pos.numel() // cam_pos_stride)
+    cs = cam_pos.shape[1] if cam_pos_stride is None else cam_pos_stride
+    vs = N * 3 if v_colors_stride is None else v_colors_stride
+    _check(lib().gs_sh_backward_cameras(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), C.c_int(n_cams),
+                                        _p(means), _p(cam_pos), C.c_int(cs), _p(v_colors),
+                                        C.c_size_t(vs), _p(v_dc),
+                                        _p(v_rest) if K > 1 else C.c_void_p(0), C.c_uint32(flags),
+                                        _stream()), "gs_sh_backward_cameras")
+    return v_dc, v_rest

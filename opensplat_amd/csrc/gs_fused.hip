@@ -224,9 +224,18 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         const float v0 = (rgb_raw[3 * g + 0] + 0.5f >= 0.0f) ? rb.y : 0.0f;
         const float v1 = (rgb_raw[3 * g + 1] + 0.5f >= 0.0f) ? rb.z : 0.0f;
         const float v2 = (rgb_raw[3 * g + 2] + 0.5f >= 0.0f) ? rb.w : 0.0f;
-        put(v_dc + 3 * g + 0, r[0] * v0);
-        put(v_dc + 3 * g + 1, r[0] * v1);
-        put(v_dc + 3 * g + 2, r[0] * v2);
+        if (flags & GS_FLAG_EMIT_VCOLOR) {
+            // factored gradient exchange: hand out the colour cotangent behind the clamp mask itself
+            // (never accumulated: every camera has its own view direction); the SH gradients are
+            // formed from all cameras' cotangents by gs_sh_backward_cameras
+            v_dc[3 * g + 0] = v0;
+            v_dc[3 * g + 1] = v1;
+            v_dc[3 * g + 2] = v2;
+        } else {
+            put(v_dc + 3 * g + 0, r[0] * v0);
+            put(v_dc + 3 * g + 1, r[0] * v1);
+            put(v_dc + 3 * g + 2, r[0] * v2);
+        }
         float *row = slab + lane * ROWP;
 #pragma unroll
         for (int b = 1; b < K; b++) {
@@ -289,6 +298,93 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
             }
         }
     }
+}
+
+// SH gradients from the colour cotangents of SEVERAL cameras (the factored gradient exchange of the
+// camera-per-rank path): v_sh[n][b] = sum over cameras c of basis_b(dir(n, c)) * v_c(n, c).
+// The SH gradient of one camera is the outer product of a basis vector every rank can evaluate
+// (it depends on the Gaussian's mean and the camera centre only) and three floats per Gaussian, so
+// the ranks exchange the three floats (all-gather, 12 B per Gaussian and camera) instead of
+// all-reducing 12 K bytes per Gaussian.  One lane per Gaussian, the sums in registers, cameras in
+// index order (deterministic, identical on every rank); rows out through the LDS slab like
+// k_gaussian_backward.  HBM-streaming: reads 12 + 12 * cameras, writes 12 K bytes per Gaussian.
+template <int K>
+__global__ void __launch_bounds__(ShSplit<K>::kBlock)
+k_sh_backward_cameras(int N, int nb, int n_cams, const float *__restrict__ means,
+                      const float *__restrict__ cam_pos, int cam_stride,
+                      const float *__restrict__ v_colors, size_t v_stride, float *__restrict__ v_dc,
+                      float *__restrict__ v_rest, uint32_t flags) {
+    constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *slab = smem + wave * (64 * ROWP);
+    const bool accum = (flags & GS_FLAG_ACCUMULATE_GRADS) != 0u;
+    auto put = [accum](float *p, float v) { *p = accum ? *p + v : v; };
+    const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
+    const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
+    if (lane < cnt) {
+        const int64_t g = g0 + lane;
+        float acc[3 * K];
+#pragma unroll
+        for (int i = 0; i < 3 * K; i++) acc[i] = 0.0f;
+        for (int c = 0; c < n_cams; c++) {
+            const float *vc = v_colors + (size_t)c * v_stride + 3 * g;
+            const float v0 = vc[0], v1 = vc[1], v2 = vc[2];
+            if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f) continue;  // culled / unseen from camera c
+            const float *cp = cam_pos + (size_t)c * cam_stride;
+            float x, y, z;
+            view_dir(means, g, cp[0], cp[1], cp[2], x, y, z);
+            float r[25];
+            sh_basis(nb, x, y, z, r);
+#pragma unroll
+            for (int b = 0; b < K; b++) {
+                acc[3 * b + 0] = acc[3 * b + 0] + r[b] * v0;
+                acc[3 * b + 1] = acc[3 * b + 1] + r[b] * v1;
+                acc[3 * b + 2] = acc[3 * b + 2] + r[b] * v2;
+            }
+        }
+        put(v_dc + 3 * g + 0, acc[0]);
+        put(v_dc + 3 * g + 1, acc[1]);
+        put(v_dc + 3 * g + 2, acc[2]);
+        float *row = slab + lane * ROWP;
+#pragma unroll
+        for (int i = 0; i < ROW; i++) row[i] = acc[3 + i];
+    }
+    __syncthreads();
+    if constexpr (ROW > 0) {
+        float *dst = v_rest + g0 * ROW;
+        const int total = cnt * ROW;
+        for (int i = lane * 4; i < total; i += 64 * 4) {
+            if (i + 3 < total) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int idx = i + k;
+                    e[k] = slab[(idx / ROW) * ROWP + (idx % ROW)];
+                }
+                float4_u v;
+                v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
+                if (accum) v = v + *reinterpret_cast<float4_u *>(dst + i);
+                *reinterpret_cast<float4_u *>(dst + i) = v;
+            } else {
+                for (int idx = i; idx < total; idx++)
+                    put(dst + idx, slab[(idx / ROW) * ROWP + (idx % ROW)]);
+            }
+        }
+    }
+}
+
+template <int K>
+static int launch_sh_backward_cameras(int N, int nb, int n_cams, const float *means,
+                                      const float *cam_pos, int cam_stride, const float *v_colors,
+                                      size_t v_stride, float *v_dc, float *v_rest, uint32_t flags,
+                                      hipStream_t s) {
+    constexpr int BLK = ShSplit<K>::kBlock;
+    const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
+    hipLaunchKernelGGL(k_sh_backward_cameras<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+                       n_cams, means, cam_pos, cam_stride, v_colors, v_stride, v_dc, v_rest, flags);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
 }
 
 template <int K>
@@ -387,8 +483,9 @@ extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_de
     if (!cam || N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg)
         return GS_ERR_INVALID_ARGUMENT;
     if (N == 0) return GS_OK;
+    const bool emit = (flags & GS_FLAG_EMIT_VCOLOR) != 0u;   // v_dc <- colour cotangent, v_rest untouched
     if (!means || !scales || !quats || !opacities || !cam_pos || !radii || !rgb_raw || !records ||
-        !v_means || !v_scales || !v_quats || !v_opacity || !v_dc || (K > 1 && !v_rest))
+        !v_means || !v_scales || !v_quats || !v_opacity || !v_dc || (K > 1 && !v_rest && !emit))
         return GS_ERR_INVALID_ARGUMENT;
     if (records_bytes < (size_t)N * gs::kRec * sizeof(float)) return GS_ERR_WORKSPACE;
     if ((uintptr_t)records & 63u) return GS_ERR_INVALID_ARGUMENT;
@@ -399,7 +496,7 @@ extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_de
     return gs::launch_gaussian_backward<KK>(a, viewmat_dev, projmat_dev, N, nb, means, scales, quats, \
                                             opacities, cam_pos, radii, rgb_raw, records, v_means,     \
                                             v_scales, v_quats, v_opacity, v_dc, v_rest, v_xy, flags, s)
-    switch (K) {
+    switch (emit ? 1 : K) {   // (the K = 1 instantiation has no SH rows to move)
     case 1: GS_BWD(1);
     case 4: GS_BWD(4);
     case 9: GS_BWD(9);
@@ -407,4 +504,30 @@ extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_de
     default: GS_BWD(25);
     }
 #undef GS_BWD
+}
+
+extern "C" int gs_sh_backward_cameras(int N, int K, int degrees_to_use, int n_cams, const float *means,
+                                      const float *cam_pos_dev, int cam_pos_stride,
+                                      const float *v_colors, size_t v_colors_stride, float *v_dc,
+                                      float *v_rest, uint32_t flags, gs_stream_t stream) {
+    const int deg = gs::deg_from_bases(K);
+    if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg || n_cams < 0)
+        return GS_ERR_INVALID_ARGUMENT;
+    if (N == 0) return GS_OK;
+    if (!means || (n_cams > 0 && (!cam_pos_dev || !v_colors)) || !v_dc || (K > 1 && !v_rest))
+        return GS_ERR_INVALID_ARGUMENT;
+    if (cam_pos_stride < 3 || v_colors_stride < (size_t)N * 3) return GS_ERR_INVALID_ARGUMENT;
+    const int nb = gs::num_bases(degrees_to_use);
+    hipStream_t s = (hipStream_t)stream;
+#define GS_SHC(KK)                                                                                   \
+    return gs::launch_sh_backward_cameras<KK>(N, nb, n_cams, means, cam_pos_dev, cam_pos_stride,     \
+                                              v_colors, v_colors_stride, v_dc, v_rest, flags, s)
+    switch (K) {
+    case 1: GS_SHC(1);
+    case 4: GS_SHC(4);
+    case 9: GS_SHC(9);
+    case 16: GS_SHC(16);
+    default: GS_SHC(25);
+    }
+#undef GS_SHC
 }

@@ -132,3 +132,70 @@ def wait_all(*works) -> None:
 def allreduce_grads(buf: GradBuffer) -> None:
     """Blocking convenience: both collectives, then wait."""
     wait_all(allreduce_sh_async(buf), allreduce_rest_async(buf))
+
+
+class FactoredExchange:
+    """The gradient exchange of the camera-per-rank path with the SH block factored.
+
+    The SH gradient of ONE camera is an outer product: v_sh[n][b][ch] = basis_b(dir(n, camera)) *
+    v_colour[n][ch] — the basis depends on the Gaussian's mean and the camera centre only, which every
+    rank has.  So instead of all-reducing 12 K bytes of SH gradients per Gaussian (192 of the 236 B at
+    K = 16) the ranks ALL-GATHER the 12-byte colour cotangents (plus the camera centres, in the same
+    message) and each forms sum_c basis(dir_c) (x) v_colour_c locally (gs_sh_backward_cameras, cameras
+    in rank order: bit-identical on every rank).  Only the geometry block (means, scales, quats,
+    opacity: 44 B per Gaussian) is all-reduced.  Bytes a rank moves over xGMI at K = 16, 1 M
+    Gaussians, world W: flat all-reduce 2 (W-1)/W x 236 MB; factored 2 (W-1)/W x 44 MB + (W-1) x 12 MB
+    — 56 instead of 236 MB at W = 2, 161 instead of 413 MB at W = 8.  With c cameras per rank the
+    all-gather grows to c x 12 MB per rank: the flat exchange wins once c x W exceeds ~32.
+
+    Layout of a rank's message: [ camera centres: 4 floats x c | v_colour: c x N x 3 floats ].
+    """
+
+    def __init__(self, N: int, K: int, cameras_per_rank: int, device):
+        self.N, self.K, self.cpr = N, K, int(cameras_per_rank)
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.multi else 1
+        self.rank = dist.get_rank() if self.multi else 0
+        self.hdr = 4 * self.cpr
+        self.chunk = self.hdr + self.cpr * N * 3
+        self.recv = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
+        # (a one-rank "exchange" runs in place: the rank's message is the gathered buffer)
+        self.send = torch.zeros(self.chunk, dtype=torch.float32, device=device) if self.multi else self.recv
+        self._works = ()
+
+    def v_color(self, j: int) -> torch.Tensor:
+        """[N, 3] view of the message where gs_gaussian_backward (GS_FLAG_EMIT_VCOLOR) puts local
+        camera j's colour cotangent."""
+        o = self.hdr + j * self.N * 3
+        return self.send[o:o + self.N * 3].view(self.N, 3)
+
+    def set_cam_pos(self, j: int, cam_pos: torch.Tensor) -> None:
+        self.send[4 * j:4 * j + 3].copy_(cam_pos.reshape(-1)[:3])
+
+    @property
+    def bytes_moved_per_rank(self) -> int:
+        """xGMI bytes a rank sends (= receives) per exchange: ring all-reduce of the geometry block +
+        all-gather of the messages."""
+        w = self.world
+        return int(2 * (w - 1) / w * 11 * self.N * 4 + (w - 1) * self.chunk * 4) if w > 1 else 0
+
+    def start(self, grads: GradBuffer):
+        """Enqueue both collectives (after the last local camera's backward)."""
+        if not self.multi:
+            self._works = ()
+            return
+        w1 = dist.all_reduce(grads.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
+        w2 = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+        self._works = (w1, w2)
+
+    def finish(self, grads: GradBuffer, means: torch.Tensor, degrees_to_use: int) -> None:
+        """Wait for the collectives, then form the SH gradients of all cameras into the flat buffer."""
+        from . import cabi
+
+        wait_all(*self._works)
+        self._works = ()
+        for j in range(self.cpr):
+            cabi.sh_backward_cameras(
+                self.K, degrees_to_use, means, self.recv[4 * j:], self.recv[self.hdr + j * self.N * 3:],
+                grads.v_dc, grads.v_rest, cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0,
+                cam_pos_stride=self.chunk, v_colors_stride=self.chunk, n_cams=self.world)

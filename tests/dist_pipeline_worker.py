@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_dist_pipeline.py (not a test module): one rank of a 2-rank job.  Renders
 C4-style camera `rank` over the shared Gaussians through bench.Pipeline (the timed path, incl. the
-flat-buffer all-reduce), then stores the all-reduced gradient buffer.
+gradient exchange — flat all-reduce or the factored one), then stores the exchanged gradient buffer.
 
     python -m torch.distributed.run --nproc-per-node 2 ... tests/dist_pipeline_worker.py OUT_PREFIX
 """
@@ -30,9 +30,17 @@ def main():
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     flags = int(os.environ.get("GSPLAT_TEST_FLAGS", "0"))
-    pipe = bench.Pipeline(small_c4(rank), dev, flags)
-    pipe.step()
-    pipe.step()
+    # GSPLAT_TEST_EXCHANGE: "flat" (one all-reduce of the whole buffer) or "factored" (geometry
+    # all-reduce + colour-cotangent all-gather + local SH backward); GSPLAT_TEST_CPR cameras per rank
+    factored = os.environ.get("GSPLAT_TEST_EXCHANGE", "flat") == "factored"
+    cpr = int(os.environ.get("GSPLAT_TEST_CPR", "1"))
+    pipe = bench.Pipeline(small_c4(rank * cpr), dev, flags, factored=factored, cameras_per_rank=cpr)
+    for _ in range(2):
+        for j in range(cpr):
+            if cpr > 1:
+                sc = small_c4(rank * cpr + j)
+                pipe.set_camera(sc.viewmat, sc.projmat)
+            pipe.step(accumulate=j > 0, exchange=j == cpr - 1, slot=j)
     torch.cuda.synchronize()
     np.save(sys.argv[1] + "_rank%d.npy" % rank, pipe.grads.flat.cpu().numpy())
     if world > 1:

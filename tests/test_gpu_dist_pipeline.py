@@ -1,8 +1,9 @@
 """-m gpu: the multi-rank path THROUGH THE REAL PIPELINE.  Two ranks (gloo, sharing the one GPU of
 the test box) render two different C4-style cameras over the same Gaussians with bench.Pipeline —
-gs_gaussian_forward ... gs_gaussian_backward writing into the flat GradBuffer, then the flat-buffer
-all-reduce — and the all-reduced buffer must equal the sum of two single-rank runs of the same
-cameras.  Also: `python bench.py --gpus 2` starts its own ranks and reports n_gpus = 2."""
+gs_gaussian_forward ... gs_gaussian_backward writing into the flat GradBuffer, then the gradient
+exchange (flat all-reduce, or the factored exchange: geometry all-reduce + colour-cotangent
+all-gather + local SH backward over all cameras) — and the exchanged buffer must equal the sum of
+single-rank runs of the same cameras.  Also: `python bench.py --gpus 2` starts its own ranks and reports n_gpus = 2."""
 import json
 import os
 import subprocess
@@ -23,7 +24,8 @@ def _clean_env(**kw):
     return env
 
 
-def test_two_ranks_allreduced_gradients_equal_the_sum_of_single_rank_runs(tmp_path):
+@pytest.mark.parametrize("mode,cpr", [("flat", 1), ("factored", 1), ("factored", 2)])
+def test_two_ranks_allreduced_gradients_equal_the_sum_of_single_rank_runs(tmp_path, mode, cpr):
     import socket
 
     import torch
@@ -38,21 +40,22 @@ def test_two_ranks_allreduced_gradients_equal_the_sum_of_single_rank_runs(tmp_pa
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(ROOT, "tests", "dist_pipeline_worker.py"), prefix],
-                       env=_clean_env(GSPLAT_DIST_BACKEND="gloo"), capture_output=True, text=True,
-                       timeout=600)
+                       env=_clean_env(GSPLAT_DIST_BACKEND="gloo", GSPLAT_TEST_EXCHANGE=mode,
+                                      GSPLAT_TEST_CPR=str(cpr)),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got0, got1 = np.load(prefix + "_rank0.npy"), np.load(prefix + "_rank1.npy")
-    assert np.array_equal(got0, got1), "ranks disagree after the all-reduce"
-    # single-rank runs of the same two cameras in THIS process (world = 1: no exchange)
+    assert np.array_equal(got0, got1), "ranks disagree after the exchange"
+    # single-rank runs of the same cameras in THIS process (world = 1: no exchange)
     dev = torch.device("cuda", 0)
     flats = []
-    for cam in (0, 1):
+    for cam in range(2 * cpr):
         pipe = bench.Pipeline(small_c4(cam), dev, 0)
         pipe.step()
         pipe.step()
         torch.cuda.synchronize()
         flats.append(pipe.grads.flat.cpu().numpy().astype(np.float64))
-    want = flats[0] + flats[1]
+    want = sum(flats)
     assert np.abs(want).max() > 0
     # every block of the flat buffer (the six gradient tensors), relative to its own magnitude:
     # the compositing backward sums with atomics, so two runs differ by summation order (2e-5)
@@ -74,8 +77,22 @@ def test_bench_gpus_2_starts_two_ranks_and_reports_them():
     assert r.returncode == 0, r.stderr[-3000:]
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
     assert line["n_gpus"] == 2 and line["config"]["cameras_per_rank_per_step"] == 2
-    assert line["grad_bytes_allreduced"] == 100000 * (3 * 16 + 11) * 4
+    # default exchange at 2 ranks x 2 cameras: factored (geometry all-reduced, colours all-gathered)
+    assert line["exchange"]["mode"] == "factored"
+    assert line["grad_bytes_allreduced"] == 100000 * 11 * 4
+    assert line["exchange"]["allgather_message_bytes"] == (2 * 100000 * 3 + 8) * 4
     assert line["value"] > 0 and line["stage_ms"]["allreduce"] >= 0
+
+
+def test_bench_flat_exchange_is_still_selectable():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--gaussians", "50000", "--exchange", "flat"],
+                       env=_clean_env(GSPLAT_DIST_BACKEND="gloo"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    assert line["exchange"]["mode"] == "flat"
+    assert line["grad_bytes_allreduced"] == 50000 * (3 * 16 + 11) * 4
 
 
 def test_gradient_accumulation_over_a_rank_s_camera_batch():

@@ -224,3 +224,49 @@ def test_gaussian_forward_backward_equal_the_stage_kernels(K, deg, N):
     assert torch.equal(out2["v_opacity"], gr["v_opacity"])
     if K > 1:
         assert torch.equal(out2["v_rest"][:, :K - 1], v_rest)
+
+
+@pytest.mark.parametrize("K,deg", [(16, 3), (16, 2), (4, 1), (1, 0)])
+def test_sh_backward_cameras_equals_the_sum_of_per_camera_sh_gradients(K, deg):
+    """gs_sh_backward_cameras (the factored gradient exchange): SH gradients formed from the colour
+    cotangents of several cameras == the per-camera SH gradients of gs_sh_backward_fused, summed;
+    rows whose cotangent is zero for a camera contribute nothing."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    rs = np.random.RandomState(11)
+    N, C = 3001, 3
+    means = rs.uniform(-2, 2, (N, 3)).astype(np.float32)
+    cams = rs.uniform(-6, 6, (C, 3)).astype(np.float32)
+    vcol = rs.normal(size=(C, N, 3)).astype(np.float32)
+    vcol[1, ::3] = 0.0           # unseen from camera 1
+    rgb_raw = np.ones((N, 3), np.float32)   # nothing clamped: the mask was applied by the sender
+    dm, dv = to_dev(means), to_dev(vcol)
+    want_dc = np.zeros((N, 3), np.float64)
+    want_rest = np.zeros((N, max(K - 1, 0), 3), np.float64)
+    for c in range(C):
+        v_dc = torch.empty((N, 3), device="cuda")
+        v_rest = torch.empty((N, max(K - 1, 1), 3), device="cuda")
+        cabi.sh_backward_fused(deg, K, dm, to_dev(cams[c]), to_dev(rgb_raw), dv[c].contiguous(),
+                               out=(v_dc, v_rest))
+        want_dc += np_(v_dc)
+        if K > 1:
+            want_rest += np_(v_rest)
+    # camera centres 4 floats apart, cotangents with a padded stride (as in the all-gather message)
+    cp = torch.zeros((C, 4), device="cuda")
+    cp[:, :3] = to_dev(cams)
+    stride = N * 3 + 8
+    flat = torch.zeros(C * stride, device="cuda")
+    for c in range(C):
+        flat[c * stride:c * stride + N * 3] = dv[c].reshape(-1)
+    got_dc = torch.full((N, 3), 7.0, device="cuda")
+    got_rest = torch.full((N, max(K - 1, 1), 3), 7.0, device="cuda")
+    cabi.sh_backward_cameras(K, deg, dm, cp, flat, got_dc, got_rest, v_colors_stride=stride)
+    assert np.abs(np_(got_dc) - want_dc).max() <= 2e-6 * np.abs(want_dc).max()
+    if K > 1:
+        assert np.abs(np_(got_rest) - want_rest).max() <= 2e-6 * max(np.abs(want_rest).max(), 1e-30)
+    # accumulate on top
+    cabi.sh_backward_cameras(K, deg, dm, cp, flat, got_dc, got_rest, cabi.GS_FLAG_ACCUMULATE_GRADS,
+                             v_colors_stride=stride)
+    assert np.abs(np_(got_dc) - 2 * want_dc).max() <= 4e-6 * np.abs(want_dc).max()
