@@ -2,8 +2,8 @@
  *
  * SURVEY.md §8e / DESIGN.md §7: one camera per rank, replicated Gaussians, a sum all-reduce of the
  * flat gradient buffer [v_features_rest | v_features_dc | v_means | v_scales | v_quats | v_opacity]
- * after backward.  OpenSplat is a C++ program without any distributed code; a
- * Model-level caller gets the exchange through these five functions — RCCL over xGMI underneath,
+ * after backward — or its factored form, gs_dist_allgather below.  OpenSplat is a C++ program without
+ * any distributed code; a Model-level caller gets the exchange through these functions — RCCL over xGMI underneath,
  * enqueued on the caller's HIP stream (the one the operators of gsplat_hip.h were given), no torch
  * type in sight.  The Python harness (opensplat_amd/dist.py) uses torch.distributed instead, whose
  * "nccl" backend is the same RCCL.
@@ -44,6 +44,18 @@ int gs_dist_allreduce_sum(GsDistComm *comm, float *buf, size_t count, gs_stream_
  * void*), event k recorded on `stream` behind bucket k. */
 int gs_dist_allreduce_sum_buckets(GsDistComm *comm, float *buf, size_t count, int n_buckets,
                                   void **done_events, gs_stream_t stream);
+
+/* All-gather: every rank contributes send[0 .. count) and receives the world_size messages in rank
+ * order in recv[0 .. world_size * count); send may be the rank's own slot of recv (in place).
+ * The factored exchange moves the colour cotangents this way — 12 B per Gaussian and
+ * camera instead of all-reducing the 12 K bytes of SH gradients they imply:
+ *     gs_gaussian_backward(..., GS_FLAG_EMIT_VCOLOR)          // v_colour into the rank's message
+ *     gs_dist_allreduce_sum(comm, geometry block, 11 N, s);   // means, scales, quats, opacity
+ *     gs_dist_allgather(comm, message, gathered, count, s);   // [camera centre 4 | v_colour 3 N]
+ *     gs_sh_backward_cameras(N, K, deg, world, means, gathered, count, gathered + 4, count, ...)
+ * world_size 1: a device copy (nothing if send == recv). */
+int gs_dist_allgather(GsDistComm *comm, const float *send, float *recv, size_t count,
+                      gs_stream_t stream);
 
 int gs_dist_world_size(const GsDistComm *comm);
 int gs_dist_rank(const GsDistComm *comm);

@@ -82,7 +82,7 @@ def lib() -> C.CDLL:
 
 # every symbol include/gsplat_dist.h declares (libgsplat_dist.so: the gradient exchange on RCCL)
 DIST_SYMBOLS = ["gs_dist_unique_id", "gs_dist_init", "gs_dist_allreduce_sum", "gs_dist_allreduce_sum_buckets",
-                "gs_dist_world_size", "gs_dist_rank", "gs_dist_destroy", "gs_dist_last_error"]
+                "gs_dist_allgather", "gs_dist_world_size", "gs_dist_rank", "gs_dist_destroy", "gs_dist_last_error"]
 _dist_lib = None
 
 
@@ -97,6 +97,7 @@ def dist_lib() -> C.CDLL:
         l.gs_dist_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.gs_dist_allreduce_sum_buckets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                                     C.c_void_p]
+        l.gs_dist_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _dist_lib = l
     return _dist_lib
 

@@ -92,6 +92,21 @@ extern "C" int gs_dist_allreduce_sum_buckets(GsDistComm *comm, float *buf, size_
     return GS_OK;
 }
 
+extern "C" int gs_dist_allgather(GsDistComm *comm, const float *send, float *recv, size_t count,
+                                 gs_stream_t stream) {
+    if (!comm || ((!send || !recv) && count)) return GS_ERR_INVALID_ARGUMENT;
+    if (count == 0) return GS_OK;
+    if (comm->world == 1) {
+        if (send == recv) return GS_OK;
+        const hipError_t e = hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice,
+                                            (hipStream_t)stream);
+        return e == hipSuccess ? GS_OK : fail_hip(e, "hipMemcpyAsync");
+    }
+    const ncclResult_t r = ncclAllGather(send, recv, count, ncclFloat32, comm->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return fail_nccl(r, "ncclAllGather");
+    return GS_OK;
+}
+
 extern "C" int gs_dist_world_size(const GsDistComm *comm) { return comm ? comm->world : 0; }
 extern "C" int gs_dist_rank(const GsDistComm *comm) { return comm ? comm->rank : -1; }
 

@@ -181,6 +181,14 @@ public:
     void allReduce(torch::Tensor flat);
     // as nBuckets collectives; returns nothing to wait for: consumers are ordered by the stream
     void allReduceBuckets(torch::Tensor flat, int nBuckets);
+    // every rank's `message` (contiguous float32) into `gathered` [worldSize * message.numel()], rank order
+    void allGather(torch::Tensor message, torch::Tensor gathered);
+    // The factored exchange (include/gsplat_dist.h): `geometry` = the [v_means | v_scales | v_quats |
+    // v_opacity] gradients as one contiguous buffer (summed in place over the ranks); `message` =
+    // [camera centre, 4 floats | v_colour N x 3] as gs_gaussian_backward wrote it under
+    // GS_FLAG_EMIT_VCOLOR; v_dc / v_rest receive the SH gradients of ALL ranks' cameras.
+    void exchangeFactored(torch::Tensor geometry, torch::Tensor message, torch::Tensor gathered,
+                          torch::Tensor means, int degreesToUse, torch::Tensor v_dc, torch::Tensor v_rest);
     int worldSize() const;
     int rank() const;
 

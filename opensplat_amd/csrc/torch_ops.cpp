@@ -831,16 +831,66 @@ void GradExchange::allReduceBuckets(Tensor flat, int nBuckets) {
                                              (size_t)flat.numel(), nBuckets, nullptr, current_stream()),
                "gs_dist_allreduce_sum_buckets");
 }
-// self-test op: a one-rank communicator through the whole C++ / C-ABI / RCCL stack
+void GradExchange::allGather(Tensor message, Tensor gathered) {
+    GS_CHECK_DEV(message);
+    GS_CHECK_DEV(gathered);
+    GS_CHECK_F32(message);
+    GS_CHECK_F32(gathered);
+    TORCH_CHECK(message.is_contiguous() && gathered.is_contiguous(), "GradExchange: contiguous buffers required");
+    TORCH_CHECK(gathered.numel() == message.numel() * (int64_t)worldSize(),
+                "GradExchange::allGather: gathered must hold worldSize messages");
+    c10::DeviceGuard guard(message.device());
+    check_dist(gs_dist_allgather(static_cast<GsDistComm *>(comm_), message.data_ptr<float>(),
+                                 gathered.data_ptr<float>(), (size_t)message.numel(), current_stream()),
+               "gs_dist_allgather");
+}
+void GradExchange::exchangeFactored(Tensor geometry, Tensor message, Tensor gathered, Tensor means,
+                                    int degreesToUse, Tensor v_dc, Tensor v_rest) {
+    GS_CHECK_DEV(means);
+    GS_CHECK_F32(means);
+    GS_CHECK_DEV(v_dc);
+    GS_CHECK_F32(v_dc);
+    TORCH_CHECK(means.is_contiguous() && v_dc.is_contiguous(), "GradExchange: contiguous tensors required");
+    const int64_t N = means.size(0);
+    TORCH_CHECK(message.numel() == 4 + 3 * N, "GradExchange: message is [camera centre 4 | v_colour N x 3]");
+    const int K = v_rest.defined() && v_rest.numel() > 0 ? (int)v_rest.size(1) + 1 : 1;
+    if (K > 1) {
+        GS_CHECK_DEV(v_rest);
+        GS_CHECK_F32(v_rest);
+        TORCH_CHECK(v_rest.is_contiguous() && v_rest.size(0) == N && v_rest.size(2) == 3, "v_rest must be [N, K-1, 3]");
+    }
+    allReduce(geometry);
+    allGather(message, gathered);
+    c10::DeviceGuard guard(means.device());
+    const int rc = gs_sh_backward_cameras((int)N, K, degreesToUse, worldSize(), means.data_ptr<float>(),
+                                          gathered.data_ptr<float>(), (int)message.numel(),
+                                          gathered.data_ptr<float>() + 4, (size_t)message.numel(),
+                                          v_dc.data_ptr<float>(), K > 1 ? v_rest.data_ptr<float>() : nullptr,
+                                          0u, current_stream());
+    TORCH_CHECK(rc == GS_OK, "gs_sh_backward_cameras failed: ", gs_strerror(rc), " — ", gs_last_hip_error());
+}
+// self-test ops: a one-rank communicator through the whole C++ / C-ABI / RCCL stack
 static Tensor op_grad_exchange_selftest(Tensor flat, int64_t buckets) {
     GradExchange ex(1, 0, GradExchange::uniqueId(), flat.device().index());
     if (buckets > 1) ex.allReduceBuckets(flat, (int)buckets); else ex.allReduce(flat);
     TORCH_CHECK(ex.worldSize() == 1 && ex.rank() == 0);
     return flat;
 }
+static std::vector<Tensor> op_grad_exchange_factored_selftest(Tensor geometry, Tensor message, Tensor means,
+                                                              int64_t K, int64_t degrees_to_use) {
+    GradExchange ex(1, 0, GradExchange::uniqueId(), means.device().index());
+    const int64_t N = means.size(0);
+    Tensor gathered = torch::empty_like(message);
+    Tensor v_dc = torch::empty({N, 3}, means.options());
+    Tensor v_rest = torch::empty({N, K - 1, 3}, means.options());
+    ex.exchangeFactored(geometry, message, gathered, means, (int)degrees_to_use, v_dc, v_rest);
+    return {v_dc, v_rest, gathered};
+}
 
 TORCH_LIBRARY(opensplat_amd, m) {
     m.def("grad_exchange_selftest(Tensor(a!) flat, int buckets) -> Tensor(a!)", &op_grad_exchange_selftest);
+    m.def("grad_exchange_factored_selftest(Tensor(a!) geometry, Tensor message, Tensor means, int K, "
+          "int degrees_to_use) -> Tensor[]", &op_grad_exchange_factored_selftest);
     m.def("project_gaussians(Tensor means, Tensor scales, float glob_scale, Tensor quats, "
           "Tensor viewmat, Tensor projmat, float fx, float fy, float cx, float cy, int img_height, "
           "int img_width, float clip_thresh=0.01) -> Tensor[]",

@@ -161,7 +161,7 @@ class FactoredExchange:
         self.recv = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
         # (a one-rank "exchange" runs in place: the rank's message is the gathered buffer)
         self.send = torch.zeros(self.chunk, dtype=torch.float32, device=device) if self.multi else self.recv
-        self._works = ()
+        self._w_gather = self._w_geo = None
 
     def v_color(self, j: int) -> torch.Tensor:
         """[N, 3] view of the message where gs_gaussian_backward (GS_FLAG_EMIT_VCOLOR) puts local
@@ -180,22 +180,31 @@ class FactoredExchange:
         return int(2 * (w - 1) / w * 11 * self.N * 4 + (w - 1) * self.chunk * 4) if w > 1 else 0
 
     def start(self, grads: GradBuffer):
-        """Enqueue both collectives (after the last local camera's backward)."""
+        """Enqueue both collectives (after the last local camera's backward): the all-gather first —
+        its consumer, the SH backward over all cameras plus the Adam step of 48 of the 59 parameters
+        per Gaussian, then overlaps the geometry all-reduce."""
+        self._w_gather = self._w_geo = None
         if not self.multi:
-            self._works = ()
             return
-        w1 = dist.all_reduce(grads.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
-        w2 = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
-        self._works = (w1, w2)
+        self._w_gather = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+        self._w_geo = dist.all_reduce(grads.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
 
-    def finish(self, grads: GradBuffer, means: torch.Tensor, degrees_to_use: int) -> None:
-        """Wait for the collectives, then form the SH gradients of all cameras into the flat buffer."""
+    def finish_sh(self, grads: GradBuffer, means: torch.Tensor, degrees_to_use: int) -> None:
+        """Wait for the all-gather, then form the SH gradients of ALL cameras into the flat buffer."""
         from . import cabi
 
-        wait_all(*self._works)
-        self._works = ()
+        wait_all(self._w_gather)
+        self._w_gather = None
         for j in range(self.cpr):
             cabi.sh_backward_cameras(
                 self.K, degrees_to_use, means, self.recv[4 * j:], self.recv[self.hdr + j * self.N * 3:],
                 grads.v_dc, grads.v_rest, cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0,
                 cam_pos_stride=self.chunk, v_colors_stride=self.chunk, n_cams=self.world)
+
+    def finish_geometry(self) -> None:
+        wait_all(self._w_geo)
+        self._w_geo = None
+
+    def finish(self, grads: GradBuffer, means: torch.Tensor, degrees_to_use: int) -> None:
+        self.finish_sh(grads, means, degrees_to_use)
+        self.finish_geometry()

@@ -72,7 +72,7 @@ class Trainer:
                  stop_screen_size_at: int = 4000, split_screen_size: float = 0.05,
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
-                 reference_alpha_reset: bool = False, grad_buckets: int = 4):
+                 reference_alpha_reset: bool = False, grad_buckets: int = 4, exchange: str = "auto"):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -124,6 +124,12 @@ class Trainer:
         self.world = torch.distributed.get_world_size() if (
             torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        # "factored" (default with several ranks): all-gather the 12-byte colour cotangents and form the
+        # SH gradients of all cameras locally, all-reduce the geometry block only; "flat": the whole
+        # gradient buffer through bucketed all-reduces (dist.FactoredExchange)
+        assert exchange in ("auto", "flat", "factored")
+        self.factored = exchange == "factored" or (exchange == "auto" and 1 < self.world <= 32)
+        self.fx = None
 
     def degrees_to_use(self, step: int) -> int:
         """model.cpp:178: one more SH degree every sh_degree_interval steps."""
@@ -199,11 +205,27 @@ class Trainer:
         keep = cabi.GS_FLAG_KEEP_RECORDS
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
                                 flags | keep, workspace=self.bwd_ws, img_raw=f["img"])
+        if self.factored:
+            if self.fx is None or self.fx.N != self.N:      # (a refinement changes N)
+                self.fx = dist.FactoredExchange(self.N, self.K, 1, self.dev)
+            fx = self.fx
+            fx.set_cam_pos(0, torch.from_numpy(np.ascontiguousarray(cam_pos, dtype=np.float32)).to(self.dev))
+            cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
+                                   cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws,
+                                   dict(self.gout, v_dc=fx.v_color(0), v_rest=None),
+                                   flags | cabi.GS_FLAG_EMIT_VCOLOR, v_xy=self.v_xy)
+            fx.start(self.grads)
+            sh = self.grads.sh_numel
+            # (lo, hi, wait-and-prepare): the SH block first — its Adam step overlaps the geometry all-reduce
+            self._pending = [(0, sh, lambda: fx.finish_sh(self.grads, self.means, deg)),
+                             (sh, self.grads.flat.numel(), fx.finish_geometry)]
+            return
         cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
                                cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws, self.gout, flags,
                                v_xy=self.v_xy)
         # start the exchange; optimizer_step() consumes it bucket by bucket
-        self._pending = dist.allreduce_buckets_async(self.grads, self.grad_buckets) \
+        self._pending = [(lo, hi, (lambda w=w: dist.wait_all(w)))
+                         for lo, hi, w in dist.allreduce_buckets_async(self.grads, self.grad_buckets)] \
             if (self.world > 1 or self.bucket_single_rank) else None
 
     def adam_groups(self, lo: int = 0, hi: int | None = None):
@@ -229,8 +251,8 @@ class Trainer:
         if self._pending is None:
             cabi.adam_step(self.adam_groups(), self.step_count)
         else:
-            for lo, hi, work in self._pending:      # Adam of bucket k overlaps the transfer of k + 1
-                dist.wait_all(work)
+            for lo, hi, ready in self._pending:     # Adam of bucket k overlaps the transfer of k + 1
+                ready()
                 groups = self.adam_groups(lo, hi)
                 if groups:
                     cabi.adam_step(groups, self.step_count)

@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: the multi-GPU exchange step (flat gradient buffer, SH block first,
 two async all-reduces) — the same code bench.py runs over RCCL."""
 import os
+
+import numpy as np
 import socket
 
 import torch
@@ -128,3 +130,56 @@ def test_bucket_bounds_tile_the_buffer():
         assert b[0][0] == 0 and b[-1][1] == numel and len(b) <= nb
         assert all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(lo < hi for lo, hi in b)
         assert all(lo % 1024 == 0 for lo, _ in b)
+
+
+def _fx_worker(rank, world, port, N, K, cpr, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+
+    from opensplat_amd import dist as gdist
+
+    gdist.init_from_env("gloo")
+    dev = torch.device("cpu")
+    grads = gdist.GradBuffer(N, K, dev)
+    grads.flat.copy_(torch.arange(grads.flat.numel(), dtype=torch.float32) * (rank + 1))
+    fx = gdist.FactoredExchange(N, K, cpr, dev)
+    for j in range(cpr):
+        fx.set_cam_pos(j, torch.tensor([rank, j, 7.0]))
+        fx.v_color(j).fill_(10.0 * rank + j)
+    fx.start(grads)
+    gdist.wait_all(fx._w_gather)      # (finish_sh would launch the HIP kernel: GPU test)
+    fx.finish_geometry()
+    q.put((rank, grads.flat.numpy().copy(), fx.recv.numpy().copy(), fx.bytes_moved_per_rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_factored_exchange_messages_world2():
+    """dist.FactoredExchange on two gloo ranks: the geometry block is summed, the SH block is left
+    alone, and both ranks hold both messages [camera centres | colour cotangents] in rank order."""
+    N, K, world, cpr = 37, 16, 2, 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fx_worker, args=(r, world, port, N, K, cpr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, (f, m, b)) for r, f, m, b in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    total = N * (3 * K + 11)
+    sh = N * 3 * K
+    base = np.arange(total, dtype=np.float32)
+    for rank in range(world):
+        flat, msg, moved = got[rank]
+        assert np.array_equal(flat[:sh], base[:sh] * (rank + 1))          # SH block: not exchanged
+        assert np.array_equal(flat[sh:], base[sh:] * 3)                   # geometry: summed (1 + 2)
+        chunk = 4 * cpr + cpr * N * 3
+        assert msg.size == world * chunk
+        for r in range(world):
+            m = msg[r * chunk:(r + 1) * chunk]
+            for j in range(cpr):
+                assert list(m[4 * j:4 * j + 3]) == [r, j, 7.0]
+                assert np.all(m[4 * cpr + j * N * 3:4 * cpr + (j + 1) * N * 3] == 10.0 * r + j)
+        assert moved == int(2 * 0.5 * 11 * N * 4 + chunk * 4)

@@ -37,6 +37,13 @@ def test_one_rank_communicator_through_the_c_abi():
     torch.cuda.synchronize()
     assert torch.equal(x, ref)                      # sum over one rank
     assert l.gs_dist_allreduce_sum_buckets(comm, C.c_void_p(x.data_ptr()), x.numel(), 0, None, s) == -1
+    # all-gather over one rank: a device copy (or nothing in place)
+    y = torch.zeros_like(x)
+    assert l.gs_dist_allgather(comm, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), x.numel(), s) == 0
+    assert l.gs_dist_allgather(comm, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), x.numel(), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and torch.equal(x, ref)
+    assert l.gs_dist_allgather(comm, None, C.c_void_p(y.data_ptr()), 4, s) == -1
     assert l.gs_dist_destroy(comm) == 0
 
 
@@ -53,3 +60,29 @@ def test_grad_exchange_class_of_the_libtorch_surface():
     assert torch.equal(y, ref) and torch.equal(z, ref)
     with pytest.raises(RuntimeError):
         torch.ops.opensplat_amd.grad_exchange_selftest(torch.zeros(8), 1)      # CPU tensor
+
+
+def test_factored_exchange_of_the_libtorch_surface():
+    """GradExchange::exchangeFactored on a one-rank communicator: geometry all-reduce (identity),
+    message all-gather (copy) and gs_sh_backward_cameras == the SH backward of the one camera."""
+    import torch
+
+    from opensplat_amd import cabi, ops  # noqa: F401
+    from tests.util import np_, to_dev
+
+    rs = np.random.RandomState(5)
+    N, K, deg = 2500, 16, 3
+    means = to_dev(rs.uniform(-2, 2, (N, 3)).astype(np.float32))
+    cam = rs.uniform(-5, 5, 3).astype(np.float32)
+    vcol = to_dev(rs.normal(size=(N, 3)).astype(np.float32))
+    geometry = torch.randn(11 * N, device="cuda")
+    gref = geometry.clone()
+    message = torch.zeros(4 + 3 * N, device="cuda")
+    message[:3] = to_dev(cam)
+    message[4:] = vcol.reshape(-1)
+    v_dc, v_rest, gathered = torch.ops.opensplat_amd.grad_exchange_factored_selftest(geometry, message, means, K, deg)
+    want_dc, want_rest = cabi.sh_backward_fused(deg, K, means, to_dev(cam), torch.ones((N, 3), device="cuda"), vcol)
+    torch.cuda.synchronize()
+    assert torch.equal(geometry, gref) and torch.equal(gathered, message)
+    assert np.abs(np_(v_dc) - np_(want_dc)).max() <= 1e-6 * np.abs(np_(want_dc)).max()
+    assert np.abs(np_(v_rest) - np_(want_rest)).max() <= 1e-6 * np.abs(np_(want_rest)).max()

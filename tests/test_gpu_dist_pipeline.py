@@ -128,3 +128,36 @@ def test_gradient_accumulation_over_a_rank_s_camera_batch():
         n = pipe.grads.views[name].numel()
         assert np.abs(got[o:o + n] - want[o:o + n]).max() <= 2e-5 * np.abs(want[o:o + n]).max(), name
         o += n
+
+
+def test_two_rank_training_flat_and_factored_exchange_agree(tmp_path):
+    """opensplat_amd.train.Trainer with one camera per rank: the exchanged gradients of the factored
+    exchange (default) equal those of the flat bucketed all-reduce, both ranks end every iteration
+    with identical parameters."""
+    import socket
+
+    out = {}
+    for mode in ("flat", "factored"):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        prefix = str(tmp_path / mode)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join(ROOT, "tests", "dist_train_worker.py"), prefix],
+                           env=_clean_env(GSPLAT_DIST_BACKEND="gloo", GSPLAT_TEST_EXCHANGE=mode),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        g0, g1 = np.load(prefix + "_grads_rank0.npy"), np.load(prefix + "_grads_rank1.npy")
+        p0, p1 = np.load(prefix + "_params_rank0.npy"), np.load(prefix + "_params_rank1.npy")
+        assert np.array_equal(g0, g1) and np.array_equal(p0, p1), mode
+        assert np.isfinite(p0).all() and np.abs(g0).max() > 0
+        out[mode] = g0.astype(np.float64)
+    N, K = 6000, 16
+    o = 0
+    for name, n in (("v_rest", N * (K - 1) * 3), ("v_dc", N * 3), ("v_means", N * 3), ("v_scales", N * 3),
+                    ("v_quats", N * 4), ("v_opacity", N)):
+        a, b = out["factored"][o:o + n], out["flat"][o:o + n]
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), name
+        o += n
+    assert o == out["flat"].size

@@ -351,7 +351,8 @@ def test_bucketed_adam_equals_the_single_launch():
         gen.manual_seed(5)
         for it in range(3):
             T.grads.flat.copy_(torch.randn(T.grads.flat.numel(), device="cuda", generator=gen) * 1e-3)
-            T._pending = gdist.allreduce_buckets_async(T.grads, T.grad_buckets) if buckets else None
+            T._pending = [(lo, hi, (lambda w=w: gdist.wait_all(w)))
+                          for lo, hi, w in gdist.allreduce_buckets_async(T.grads, T.grad_buckets)] if buckets else None
             T.optimizer_step()
         torch.cuda.synchronize()
         results.append((T.params.flat.clone(), T.exp_avg.flat.clone(), T.exp_avg_sq.flat.clone(), T.means_lr))
