@@ -7,6 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke_$TAG.log 2>&1; tail -1 $OUT/smoke_$TAG.log
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest_$TAG.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest_$TAG.log
 tail -14 $OUT/pytest_$TAG.log
@@ -19,13 +20,14 @@ timeout 300 $B --order morton > $OUT/bench_${TAG}_morton.json 2>> $OUT/bench_$TA
 timeout 300 $B --config c4-sequence --steps 48 --warmup 0 > $OUT/bench_${TAG}_c4seq_cold.json 2>> $OUT/bench_$TAG.err
 timeout 300 $B --config c4-sequence --steps 48 --warmup 8 > $OUT/bench_${TAG}_c4seq.json 2>> $OUT/bench_$TAG.err
 GSPLAT_DIST_BACKEND=gloo timeout 600 $B --gpus 2 --steps 10 --warmup 2 > $OUT/bench_${TAG}_gloo2.json 2>> $OUT/bench_$TAG.err
+GSPLAT_DIST_BACKEND=gloo timeout 600 $B --gpus 2 --steps 10 --warmup 2 --exchange flat > $OUT/bench_${TAG}_gloo2_flat.json 2>> $OUT/bench_$TAG.err
 GSPLAT_DIST_BACKEND=gloo timeout 600 $B --gpus 2 --steps 10 --warmup 2 --cameras-per-rank 4 > $OUT/bench_${TAG}_gloo2_c4.json 2>> $OUT/bench_$TAG.err
 for c in C2 C3; do
 GSPLAT_HIP_LIB=opensplat_amd/csrc/libgsplat_hip_stats.so timeout 300 python scripts/work_stats.py $c > $OUT/work_stats_${TAG}_$c.json 2>> $OUT/bench_$TAG.err
 done
 bash scripts/profile.sh $TAG > /dev/null 2>&1
 BENCH_ARGS="--config c3" bash scripts/profile.sh ${TAG}_c3 > /dev/null 2>&1
-for f in "" _c3 _fastexp _hot _morton _c4seq_cold _c4seq _gloo2 _gloo2_c4; do python - <<PY
+for f in "" _c3 _fastexp _hot _morton _c4seq_cold _c4seq _gloo2 _gloo2_flat _gloo2_c4; do python - <<PY
 import json
 try:
     d=json.loads(open("$OUT/bench_${TAG}$f.json").read().strip().splitlines()[-1])

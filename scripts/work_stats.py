@@ -2,7 +2,7 @@
 """Work counters of the compositing kernels on the bench scene (instrumented -DGS_STATS build).
 
   cd opensplat_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-      -ffp-contract=off -DGS_STATS gs_*.hip -o libgsplat_hip_stats.so
+      -ffp-contract=off -fno-slp-vectorize -DGS_STATS gs_*.hip -o libgsplat_hip_stats.so
   GSPLAT_HIP_LIB=opensplat_amd/csrc/libgsplat_hip_stats.so python scripts/work_stats.py
 """
 import ctypes as C
