@@ -143,14 +143,19 @@ k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__res
                uint32_t flags) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    load_device_matrices(cam, vm_dev, pm_dev);
+    // every input of the lane is requested before the first use: the projection's few hundred
+    // instructions then run on top of ONE memory round trip (the first version fetched the quaternion
+    // after the scales had arrived and the colour / opacity after the projection: three in a row)
     float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
+    const float c0 = rgb_raw[3 * g + 0], c1 = rgb_raw[3 * g + 1], c2 = rgb_raw[3 * g + 2];
+    const float opac = opacities[g];
+    load_device_matrices(cam, vm_dev, pm_dev);
     if (cam.flags & GS_CAM_LOG_SCALES) {
 #pragma unroll
         for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
     }
-    const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
     float quat[4] = {q4.x, q4.y, q4.z, q4.w};
     Proj o;
     project_one(cam, mean, scale, quat, o);
@@ -162,10 +167,9 @@ k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__res
         xys[2 * g + 0] = po.u;
         xys[2 * g + 1] = po.v;
     }
-    const float c0 = rgb_raw[3 * g + 0], c1 = rgb_raw[3 * g + 1], c2 = rgb_raw[3 * g + 2];
     float4 p0, p1, p2;
     pack_one(cam.W, cam.H, po.u, po.v, po.conic[0], po.conic[1], po.conic[2], true, o.a, o.c,
-             opacities[g], po.radius, fmaxf(c0 + 0.5f, 0.0f), fmaxf(c1 + 0.5f, 0.0f),
+             opac, po.radius, fmaxf(c0 + 0.5f, 0.0f), fmaxf(c1 + 0.5f, 0.0f),
              fmaxf(c2 + 0.5f, 0.0f), flags, p0, p1, p2);
     packed[3 * g + 0] = p0;
     packed[3 * g + 1] = p1;
@@ -197,9 +201,18 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
     const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
     if (lane < cnt) {
         const int64_t g = g0 + lane;
-        // ---- the gradient record of gs_rasterize_backward: {vx vy vA vB | vC vr vg vb | vo - - -}
+        // ---- every input of the lane is requested before the first use (one memory round trip under
+        //      the arithmetic instead of a chain of seven: record, opacity, mean, rgb, radius, mean /
+        //      scale, quaternion) ----
+        // the gradient record of gs_rasterize_backward: {vx vy vA vB | vC vr vg vb | vo - - -}
         const float4 ra = records[4 * g + 0], rb = records[4 * g + 1];
         float vo = reinterpret_cast<const float *>(records)[kRec * (size_t)g + 8];
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        const float raw0 = rgb_raw[3 * g + 0], raw1 = rgb_raw[3 * g + 1], raw2 = rgb_raw[3 * g + 2];
+        const int32_t radius = radii[g];
+        const float logit = opacities[g];
+        float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         if (flags & GS_FLAG_RECORDS_ZEROED) {  // keep the "records are zero between frames" invariant
             records[4 * g + 0] = zero;
@@ -207,7 +220,7 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
             records[4 * g + 2] = zero;
         }
         if (flags & GS_FLAG_LOGIT_OPACITY) {  // d sigmoid: s (1 - s), model.cpp:215
-            const float sg = 1.0f / (1.0f + expf(-opacities[g]));
+            const float sg = 1.0f / (1.0f + expf(-logit));
             vo *= sg * (1.0f - sg);
         }
         put(v_opacity + g, vo);
@@ -217,13 +230,15 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         }
 
         // ---- SH backward (gs_sh_backward_fused) ------------------------------------------------------
-        float x, y, z;
-        view_dir(means, g, cx, cy, cz, x, y, z);
+        // view_dir(): (mean - T) / ||mean - T||, model.cpp:176-177, on the values loaded above
+        float x = mean[0] - cx, y = mean[1] - cy, z = mean[2] - cz;
+        const float nrm = sqrtf(x * x + y * y + z * z);
+        x /= nrm; y /= nrm; z /= nrm;
         float r[25];
         sh_basis(nb, x, y, z, r);
-        const float v0 = (rgb_raw[3 * g + 0] + 0.5f >= 0.0f) ? rb.y : 0.0f;
-        const float v1 = (rgb_raw[3 * g + 1] + 0.5f >= 0.0f) ? rb.z : 0.0f;
-        const float v2 = (rgb_raw[3 * g + 2] + 0.5f >= 0.0f) ? rb.w : 0.0f;
+        const float v0 = (raw0 + 0.5f >= 0.0f) ? rb.y : 0.0f;
+        const float v1 = (raw1 + 0.5f >= 0.0f) ? rb.z : 0.0f;
+        const float v2 = (raw2 + 0.5f >= 0.0f) ? rb.w : 0.0f;
         if (flags & GS_FLAG_EMIT_VCOLOR) {
             // factored gradient exchange: hand out the colour cotangent behind the clamp mask itself
             // (never accumulated: every camera has its own view direction); the SH gradients are
@@ -246,20 +261,17 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
 
         // ---- projection backward (gs_project_backward) -----------------------------------------------
         float4_u *vq4 = reinterpret_cast<float4_u *>(v_quats);
-        if (radii[g] <= 0) {  // culled Gaussians get no gradient (backward.cu:380-382)
+        if (radius <= 0) {  // culled Gaussians get no gradient (backward.cu:380-382)
             if (!accum) {
                 v_means[3 * g] = v_means[3 * g + 1] = v_means[3 * g + 2] = 0.0f;
                 v_scales[3 * g] = v_scales[3 * g + 1] = v_scales[3 * g + 2] = 0.0f;
                 vq4[g] = (float4_u)(0.0f);
             }
         } else {
-            float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-            float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
             if (cam.flags & GS_CAM_LOG_SCALES) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) scale[j] = expf(scale[j]);
             }
-            const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
             float quat[4] = {q4.x, q4.y, q4.z, q4.w};
             Proj o;
             project_one(cam, mean, scale, quat, o);
@@ -327,13 +339,23 @@ k_sh_backward_cameras(int N, int nb, int n_cams, const float *__restrict__ means
         float acc[3 * K];
 #pragma unroll
         for (int i = 0; i < 3 * K; i++) acc[i] = 0.0f;
+        const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+        float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;   // the next camera's cotangent, requested one iteration ahead
+        if (n_cams > 0) {
+            const float *vc = v_colors + 3 * g;
+            n0 = vc[0]; n1 = vc[1]; n2 = vc[2];
+        }
         for (int c = 0; c < n_cams; c++) {
-            const float *vc = v_colors + (size_t)c * v_stride + 3 * g;
-            const float v0 = vc[0], v1 = vc[1], v2 = vc[2];
+            const float v0 = n0, v1 = n1, v2 = n2;
+            if (c + 1 < n_cams) {
+                const float *vc = v_colors + (size_t)(c + 1) * v_stride + 3 * g;
+                n0 = vc[0]; n1 = vc[1]; n2 = vc[2];
+            }
             if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f) continue;  // culled / unseen from camera c
             const float *cp = cam_pos + (size_t)c * cam_stride;
-            float x, y, z;
-            view_dir(means, g, cp[0], cp[1], cp[2], x, y, z);
+            float x = mx - cp[0], y = my - cp[1], z = mz - cp[2];   // view_dir()
+            const float nrm = sqrtf(x * x + y * y + z * z);
+            x /= nrm; y /= nrm; z /= nrm;
             float r[25];
             sh_basis(nb, x, y, z, r);
 #pragma unroll

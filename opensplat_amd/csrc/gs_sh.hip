@@ -277,10 +277,15 @@ k_sh_backward_fused(int N, int nb, const float *__restrict__ means, float cx, fl
     }
 }
 
-// K = 16 fused forward, four lanes per Gaussian (see k_sh_forward16_quad): lane q combines the
-// coefficients c = 12q .. 12q+11 of the virtual [dc | rest] row.  Rows of features_rest are 180 bytes,
-// so the 16-byte loads are only 4-byte aligned — gfx950 global loads allow that.
-
+// K = 16 fused forward, four lanes per Gaussian.  Lane q < 3 combines the coefficients 4q+1 .. 4q+4
+// = floats 12q .. 12q+11 of the Gaussian's features_rest row; lane 3 takes coefficients 13, 14, 15
+// (floats 36 .. 44) and the dc term.  Every lane issues the SAME three 16-byte loads — lane 3's third
+// one starts at float 41 instead of 44, so that it ends with the row and never leaves the tensor —
+// plus dc and the mean, all before any arithmetic: the first version chose between two differently
+// shaped load sets in a divergent branch, which the compiler could only place behind the view
+// direction's divisions, i.e. two dependent memory round trips per wave (3.9 TB/s; a plain streaming
+// read of the same 216 MB reaches 6.0, scripts/ubench/stream_bw.hip).  Rows of features_rest are
+// 180 bytes, so the 16-byte loads are only 4-byte aligned — gfx950 global loads allow that.
 __global__ void __launch_bounds__(256)
 k_sh_forward_fused16_quad(int N, int nb, const float *__restrict__ means, float cx, float cy,
                           float cz, const float *__restrict__ cp_dev, const float *__restrict__ dc,
@@ -290,30 +295,32 @@ k_sh_forward_fused16_quad(int N, int nb, const float *__restrict__ means, float 
     const int64_t g = t >> 2;
     const int q = (int)(t & 3);
     if (g >= N) return;  // whole quads drop out together
+    // the mean first: its consumer (the view direction) is waited for with the rows still in flight
+    const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+    const float *row = rest + g * 45 + 12 * q;
+    // {A.r A.g A.b B.r | B.g B.b C.r C.g | C.b D.r D.g D.b}; lane 3: {.. | .. | C.g* C.b* C.b D?} -> c.w = float 44
+    const float4_u a = *reinterpret_cast<const float4_u *>(row);
+    const float4_u b = *reinterpret_cast<const float4_u *>(row + 4);
+    const float4_u c = *reinterpret_cast<const float4_u *>(row + (q == 3 ? 5 : 8));
+    const float d0 = dc[3 * g], d1 = dc[3 * g + 1], d2 = dc[3 * g + 2];
     if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
-    float x, y, z;
-    view_dir(means, g, cx, cy, cz, x, y, z);
+    float x = mx - cx, y = my - cy, z = mz - cz;       // view_dir(), on the values loaded above
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    x /= nrm; y /= nrm; z /= nrm;
     float r[25];
     sh_basis(nb, x, y, z, r);
-    const float *row = rest + g * 45;
-    float4_u a, b, c;
-    if (q == 0) {  // {dc0 dc1 dc2 r0 | r1 r2 r3 r4 | r5 r6 r7 r8}
-        a.x = dc[3 * g]; a.y = dc[3 * g + 1]; a.z = dc[3 * g + 2]; a.w = row[0];
-        b = *reinterpret_cast<const float4_u *>(row + 1);
-        c = *reinterpret_cast<const float4_u *>(row + 5);
-    } else {
-        const float *p = row + 12 * q - 3;
-        a = *reinterpret_cast<const float4_u *>(p);
-        b = *reinterpret_cast<const float4_u *>(p + 4);
-        c = *reinterpret_cast<const float4_u *>(p + 8);
-    }
-    const float r0 = q == 0 ? r[0] : q == 1 ? r[4] : q == 2 ? r[8] : r[12];
-    const float r1 = q == 0 ? r[1] : q == 1 ? r[5] : q == 2 ? r[9] : r[13];
-    const float r2 = q == 0 ? r[2] : q == 1 ? r[6] : q == 2 ? r[10] : r[14];
-    const float r3 = q == 0 ? r[3] : q == 1 ? r[7] : q == 2 ? r[11] : r[15];
-    float c0 = r0 * a.x + r1 * a.w + r2 * b.z + r3 * c.y;
-    float c1 = r0 * a.y + r1 * b.x + r2 * b.w + r3 * c.z;
-    float c2 = r0 * a.z + r1 * b.y + r2 * c.x + r3 * c.w;
+    const bool l3 = q == 3;
+    const float rA = q == 0 ? r[1] : q == 1 ? r[5] : q == 2 ? r[9] : r[13];
+    const float rB = q == 0 ? r[2] : q == 1 ? r[6] : q == 2 ? r[10] : r[14];
+    const float rC = q == 0 ? r[3] : q == 1 ? r[7] : q == 2 ? r[11] : r[15];
+    const float rD = q == 0 ? r[4] : q == 1 ? r[8] : q == 2 ? r[12] : r[0];
+    // third coefficient's blue: float 8 of the lane's span (c.x), for lane 3 float 44 = c.w;
+    // fourth coefficient: floats 9 .. 11 (c.y c.z c.w), for lane 3 the dc term
+    const float Cb = l3 ? c.w : c.x;
+    const float D0 = l3 ? d0 : c.y, D1 = l3 ? d1 : c.z, D2 = l3 ? d2 : c.w;
+    float c0 = rA * a.x + rB * a.w + rC * b.z + rD * D0;
+    float c1 = rA * a.y + rB * b.x + rC * b.w + rD * D1;
+    float c2 = rA * a.z + rB * b.y + rC * Cb + rD * D2;
     c0 += dpp_f<0xB1>(c0); c1 += dpp_f<0xB1>(c1); c2 += dpp_f<0xB1>(c2);  // quad_perm [1,0,3,2]
     c0 += dpp_f<0x4E>(c0); c1 += dpp_f<0x4E>(c1); c2 += dpp_f<0x4E>(c2);  // quad_perm [2,3,0,1]
     if (q == 0) {
