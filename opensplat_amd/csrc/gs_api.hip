@@ -1,5 +1,7 @@
 // gs_api.hip — status strings, version and the thread-local HIP error text of libgsplat_hip.so.
+#include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "gs_device.h"
 
@@ -8,6 +10,35 @@ static thread_local char g_hip_err[256] = "";
 void set_hip_error(hipError_t e, const char *what) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
 }
+
+// ROCTX ranges around the entry points of the path (SURVEY.md §5 tracing; `rocprofv3 --marker-trace`
+// shows them above the kernels).  Off unless GSPLAT_ROCTX is set in the environment; libroctx64 is
+// looked up in the process at first use (libtorch-ROCm brings it; otherwise dlopen) — the library
+// has no link-time dependency on it.
+namespace {
+using push_fn = int (*)(const char *);
+using pop_fn = int (*)();
+push_fn g_push = nullptr;
+pop_fn g_pop = nullptr;
+bool roctx_ready() {
+    static const bool ok = [] {
+        if (!getenv("GSPLAT_ROCTX")) return false;
+        void *h = dlopen(nullptr, RTLD_NOW);
+        g_push = h ? reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA")) : nullptr;
+        g_pop = h ? reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop")) : nullptr;
+        if (!g_push || !g_pop) {
+            void *l = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!l) l = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            g_push = l ? reinterpret_cast<push_fn>(dlsym(l, "roctxRangePushA")) : nullptr;
+            g_pop = l ? reinterpret_cast<pop_fn>(dlsym(l, "roctxRangePop")) : nullptr;
+        }
+        return g_push && g_pop;
+    }();
+    return ok;
+}
+}  // namespace
+TraceRange::TraceRange(const char *name) : on_(roctx_ready()) { if (on_) g_push(name); }
+TraceRange::~TraceRange() { if (on_) g_pop(); }
 }  // namespace gs
 
 extern "C" const char *gs_strerror(int status) {

@@ -717,6 +717,7 @@ extern "C" size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H
 extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
                            int32_t *tile_order, int32_t *num_isects_host, void *workspace,
                            size_t workspace_bytes, gs_stream_t stream) {
+    GS_TRACE("gs_bin_scan");
     if (N < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (!tile_bins || !workspace) return GS_ERR_INVALID_ARGUMENT;
@@ -766,6 +767,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                            const float *depths, int32_t *tile_bins,
                            int32_t *gaussian_ids_sorted, const int32_t *list_stats,
                            void *workspace, size_t workspace_bytes, gs_stream_t stream) {
+    GS_TRACE("gs_bin_sort");
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0 || capacity == 0) return GS_OK;

@@ -23,6 +23,18 @@ constexpr int kWave = 64;
 // ---- host-side error plumbing ---------------------------------------------------------------
 void set_hip_error(hipError_t e, const char *what);
 
+// RAII ROCTX range around an entry point (gs_api.hip); a no-op unless GSPLAT_ROCTX is set.
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+
+private:
+    bool on_;
+};
+#define GS_TRACE(name) ::gs::TraceRange gs_trace_range_(name)
+
 #define GS_HIP_CHECK(expr)                                                                       \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

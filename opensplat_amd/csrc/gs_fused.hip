@@ -456,6 +456,7 @@ extern "C" int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev
                                    const float *features_rest, const float *cam_pos, float *packed,
                                    float *depths, int32_t *radii, float *rgb_raw, float *xys,
                                    uint32_t flags, gs_stream_t stream) {
+    GS_TRACE("gs_gaussian_forward");
     const int deg = gs::deg_from_bases(K);
     if (!cam || N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg)
         return GS_ERR_INVALID_ARGUMENT;
@@ -501,6 +502,7 @@ extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_de
                                     size_t records_bytes, float *v_means, float *v_scales,
                                     float *v_quats, float *v_opacity, float *v_dc, float *v_rest,
                                     float *v_xy, uint32_t flags, gs_stream_t stream) {
+    GS_TRACE("gs_gaussian_backward");
     const int deg = gs::deg_from_bases(K);
     if (!cam || N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg)
         return GS_ERR_INVALID_ARGUMENT;
@@ -532,6 +534,7 @@ extern "C" int gs_sh_backward_cameras(int N, int K, int degrees_to_use, int n_ca
                                       const float *cam_pos_dev, int cam_pos_stride,
                                       const float *v_colors, size_t v_colors_stride, float *v_dc,
                                       float *v_rest, uint32_t flags, gs_stream_t stream) {
+    GS_TRACE("gs_sh_backward_cameras");
     const int deg = gs::deg_from_bases(K);
     if (N < 0 || deg < 0 || degrees_to_use < 0 || degrees_to_use > deg || n_cams < 0)
         return GS_ERR_INVALID_ARGUMENT;

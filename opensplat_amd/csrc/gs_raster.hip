@@ -737,6 +737,7 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
                                     int32_t *final_idx, float *out_img_clamped,
                                     const int32_t *list_stats, const int32_t *tile_order,
                                     uint32_t flags, gs_stream_t stream) {
+    GS_TRACE("gs_rasterize_forward");
     if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
     float *clamped = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img_clamped : nullptr;
@@ -776,6 +777,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                                      void *workspace, size_t workspace_bytes,
                                      const int32_t *list_stats, const int32_t *tile_order,
                                      uint32_t flags, gs_stream_t stream) {
+    GS_TRACE("gs_rasterize_backward");
     if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
     const float *img_raw = (flags & GS_FLAG_CLAMP_IMAGE) ? out_img : nullptr;

@@ -514,3 +514,17 @@ def test_stale_list_statistics_only_cost_time():
     assert (lens[:, 1] - lens[:, 0]).max() > 1024
     assert np.array_equal(np_(b.gaussian_ids_sorted), np_(ref["binned"].gaussian_ids_sorted))
     assert np.array_equal(np_(f["img"]), np_(ref["img"]))
+
+
+def test_roctx_ranges_can_be_switched_on():
+    """GSPLAT_ROCTX=1: the entry points of the path push / pop ROCTX ranges (SURVEY.md §5 tracing);
+    libroctx64 is resolved in the process at first use.  The smoke step must run unchanged."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('ok')"],
+                       cwd=root, env=dict(os.environ, GSPLAT_ROCTX="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
