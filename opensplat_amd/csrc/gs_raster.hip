@@ -218,11 +218,13 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             float sg = (q0.z * dx) * dx + (q1.x * dy) * dy;
             sg = 0.5f * sg;
             sg = sg + (q0.w * dx) * dy;
-            if (__builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull) {
+            // (lane predicates as 64-bit scalar masks + inverse_ballot: one compare per predicate)
+            const uint64_t mbinds = __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u);
+            if (mbinds != 0ull) {
                 // rare: some group's Gaussian has a rectangle that cuts its sigma_max ellipse —
                 // apply the rectangle per pixel (and turn -0.0 into +0.0, see gs_pack_splats)
                 asm volatile("; rectangle binds");
-                if (sbits & 1u) {
+                if (__builtin_amdgcn_inverse_ballot_w64(mbinds)) {
                     const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
                     const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
                                     (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
@@ -230,19 +232,20 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 }
             }
             // 0 <= sigma <= sigma_max as ONE unsigned compare of the bit patterns
-            const bool need = __float_as_uint(sg) <= sbits;
-            const uint64_t mneed = __builtin_amdgcn_ballot_w64(need);
+            const uint64_t mneed = __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
             if (mneed == 0ull) continue;
             GS_STAT(1, 1);
             GS_STAT(2, __builtin_popcountll(mneed));
-            float vis = 0.0f;
-            if (need) vis = gs_exp<EXACT>(-sg, exp_tab);
+            // every lane evaluates the exponential (masking lanes off saves no issue cycle); lanes
+            // that do not need the entry — sigma possibly NaN — are discarded by `ok`
+            const float vis = gs_exp<EXACT>(-sg, exp_tab);
             // gsplat_cpu.cpp:220-236: alpha = min(0.999, opacity*vis); skip if alpha < 1/255;
             // nextT = T*(1-alpha); nextT <= 1e-4 -> pixel done (Gaussian not rendered).  A skipped
             // pixel is given alpha = 0, which composites exactly nothing.
             float alpha = q1.y * vis;
             alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.999f);
-            bool ok = alpha >= (1.0f / 255.0f);
+            bool ok = __builtin_amdgcn_inverse_ballot_w64(
+                mneed & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)));
             alpha = ok ? alpha : 0.0f;
             float nT = T * (1.0f - alpha);
             if (__builtin_amdgcn_ballot_w64(nT <= 1e-4f) != 0ull) {
