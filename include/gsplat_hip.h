@@ -230,9 +230,12 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            accumulates into them).  Partial gradients are accumulated with fp32 atomics into
  *            64-byte per-Gaussian records in `workspace` (gs_rasterize_backward_workspace_bytes(N)
  *            bytes, 64-byte aligned) and split into the four tensors at the end.
- *            tile_order (from gs_bin_scan): the launch starts with the longest lists; list_stats is
- *            accepted for source compatibility and ignored (every tile is composited by four
- *            quadrant waves).  Scheduling only, same results.
+ *            tile_order (from gs_bin_scan): the launch starts with the longest lists.  list_stats
+ *            (the scan's {M, longest list}; nullable): the forward ignores it (every tile is
+ *            composited by four quadrant waves); the backward gives a tile to ONE wave with four
+ *            pixels per lane when the longest list is within 8x the mean (+256), to two waves
+ *            with two pixels per lane otherwise or when the statistics are unknown.  Scheduling
+ *            only: the sums differ by atomic order as always.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */

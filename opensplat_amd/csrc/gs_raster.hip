@@ -332,7 +332,7 @@ __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float
 constexpr int kAcc = 9;           // accumulator floats per staged entry
 constexpr int kAccStride = kChunk + 1;  // component-major [9][65]: the nine components of an entry in nine banks
 constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_FLAG_DETERMINISTIC
-constexpr int kBackwardPixelsPerLane = 2;      // default WaveGeom of the backward (measured)
+constexpr int kBackwardPixelsPerLane = 2;      // WaveGeom of the backward when the list statistics are unknown
 
 // (five waves per SIMD: the compiler keeps the rare exact-exponential / rectangle paths out of the
 // register budget — measured -0.7 % at C2, -4 % at C3 against the unconstrained 116 VGPRs)
@@ -340,7 +340,7 @@ constexpr int kBackwardPixelsPerLane = 2;      // default WaveGeom of the backwa
 #define GS_BWD_WAVES 5
 #endif
 template <bool EXACT, bool DET, int PX>
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+__global__ void __launch_bounds__(64, PX == 4 ? 4 : GS_BWD_WAVES)   // (4 px/lane: 128 VGPRs, no spills)
 k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                      const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
                      const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
@@ -807,8 +807,17 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         GS_HIP_CHECK(hipMemsetAsync(gfix, 0, (size_t)N * gs::kGradRec * sizeof(long long), s));
     else if (!(flags & GS_FLAG_RECORDS_ZEROED))
         GS_HIP_CHECK(hipMemsetAsync(gacc, 0, rec_bytes, s));
-    // pixels per lane of the backward (WaveGeom): flag bits 21..22 select 1 / 2 / 4 for experiments
+    // pixels per lane of the backward (WaveGeom).  Four (one wave per tile, 8 x 8 blocks) amortise
+    // the per-step reduction best — 360 against 381 us at C2, 2.13 against 2.26 ms at C3 — but leave
+    // a tile's whole list to ONE wave: with a few very long lists (hot-spot scene: 0.81 against 0.51
+    // ms) two pixels per lane, i.e. two waves per tile, finish sooner.  list_stats (the scan's
+    // {M, longest list}) decides; without it the safe middle is taken.  Flag bits 21..22 select
+    // 1 / 2 / 4 explicitly (measurements).
     int px_per_lane = gs::kBackwardPixelsPerLane;
+    if (list_stats && list_stats[0] > 0) {
+        const int64_t mean_len = ((int64_t)list_stats[0] + tiles - 1) / tiles;
+        px_per_lane = (int64_t)list_stats[1] <= 8 * mean_len + 256 ? 4 : 2;
+    }
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
     const int units = (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // WaveGeom<PX>::PER_TILE waves per tile
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
