@@ -182,6 +182,14 @@ class Trainer:
                                 cam["cy"], W, H, flags=cabi.GS_CAM_LOG_SCALES)
         vm = np.asarray(cam["viewmat"], dtype=np.float32)
         cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)   # model.cpp:95
+        if self.factored:
+            # the camera centre travels in the exchange message: keep a device copy per camera (the
+            # upload is a synchronising copy — once per camera, not once per step)
+            key = (vm.tobytes(), str(self.dev))
+            hit = cam.get("_cam_pos_dev")
+            if hit is None or hit[0] != key:
+                hit = cam["_cam_pos_dev"] = (key, torch.from_numpy(cam_pos).to(self.dev))
+            self._cam_pos_dev = hit[1]
         flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
         while True:
             p = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats,
@@ -209,7 +217,7 @@ class Trainer:
             if self.fx is None or self.fx.N != self.N:      # (a refinement changes N)
                 self.fx = dist.FactoredExchange(self.N, self.K, 1, self.dev)
             fx = self.fx
-            fx.set_cam_pos(0, torch.from_numpy(np.ascontiguousarray(cam_pos, dtype=np.float32)).to(self.dev))
+            fx.set_cam_pos(0, self._cam_pos_dev)      # device-to-device: no host synchronisation
             cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
                                    cam_pos, self.K, deg, p["radii"], rgb_raw, self.bwd_ws,
                                    dict(self.gout, v_dc=fx.v_color(0), v_rest=None),
