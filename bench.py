@@ -134,6 +134,7 @@ class Pipeline:
         # default: the per-Gaussian stages fused into one kernel per direction (gs_gaussian_*);
         # --stage-kernels runs them as the separate operator-granular kernels instead
         self.stage_kernels = stage_kernels
+        self.fx = None
         if stage_kernels:
             self.stage_names = ["project_fwd", "sh_fwd", "bin_sort", "rasterize_fwd", "rasterize_bwd",
                                 "sh_bwd", "project_bwd", "allreduce"]

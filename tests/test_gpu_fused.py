@@ -226,7 +226,7 @@ def test_gaussian_forward_backward_equal_the_stage_kernels(K, deg, N):
         assert torch.equal(out2["v_rest"][:, :K - 1], v_rest)
 
 
-@pytest.mark.parametrize("K,deg", [(16, 3), (16, 2), (4, 1), (1, 0)])
+@pytest.mark.parametrize("K,deg", [(16, 3), (16, 2), (4, 1), (1, 0), (9, 2), (25, 4)])
 def test_sh_backward_cameras_equals_the_sum_of_per_camera_sh_gradients(K, deg):
     """gs_sh_backward_cameras (the factored gradient exchange): SH gradients formed from the colour
     cotangents of several cameras == the per-camera SH gradients of gs_sh_backward_fused, summed;
