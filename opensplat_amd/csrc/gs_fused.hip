@@ -302,8 +302,21 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
                 }
                 float4_u v;
                 v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
-                if (accum) v = v + *reinterpret_cast<float4_u *>(dst + i);
-                *reinterpret_cast<float4_u *>(dst + i) = v;
+                if (accum) {
+                    v = v + *reinterpret_cast<float4_u *>(dst + i);
+                    *reinterpret_cast<float4_u *>(dst + i) = v;
+                } else {
+                    // 180 B per Gaussian that nothing on the path reads back: streamed past the
+                    // caches, so that their write-back does not sit on the NEXT kernel's reads (the
+                    // SH forward of the following step: 53 -> 40 us in the timed loop; this kernel
+                    // +5 us; the training iteration, whose Adam step reads them at once, unchanged)
+                    // (four scalar builtins: the back end merges them into one global_store_dwordx4 nt;
+                    // on the 4-byte-aligned vector type the hint is dropped)
+                    __builtin_nontemporal_store(v.x, dst + i);
+                    __builtin_nontemporal_store(v.y, dst + i + 1);
+                    __builtin_nontemporal_store(v.z, dst + i + 2);
+                    __builtin_nontemporal_store(v.w, dst + i + 3);
+                }
             } else {
                 for (int idx = i; idx < total; idx++)
                     put(dst + idx, slab[(idx / ROW) * ROWP + (idx % ROW)]);
@@ -386,8 +399,21 @@ k_sh_backward_cameras(int N, int nb, int n_cams, const float *__restrict__ means
                 }
                 float4_u v;
                 v.x = e[0]; v.y = e[1]; v.z = e[2]; v.w = e[3];
-                if (accum) v = v + *reinterpret_cast<float4_u *>(dst + i);
-                *reinterpret_cast<float4_u *>(dst + i) = v;
+                if (accum) {
+                    v = v + *reinterpret_cast<float4_u *>(dst + i);
+                    *reinterpret_cast<float4_u *>(dst + i) = v;
+                } else {
+                    // 180 B per Gaussian that nothing on the path reads back: streamed past the
+                    // caches, so that their write-back does not sit on the NEXT kernel's reads (the
+                    // SH forward of the following step: 53 -> 40 us in the timed loop; this kernel
+                    // +5 us; the training iteration, whose Adam step reads them at once, unchanged)
+                    // (four scalar builtins: the back end merges them into one global_store_dwordx4 nt;
+                    // on the 4-byte-aligned vector type the hint is dropped)
+                    __builtin_nontemporal_store(v.x, dst + i);
+                    __builtin_nontemporal_store(v.y, dst + i + 1);
+                    __builtin_nontemporal_store(v.z, dst + i + 2);
+                    __builtin_nontemporal_store(v.w, dst + i + 3);
+                }
             } else {
                 for (int idx = i; idx < total; idx++)
                     put(dst + idx, slab[(idx / ROW) * ROWP + (idx % ROW)]);

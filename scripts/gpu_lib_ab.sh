@@ -7,6 +7,6 @@ for v in default "$@"; do
   if [ "$v" = default ]; then unset GSPLAT_HIP_LIB; else export GSPLAT_HIP_LIB=$PWD/opensplat_amd/csrc/libgsplat_hip_$v.so; fi
   $B ${BENCH_EXTRA:-} 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['value'],1), round(d['ms_per_step'],4), {k:round(v,4) for k,v in d['kernel_ms'].items()})"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['value'],1), round(d['ms_per_step'],4), {k:round(v,4) for k,v in d['kernel_ms'].items()}, {k:round(v,3) for k,v in d['stage_ms'].items()})"
 done
 done
