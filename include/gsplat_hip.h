@@ -327,7 +327,7 @@ int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_dev, const fl
  *        wrote to v_dc under GS_FLAG_EMIT_VCOLOR; all-zero rows are skipped)
  *   out: v_dc[N,3] v_rest[N,K-1,3]; GS_FLAG_ACCUMULATE_GRADS adds instead of overwriting            */
 int gs_sh_backward_cameras(int N, int K, int degrees_to_use, int n_cams, const float *means,
-                           const float *cam_pos_dev, int cam_pos_stride, const float *v_colors,
+                           const float *cam_pos_dev, size_t cam_pos_stride, const float *v_colors,
                            size_t v_colors_stride, float *v_dc, float *v_rest, uint32_t flags,
                            gs_stream_t stream);
 

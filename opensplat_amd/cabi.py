@@ -608,7 +608,7 @@ def sh_backward_cameras(K, degrees_to_use, means, cam_pos, v_colors, v_dc, v_res
     cs = cam_pos.shape[1] if cam_pos_stride is None else cam_pos_stride
     vs = N * 3 if v_colors_stride is None else v_colors_stride
     _check(lib().gs_sh_backward_cameras(C.c_int(N), C.c_int(K), C.c_int(degrees_to_use), C.c_int(n_cams),
-                                        _p(means), _p(cam_pos), C.c_int(cs), _p(v_colors),
+                                        _p(means), _p(cam_pos), C.c_size_t(cs), _p(v_colors),
                                         C.c_size_t(vs), _p(v_dc),
                                         _p(v_rest) if K > 1 else C.c_void_p(0), C.c_uint32(flags),
                                         _stream()), "gs_sh_backward_cameras")

@@ -336,7 +336,7 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
 k_sh_backward_cameras(int N, int nb, int n_cams, const float *__restrict__ means,
-                      const float *__restrict__ cam_pos, int cam_stride,
+                      const float *__restrict__ cam_pos, size_t cam_stride,
                       const float *__restrict__ v_colors, size_t v_stride, float *__restrict__ v_dc,
                       float *__restrict__ v_rest, uint32_t flags) {
     constexpr int ROW = ShSplit<K>::ROW, ROWP = ShSplit<K>::ROWP;
@@ -424,7 +424,7 @@ k_sh_backward_cameras(int N, int nb, int n_cams, const float *__restrict__ means
 
 template <int K>
 static int launch_sh_backward_cameras(int N, int nb, int n_cams, const float *means,
-                                      const float *cam_pos, int cam_stride, const float *v_colors,
+                                      const float *cam_pos, size_t cam_stride, const float *v_colors,
                                       size_t v_stride, float *v_dc, float *v_rest, uint32_t flags,
                                       hipStream_t s) {
     constexpr int BLK = ShSplit<K>::kBlock;
@@ -557,7 +557,7 @@ extern "C" int gs_gaussian_backward(const GsCamera *cam, const float *viewmat_de
 }
 
 extern "C" int gs_sh_backward_cameras(int N, int K, int degrees_to_use, int n_cams, const float *means,
-                                      const float *cam_pos_dev, int cam_pos_stride,
+                                      const float *cam_pos_dev, size_t cam_pos_stride,
                                       const float *v_colors, size_t v_colors_stride, float *v_dc,
                                       float *v_rest, uint32_t flags, gs_stream_t stream) {
     GS_TRACE("gs_sh_backward_cameras");

@@ -863,7 +863,7 @@ void GradExchange::exchangeFactored(Tensor geometry, Tensor message, Tensor gath
     allGather(message, gathered);
     c10::DeviceGuard guard(means.device());
     const int rc = gs_sh_backward_cameras((int)N, K, degreesToUse, worldSize(), means.data_ptr<float>(),
-                                          gathered.data_ptr<float>(), (int)message.numel(),
+                                          gathered.data_ptr<float>(), (size_t)message.numel(),
                                           gathered.data_ptr<float>() + 4, (size_t)message.numel(),
                                           v_dc.data_ptr<float>(), K > 1 ? v_rest.data_ptr<float>() : nullptr,
                                           0u, current_stream());
