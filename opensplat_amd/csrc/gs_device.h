@@ -127,7 +127,10 @@ __device__ __forceinline__ float expf_glibc(float x, const uint64_t *tab) {
     const uint64_t t = tab[ki & 0xFFu];
     const uint32_t hi = (uint32_t)(t >> 32) + (ki << 15);
     const double s = __hiloint2double((int)hi, (int)(uint32_t)t);
-    double p = fma(C0, r, C1);
+    // p = fma(C0, r, C1) in the three-address form: the compiler picks the two-address v_fmac_f64 and
+    // pays a v_mov_b64 of C1 in front of it on every evaluation
+    double p;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(C0), "v"(r), "v"(C1));
     double r2 = r * r;
     double y = fma(C2, r, 1.0);
     y = fma(p, r2, y);

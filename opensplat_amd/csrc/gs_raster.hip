@@ -169,7 +169,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     // NaN once the pixel is finished (or outside the image): a NaN row makes sigma NaN
     float pyf = inimg ? (float)py : qnan();
     float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    int last = -1;
+    int last = -1;   // list index of the last composited entry
+    int le = -1;     // ... as a slot of the current chunk (turned into an index once per chunk)
 
     const int2 range = bins[tile];
     // the next chunk's entry of this lane, gathered one chunk ahead (registers, not a struct: a
@@ -257,8 +258,10 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a1 = a1 + w * q2.y;
             a2 = a2 + w * q2.z;
             T = nT;
-            last = ok ? (c0 + e) : last;
+            le = ok ? e : le;
         }
+        last = le >= 0 ? c0 + le : last;
+        le = -1;
     }
     if (inimg) {
         const size_t pix = (size_t)py * W + px;
