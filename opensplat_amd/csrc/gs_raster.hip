@@ -473,6 +473,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
                 const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
+                const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
                 // rectangle test data of the rare entries whose rectangle cuts the sigma_max ellipse
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
                 float su = 0.0f, suy = 0.0f, suyy = 0.0f, gr = 0.0f, gg = 0.0f, gb = 0.0f;
@@ -480,7 +481,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
-                    float sg = 0.5f * fmaf(q1.x * dy, dy, Adxdx);
+                    // 0.5 (A dx^2 + C dy^2) + B dx dy with the halving folded into the per-step factors
+                    // (a power of two commutes with every rounding: the same bits as halving the sum)
+                    float sg = fmaf(hC * dy, dy, hAdxdx);
                     sg = fmaf(Bdx, dy, sg);
                     if (any_binds) {
                         asm volatile("; rectangle binds");
