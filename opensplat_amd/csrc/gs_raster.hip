@@ -338,12 +338,14 @@ constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_
 constexpr int kBackwardPixelsPerLane = 2;      // WaveGeom of the backward when the list statistics are unknown
 
 // (five waves per SIMD: the compiler keeps the rare exact-exponential / rectangle paths out of the
-// register budget — measured -0.7 % at C2, -4 % at C3 against the unconstrained 116 VGPRs)
+// register budget)
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 5
 #endif
 template <bool EXACT, bool DET, int PX>
-__global__ void __launch_bounds__(64, PX == 4 ? 4 : GS_BWD_WAVES)   // (4 px/lane: 128 VGPRs, no spills)
+// (four pixels per lane at 96 VGPRs keep eight values in scratch, touched once per CHUNK, not per step:
+// 356 us against 363 us with four waves per SIMD and none)
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
 k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                      const int32_t *__restrict__ ids, const int2 *__restrict__ bins,
                      const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
@@ -370,9 +372,10 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     const int px = wx0 + G::BW * (grp & 1) + (li % G::LW);
     const int py0 = wy0 + G::BH * (grp >> 1) + (li / G::LW);   // pixel p of the lane: row py0 + p * LH
     const float pxf = (float)px;
-    // per pixel: row, transmittance being unwound, T_final * (v_out_alpha - bg . v_out), running
-    // <colour buffer, v_out>, cotangent, list index of the last contributor
-    float pyf[PX], T[PX], TW[PX], bv[PX], vo0[PX], vo1[PX], vo2[PX];
+    // per pixel: row, transmittance being unwound, D = T_final * (v_out_alpha - bg . v_out) minus the
+    // running <colour buffer, v_out> (one accumulator: the difference is what v_alpha needs),
+    // cotangent, list index of the last contributor
+    float pyf[PX], T[PX], D[PX], vo0[PX], vo1[PX], vo2[PX];
     int last[PX];
     int gl = -1;
 #pragma unroll
@@ -397,8 +400,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         }
         pyf[p] = (float)py;
         T[p] = Tfin;
-        TW[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
-        bv[p] = 0.0f;
+        D[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
         gl = max(gl, last[p]);
     }
     // last contributor of each block (one DPP row) and of the wave
@@ -542,10 +544,10 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                     gr = fmaf(fac, vo0[p], gr);
                     gg = fmaf(fac, vo1[p], gg);
                     gb = fmaf(fac, vo2[p], gb);
-                    // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>)
+                    // cv = <colour, v_out>;  v_alpha = T*cv + ra*(T_final*w - <buffer, v_out>) = T*cv + ra*D
                     const float cv = fmaf(q2.z, vo2[p], fmaf(q2.y, vo1[p], q2.x * vo0[p]));
-                    const float v_alpha = fmaf(T[p], cv, ra * (TW[p] - bv[p]));
-                    bv[p] = fmaf(fac, cv, bv[p]);
+                    const float v_alpha = fmaf(T[p], cv, ra * D[p]);
+                    D[p] = fmaf(-fac, cv, D[p]);
                     // u = vis * v_alpha (= d/d opacity); v_sigma = -opacity * u is applied at the flush
                     const float u = vis * v_alpha;
                     const float uy = u * dy;
