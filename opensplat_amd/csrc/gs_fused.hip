@@ -12,7 +12,8 @@
 //   zeroes the record so that the next frame can skip its memset — slower at C2, see the header).
 // One lane per Gaussian; the higher-band SH rows of a wave's 64 Gaussians move through an LDS slab
 // of odd row stride with coalesced 16-byte global accesses (as in gs_sh.hip).  Both kernels are
-// HBM-streaming; at K = 16 the forward runs as two LDS-free kernels instead (k_project_pack).
+// HBM-streaming; at K = 16 the forward is one launch of two kinds of LDS-free workgroups instead
+// (k_sh_project_pack16).
 // Device functions are shared with the stage kernels (gs_gaussian.h): identical results.
 #include "gs_gaussian.h"
 
@@ -130,18 +131,18 @@ k_gaussian_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *_
     packed[3 * g + 2] = p2;
 }
 
-// K = 16: the SH rows are 180 bytes; one lane per Gaussian needs them in an 11.5 KB-per-wave LDS slab,
-// which caps the occupancy at three waves per SIMD and leaves the kernel above waiting on memory
-// (measured 103 us at N = 1 M).  Faster: the four-lanes-per-Gaussian SH kernel of gs_sh.hip (no
-// LDS, 3.9 TB/s) writes the raw rgb, and this LDS-free kernel does projection + packed record.
-__global__ void __launch_bounds__(256)
-k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev, int N,
-               const float *__restrict__ means, const float *__restrict__ scales,
-               const float *__restrict__ quats, const float *__restrict__ opacities,
-               const float *__restrict__ rgb_raw, float4 *__restrict__ packed,
-               float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ xys,
-               uint32_t flags) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// rgb_raw == nullptr: the colour part of the record (p2.xyz) is somebody else's to write — the SH
+// lanes of k_sh_project_pack16 — and only p2.w (the rectangle's rows) is stored
+__device__ __forceinline__ void project_pack_body(int g, CamArgs &cam, const float *__restrict__ vm_dev,
+                                                  const float *__restrict__ pm_dev, int N,
+                                                  const float *__restrict__ means,
+                                                  const float *__restrict__ scales,
+                                                  const float *__restrict__ quats,
+                                                  const float *__restrict__ opacities,
+                                                  const float *__restrict__ rgb_raw,
+                                                  float4 *__restrict__ packed, float *__restrict__ depths,
+                                                  int32_t *__restrict__ radii, float *__restrict__ xys,
+                                                  uint32_t flags) {
     if (g >= N) return;
     // every input of the lane is requested before the first use: the projection's few hundred
     // instructions then run on top of ONE memory round trip (the first version fetched the quaternion
@@ -149,7 +150,8 @@ k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__res
     float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
     const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
-    const float c0 = rgb_raw[3 * g + 0], c1 = rgb_raw[3 * g + 1], c2 = rgb_raw[3 * g + 2];
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    if (rgb_raw) { c0 = rgb_raw[3 * g + 0]; c1 = rgb_raw[3 * g + 1]; c2 = rgb_raw[3 * g + 2]; }
     const float opac = opacities[g];
     load_device_matrices(cam, vm_dev, pm_dev);
     if (cam.flags & GS_CAM_LOG_SCALES) {
@@ -171,9 +173,49 @@ k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__res
     pack_one(cam.W, cam.H, po.u, po.v, po.conic[0], po.conic[1], po.conic[2], true, o.a, o.c,
              opac, po.radius, fmaxf(c0 + 0.5f, 0.0f), fmaxf(c1 + 0.5f, 0.0f),
              fmaxf(c2 + 0.5f, 0.0f), flags, p0, p1, p2);
-    packed[3 * g + 0] = p0;
-    packed[3 * g + 1] = p1;
-    packed[3 * g + 2] = p2;
+    packed[3 * (size_t)g + 0] = p0;
+    packed[3 * (size_t)g + 1] = p1;
+    if (rgb_raw) packed[3 * (size_t)g + 2] = p2;
+    else reinterpret_cast<float *>(packed)[12 * (size_t)g + 11] = p2.w;
+}
+
+// K = 16: the SH rows are 180 bytes; one lane per Gaussian needs them in an 11.5 KB-per-wave LDS slab,
+// which caps the occupancy at three waves per SIMD and leaves the kernel above waiting on memory
+// (measured 103 us at N = 1 M).  Faster: the four-lanes-per-Gaussian SH kernel of gs_sh.hip (no
+// LDS) writes the raw rgb, and this LDS-free kernel does projection + packed record.
+__global__ void __launch_bounds__(256)
+k_project_pack(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev, int N,
+               const float *__restrict__ means, const float *__restrict__ scales,
+               const float *__restrict__ quats, const float *__restrict__ opacities,
+               const float *__restrict__ rgb_raw, float4 *__restrict__ packed,
+               float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ xys,
+               uint32_t flags) {
+    project_pack_body(blockIdx.x * blockDim.x + threadIdx.x, cam, vm_dev, pm_dev, N, means, scales, quats,
+                      opacities, rgb_raw, packed, depths, radii, xys, flags);
+}
+
+// Both of them in ONE launch (gs_gaussian_forward at K = 16): of every five consecutive workgroups
+// four run the SH forward (256 threads = 64 Gaussians each, HBM-streaming) and the fifth the
+// projection + packed record of the same 256 Gaussians (VALU-bound), so that the two kinds sit on the
+// CUs side by side instead of one kernel after the other.  Nothing depends on anything: the SH
+// lanes put clamp_min(rgb + 0.5, 0) into bytes 32..43 of the packed record themselves, the
+// projection lanes write the other 36 bytes.
+__global__ void __launch_bounds__(256)
+k_sh_project_pack16(CamArgs cam, const float *__restrict__ vm_dev, const float *__restrict__ pm_dev, int N,
+                    int nb, const float *__restrict__ means, const float *__restrict__ scales,
+                    const float *__restrict__ quats, const float *__restrict__ opacities,
+                    const float *__restrict__ dc, const float *__restrict__ rest, float cx, float cy,
+                    float cz, const float *__restrict__ cp_dev, float4 *__restrict__ packed,
+                    float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ rgb_raw,
+                    float *__restrict__ xys, uint32_t flags) {
+    const int grp = blockIdx.x / 5, r = blockIdx.x - 5 * grp;
+    if (r < 4) {
+        sh_forward16_quad_body((int64_t)(4 * grp + r) * 256 + threadIdx.x, N, nb, means, cx, cy, cz, cp_dev, dc, rest,
+                               reinterpret_cast<float *>(packed) + 8, 12, rgb_raw);
+    } else {
+        project_pack_body(grp * 256 + (int)threadIdx.x, cam, vm_dev, pm_dev, N, means, scales, quats, opacities,
+                          nullptr, packed, depths, radii, xys, flags);
+    }
 }
 
 template <int K>
@@ -505,13 +547,13 @@ extern "C" int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev
     case 1: GS_FWD(1);
     case 4: GS_FWD(4);
     case 9: GS_FWD(9);
-    case 16: {  // two LDS-free kernels beat the one-kernel slab variant (see k_project_pack)
-        const int rc = gs::launch_sh_forward_fused16_quad(N, nb, means, cam_pos, features_dc,
-                                                          features_rest, nullptr, rgb_raw, s);
-        if (rc != GS_OK) return rc;
-        hipLaunchKernelGGL(gs::k_project_pack, dim3((N + 255) / 256), dim3(256), 0, s, a, viewmat_dev,
-                           projmat_dev, N, means, scales, quats, opacities, rgb_raw,
-                           reinterpret_cast<float4 *>(packed), depths, radii, xys, flags);
+    case 16: {  // SH forward and projection + record as one launch of two kinds of workgroups
+        const bool dev = gs::on_device(cam_pos);
+        hipLaunchKernelGGL(gs::k_sh_project_pack16, dim3(5 * ((N + 255) / 256)), dim3(256), 0, s, a,
+                           viewmat_dev, projmat_dev, N, nb, means, scales, quats, opacities, features_dc,
+                           features_rest, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
+                           dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr,
+                           reinterpret_cast<float4 *>(packed), depths, radii, rgb_raw, xys, flags);
         GS_LAUNCH_CHECK();
         return GS_OK;
     }

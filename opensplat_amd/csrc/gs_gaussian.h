@@ -366,6 +366,60 @@ __device__ __forceinline__ void view_dir(const float *__restrict__ means, int64_
     x /= n; y /= n; z /= n;
 }
 
+// Body of the K = 16 split-coefficient SH forward, four lanes per Gaussian (t = 4 * Gaussian + lane of
+// the quad; comments: gs_sh.hip, k_sh_forward_fused16_quad).  colors (nullable) receives
+// clamp_min(rgb + 0.5, 0) at colors[color_stride * g + 0..2] — stride 3 for a colour tensor, 12 with
+// colors = packed + 8 to drop it straight into the packed record.
+__device__ __forceinline__ void sh_forward16_quad_body(int64_t t, int N, int nb, const float *__restrict__ means,
+                                                       float cx, float cy, float cz,
+                                                       const float *__restrict__ cp_dev,
+                                                       const float *__restrict__ dc,
+                                                       const float *__restrict__ rest,
+                                                       float *__restrict__ colors, int color_stride,
+                                                       float *__restrict__ rgb_raw) {
+    const int64_t g = t >> 2;
+    const int q = (int)(t & 3);
+    if (g >= N) return;  // whole quads drop out together
+    // the mean first: its consumer (the view direction) is waited for with the rows still in flight
+    const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+    const float *row = rest + g * 45 + 12 * q;
+    // {A.r A.g A.b B.r | B.g B.b C.r C.g | C.b D.r D.g D.b}; lane 3: {.. | .. | C.g* C.b* C.b D?} -> c.w = float 44
+    const float4_u a = *reinterpret_cast<const float4_u *>(row);
+    const float4_u b = *reinterpret_cast<const float4_u *>(row + 4);
+    const float4_u c = *reinterpret_cast<const float4_u *>(row + (q == 3 ? 5 : 8));
+    const float d0 = dc[3 * g], d1 = dc[3 * g + 1], d2 = dc[3 * g + 2];
+    if (cp_dev) { cx = cp_dev[0]; cy = cp_dev[1]; cz = cp_dev[2]; }
+    float x = mx - cx, y = my - cy, z = mz - cz;       // view_dir(), on the values loaded above
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    x /= nrm; y /= nrm; z /= nrm;
+    float r[25];
+    sh_basis(nb, x, y, z, r);
+    const bool l3 = q == 3;
+    const float rA = q == 0 ? r[1] : q == 1 ? r[5] : q == 2 ? r[9] : r[13];
+    const float rB = q == 0 ? r[2] : q == 1 ? r[6] : q == 2 ? r[10] : r[14];
+    const float rC = q == 0 ? r[3] : q == 1 ? r[7] : q == 2 ? r[11] : r[15];
+    const float rD = q == 0 ? r[4] : q == 1 ? r[8] : q == 2 ? r[12] : r[0];
+    // third coefficient's blue: float 8 of the lane's span (c.x), for lane 3 float 44 = c.w;
+    // fourth coefficient: floats 9 .. 11 (c.y c.z c.w), for lane 3 the dc term
+    const float Cb = l3 ? c.w : c.x;
+    const float D0 = l3 ? d0 : c.y, D1 = l3 ? d1 : c.z, D2 = l3 ? d2 : c.w;
+    float c0 = rA * a.x + rB * a.w + rC * b.z + rD * D0;
+    float c1 = rA * a.y + rB * b.x + rC * b.w + rD * D1;
+    float c2 = rA * a.z + rB * b.y + rC * Cb + rD * D2;
+    c0 += dpp_f<0xB1>(c0); c1 += dpp_f<0xB1>(c1); c2 += dpp_f<0xB1>(c2);  // quad_perm [1,0,3,2]
+    c0 += dpp_f<0x4E>(c0); c1 += dpp_f<0x4E>(c1); c2 += dpp_f<0x4E>(c2);  // quad_perm [2,3,0,1]
+    if (q == 0) {
+        rgb_raw[3 * g + 0] = c0;
+        rgb_raw[3 * g + 1] = c1;
+        rgb_raw[3 * g + 2] = c2;
+        if (colors) {
+            colors[color_stride * g + 0] = fmaxf(c0 + 0.5f, 0.0f);
+            colors[color_stride * g + 1] = fmaxf(c1 + 0.5f, 0.0f);
+            colors[color_stride * g + 2] = fmaxf(c2 + 0.5f, 0.0f);
+        }
+    }
+}
+
 // Split-coefficient SH kernels (features_dc + features_rest): LDS slab geometry per K.
 template <int K>
 struct ShSplit {
