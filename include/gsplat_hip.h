@@ -202,9 +202,22 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
  * scan + sort + compositing with a larger buffer if it was exceeded. */
 int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
                 int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                uint16_t *block_masks /*[capacity], see gs_block_masks*/,
                 const int32_t *list_stats /*host int32[2] {M, longest list} of an earlier frame,
                                             nullable: lets the launch skip empty size classes*/,
                 void *workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* Coverage masks of a sorted list: block_masks[i], bit 4 r + c set <=> list entry i (Gaussian
+ * gaussian_ids_sorted[i] in the tile whose segment holds i) can reach the 4x4-pixel block at block
+ * column c, block row r of that 16x16 tile — its sigma <= sigma_max ellipse (alpha >= 1/255,
+ * gsplat_cpu.cpp:220-222) and its rectangle intersect the block (conservatively: a superset of the
+ * blocks holding a composited pixel).  The compositing kernels walk a block's list from these bits
+ * and never gather a record that misses the wave's part of the tile.  gs_bin_sort / gs_bin_and_sort
+ * fill them themselves; this entry point serves lists built elsewhere (the reference's own global
+ * sort, include/gsplat_compat.h).  There is no counterpart in the reference: its kernels evaluate all
+ * 256 pixels of a tile for every list entry (forward.cu:301-361). */
+int gs_block_masks(int W, int H, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                   const float *packed, uint16_t *block_masks, gs_stream_t stream);
 
 /* gs_bin_scan + stream synchronisation + gs_bin_sort in one call (binAndSortGaussians,
  * rasterize_gaussians.cpp:6-37 together with its caller's cumsum/.item(), :62-63): for callers
@@ -215,6 +228,7 @@ int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, cons
  * reference blocks). */
 int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
                     const float *depths, int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                    uint16_t *block_masks /*[capacity]*/,
                     int32_t *tile_order /*[tiles], nullable*/, int32_t *num_isects_host /*pinned host int32[2]*/, void *workspace,
                     size_t workspace_bytes,
                     gs_stream_t stream);
@@ -240,6 +254,7 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
 int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
+                         const uint16_t *block_masks /*from gs_bin_sort / gs_block_masks*/,
                          const int32_t *tile_bins, const float *packed,
                          const float *background /*host or device [3]*/, float *out_img, float *final_Ts,
                          int32_t *final_idx,
@@ -255,6 +270,7 @@ size_t gs_rasterize_backward_workspace_bytes(int N);
 size_t gs_rasterize_backward_workspace_bytes_det(int N);
 
 int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+                          const uint16_t *block_masks,
                           const int32_t *tile_bins, const float *packed,
                           const float *background /*host or device [3]*/, const float *final_Ts,
                           const int32_t *final_idx, const float *v_out,

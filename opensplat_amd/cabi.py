@@ -31,7 +31,7 @@ GS_CAM_LOG_SCALES = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
-    "gs_bin_sort", "gs_bin_and_sort", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
+    "gs_bin_sort", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
 ]
@@ -198,6 +198,7 @@ class Binned:
     num_isects: int
     gaussian_ids_sorted: torch.Tensor   # [M] i32, per-tile depth-ordered lists
     tile_bins: torch.Tensor       # [tiles, 2] i32
+    block_masks: torch.Tensor = None    # [M] i16: per list entry, the 4x4-pixel blocks of its tile it reaches
 
 
 class BinWorkspace:
@@ -258,6 +259,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         ws_bytes = l.gs_bin_workspace_bytes(N, cap, W, H)
         ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
         ids = w.get("ids_sorted", (cap,), torch.int32, dev)
+        masks = w.get("block_masks", (cap,), torch.int16, dev)
         if speculative:
             _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
                                  _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
@@ -266,15 +268,15 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                 w.scan_done = torch.cuda.Event()
             w.scan_done.record()   # validate_binning waits for THIS, not for the whole stream
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                                 _p(depths), _p(tile_bins), _p(ids), w.list_stats, _p(ws),
+                                 _p(depths), _p(tile_bins), _p(ids), _p(masks), w.list_stats, _p(ws),
                                  C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
-            b = Binned(packed, tiles_hit, -1, ids, tile_bins)
+            b = Binned(packed, tiles_hit, -1, ids, tile_bins, masks)
             b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w
             b.list_stats = w.list_stats   # from the previous validated frame
             return b
         rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                               _p(depths), _p(tile_bins), _p(ids), _p(tile_order),
+                               _p(depths), _p(tile_bins), _p(ids), _p(masks), _p(tile_order),
                                C.c_void_p(m_host.data_ptr()), _p(ws), C.c_size_t(ws_bytes), _stream())
         M = int(m_host[0])
         if rc == GS_ERR_CAPACITY:
@@ -283,7 +285,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         _check(rc, "gs_bin_and_sort")
         break
     w.list_stats[0], w.list_stats[1] = int(m_host[0]), int(m_host[1])
-    b = Binned(packed, tiles_hit, M, ids[:M], tile_bins)
+    b = Binned(packed, tiles_hit, M, ids[:M], tile_bins, masks[:M])
     b.list_stats = w.list_stats
     b.tile_order = tile_order
     return b
@@ -301,6 +303,7 @@ def validate_binning(b: Binned) -> bool:
         b.workspace.capacity = M + M // 8 + 1024
         return False
     b.gaussian_ids_sorted = b.gaussian_ids_sorted[:M]
+    b.block_masks = b.block_masks[:M]
     return True
 
 
@@ -312,7 +315,8 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
                    final_idx=torch.empty((H, W), device=dev, dtype=torch.int32))
     bg = _vec3(background)
     _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
-                                      _p(binned.tile_bins), _p(binned.packed), bg, _p(out["img"]),
+                                      _p(binned.block_masks), _p(binned.tile_bins),
+                                      _p(binned.packed), bg, _p(out["img"]),
                                       _p(out["final_Ts"]), _p(out["final_idx"]),
                                       _p(out.get("img_clamped")), getattr(binned, "list_stats", None),
                                       _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
@@ -335,7 +339,8 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
         workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
     bg = _vec3(background)
     _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N),
-                                       _p(binned.gaussian_ids_sorted), _p(binned.tile_bins),
+                                       _p(binned.gaussian_ids_sorted), _p(binned.block_masks),
+                                       _p(binned.tile_bins),
                                        _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
                                        _p(v_out_alpha), _p(img_raw), _p(out["v_xy"]), _p(out["v_conic"]),
                                        _p(out["v_colors"]), _p(out["v_opacity"]), _p(workspace),

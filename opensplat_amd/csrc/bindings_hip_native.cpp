@@ -55,6 +55,16 @@ Tensor pack(int W, int H, const Tensor &xys, const Tensor &conics, const Tensor 
     return packed;
 }
 
+// coverage masks of a caller-sorted list (gs_block_masks): the compositing kernels need them beside
+// the ids; the reference's contract has no slot for them, so they are rebuilt per call here
+Tensor block_masks(int W, int H, const Tensor &ids, const Tensor &bins, const Tensor &packed) {
+    Tensor masks = torch::empty({std::max<int64_t>(ids.numel(), 1)}, ids.options().dtype(torch::kInt16));
+    ok(gs_block_masks(W, H, ids.data_ptr<int32_t>(), bins.data_ptr<int32_t>(), packed.data_ptr<float>(),
+                      reinterpret_cast<uint16_t *>(masks.data_ptr<int16_t>()), stream()),
+       "gs_block_masks");
+    return masks;
+}
+
 }  // namespace
 
 Tensor compute_sh_forward_tensor(unsigned num_points, unsigned degree, unsigned degrees_to_use,
@@ -201,7 +211,10 @@ std::tuple<Tensor, Tensor, Tensor> rasterize_forward_tensor(
     Tensor bg = f32c(background);
     Tensor img = torch::empty({H, W, 3}, fo), Ts = torch::empty({H, W}, fo);
     Tensor idx = torch::empty({H, W}, fo.dtype(torch::kInt32));
-    ok(gs_rasterize_forward(W, H, ids.data_ptr<int32_t>(), bins.data_ptr<int32_t>(),
+    Tensor masks = block_masks(W, H, ids, bins, packed);
+    ok(gs_rasterize_forward(W, H, ids.data_ptr<int32_t>(),
+                            reinterpret_cast<const uint16_t *>(masks.data_ptr<int16_t>()),
+                            bins.data_ptr<int32_t>(),
                             packed.data_ptr<float>(), bg.data_ptr<float>(), img.data_ptr<float>(),
                             Ts.data_ptr<float>(), idx.data_ptr<int32_t>(), nullptr, nullptr, nullptr, 0u,
                             stream()),
@@ -234,7 +247,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> rasterize_backward_tensor(
     Tensor ws = torch::empty({(int64_t)ws_bytes + 64}, fo.dtype(torch::kUInt8));
     char *wp = reinterpret_cast<char *>(ws.data_ptr<uint8_t>());
     wp += (64 - (reinterpret_cast<uintptr_t>(wp) & 63u)) & 63u;
-    ok(gs_rasterize_backward(W, H, (int)N, ids.data_ptr<int32_t>(), bins.data_ptr<int32_t>(),
+    Tensor masks = block_masks(W, H, ids, bins, packed);
+    ok(gs_rasterize_backward(W, H, (int)N, ids.data_ptr<int32_t>(),
+                             reinterpret_cast<const uint16_t *>(masks.data_ptr<int16_t>()),
+                             bins.data_ptr<int32_t>(),
                              packed.data_ptr<float>(), bg.data_ptr<float>(), fT.data_ptr<float>(),
                              fi.data_ptr<int32_t>(), vo.data_ptr<float>(),
                              voa.defined() ? voa.data_ptr<float>() : nullptr, nullptr,

@@ -660,6 +660,28 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
     }
 }
 
+// ---- 5. coverage masks ------------------------------------------------------------------------
+// One wave per tile: block_masks[i] = block_mask16 (gs_device.h) of list entry i against its tile —
+// which of the tile's sixteen 4x4-pixel blocks the Gaussian's sigma_max ellipse (and rectangle) can
+// reach.  The compositing kernels build their per-block walk lists from these bits instead of
+// testing the bounding rectangle in every wave of the tile, and skip the gather of entries that miss
+// their part of the tile.  2 B written per intersection; the record gather is served by L2 (the sort
+// and the compositing kernels read the same lines).
+__global__ void __launch_bounds__(64)
+k_block_masks(int tiles_x, const int2 *__restrict__ bins, const int32_t *__restrict__ ids,
+              const float4 *__restrict__ packed, uint16_t *__restrict__ masks) {
+    const int tile = blockIdx.x;
+    const int2 range = bins[tile];
+    const int tx0 = (tile % tiles_x) * GS_TILE, ty0 = (tile / tiles_x) * GS_TILE;
+    for (int i = range.x + (int)threadIdx.x; i < range.y; i += 64) {
+        const size_t g = (size_t)ids[i];
+        const float4 p0 = packed[3 * g + 0], p1 = packed[3 * g + 1];
+        const uint32_t ry = __float_as_uint(reinterpret_cast<const float *>(packed)[12 * g + 11]);
+        masks[i] = (uint16_t)block_mask16(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z),
+                                          __float_as_uint(p1.w), ry, tx0, ty0);
+    }
+}
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // LDS budget of the privatised count / scatter kernels (the CU has 160 KiB) and their grid: one
@@ -763,15 +785,32 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
     return GS_OK;
 }
 
+extern "C" int gs_block_masks(int W, int H, const int32_t *gaussian_ids_sorted,
+                              const int32_t *tile_bins, const float *packed, uint16_t *block_masks,
+                              gs_stream_t stream) {
+    GS_TRACE("gs_block_masks");
+    if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (!tile_bins || !gaussian_ids_sorted || !packed || !block_masks) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    hipLaunchKernelGGL(gs::k_block_masks, dim3(tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream,
+                       tiles_x, reinterpret_cast<const int2 *>(tile_bins), gaussian_ids_sorted,
+                       reinterpret_cast<const float4 *>(packed), block_masks);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
 extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed,
                            const float *depths, int32_t *tile_bins,
-                           int32_t *gaussian_ids_sorted, const int32_t *list_stats,
+                           int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                           const int32_t *list_stats,
                            void *workspace, size_t workspace_bytes, gs_stream_t stream) {
     GS_TRACE("gs_bin_sort");
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (N == 0 || capacity == 0) return GS_OK;
-    if (!packed || !depths || !tile_bins || !gaussian_ids_sorted || !workspace)
+    if (!packed || !depths || !tile_bins || !gaussian_ids_sorted || !block_masks || !workspace)
         return GS_ERR_INVALID_ARGUMENT;
     if ((uintptr_t)workspace & 15u) return GS_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
@@ -825,14 +864,15 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
                        1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted);
     GS_LAUNCH_CHECK();
-    return GS_OK;
+    // (after the short class: tile_bins is clamped to the capacity by now)
+    return gs_block_masks(W, H, gaussian_ids_sorted, tile_bins, packed, block_masks, stream);
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
                                const float *depths, int32_t *tile_bins,
-                               int32_t *gaussian_ids_sorted, int32_t *tile_order,
-                               int32_t *num_isects_host, void *workspace, size_t workspace_bytes,
-                               gs_stream_t stream) {
+                               int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                               int32_t *tile_order, int32_t *num_isects_host, void *workspace,
+                               size_t workspace_bytes, gs_stream_t stream) {
     if (!num_isects_host) return GS_ERR_INVALID_ARGUMENT;
     // a reused pinned buffer must never report the previous frame's counts, whatever path the scan takes
     num_isects_host[0] = 0;
@@ -843,6 +883,6 @@ extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const floa
     GS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const int32_t M = *num_isects_host;
     if (M > capacity) return GS_ERR_CAPACITY;
-    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, num_isects_host,
-                       workspace, workspace_bytes, stream);
+    return gs_bin_sort(W, H, N, M, packed, depths, tile_bins, gaussian_ids_sorted, block_masks,
+                       num_isects_host, workspace, workspace_bytes, stream);
 }

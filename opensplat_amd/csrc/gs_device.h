@@ -207,6 +207,80 @@ __device__ __forceinline__ int rect_tiles(const PixRect &r) {
     return (tx1 - tx0) * (ty1 - ty0);
 }
 
+// ---- coverage of a tile's sixteen 4x4-pixel blocks by one Gaussian ----------------------------
+// block_mask16: bit 4*r + c is set if the block at columns [4c, 4c+3], rows [4r, 4r+3] of the 16x16
+// tile with pixel origin (tx0, ty0) may hold a pixel that the compositing kernels composite for this
+// packed record — a pixel inside the record's rectangle whose sigma = 0.5 (A u^2 + C v^2) + B u v
+// (u, v = pixel - centre) does not exceed sigma_max (= ln(255 opacity) + margin: alpha >= 1/255,
+// gsplat_cpu.cpp:213-222).  A SUPERSET of those blocks is always valid (the kernels evaluate every
+// pixel of a block they visit); a missing one would change the image, so every step is conservative:
+//   * the rectangle alone (block columns x block rows it touches) is the fallback whenever the
+//     conic is not a comfortably conditioned ellipse (A, C > 0, det > 1e-3 A C) or the centre is not
+//     finite;
+//   * otherwise each block row is a slab v in [vlo, vhi] (its pixel rows, clipped to the rectangle
+//     and to the ellipse's own v range); the ellipse's u-extent over the slab is attained where the
+//     unconstrained extremum v* = -+B u_max / C is clamped into the slab (the right / left boundary
+//     u(v) = (-B v +- sqrt(s2 A - det v^2)) / A is concave / convex in v); s2 = 2 sigma_max inflated
+//     by 2e-3 (relative) + 1e-3, extents by 1e-3 u_max + 2e-3 pixels: orders of magnitude above the
+//     fp32 error of the kernels' sigma for det > 1e-3 A C (det itself is then good to 1e-4), far
+//     below a pixel.
+// Measured on the benchmark scenes (sampled against per-pixel evaluation): 7.56 blocks per Gaussian
+// against 7.54 exactly covered and 8.83 touched by the rectangle at C2; 20.3 / 20.2 / 25.0 at C3; no
+// covered block missed (tests/test_gpu_block_masks.py checks that on the device).
+__device__ __forceinline__ uint32_t block_mask16(float gx, float gy, float A, float B, float C,
+                                                 uint32_t smax_bits, uint32_t rx, uint32_t ry,
+                                                 int tx0, int ty0) {
+    // rectangle, tile-local, inclusive, clipped to the tile
+    int x0 = (int)(rx & 0xFFFFu) - tx0, x1 = (int)(rx >> 16) - 1 - tx0;
+    int y0 = (int)(ry & 0xFFFFu) - ty0, y1 = (int)(ry >> 16) - 1 - ty0;
+    x0 = max(x0, 0); x1 = min(x1, GS_TILE - 1);
+    y0 = max(y0, 0); y1 = min(y1, GS_TILE - 1);
+    if (x1 < x0 || y1 < y0) return 0u;
+    const uint32_t cols_rect = ((2u << (x1 >> 2)) - 1u) & ~((1u << (x0 >> 2)) - 1u);
+    const float smax = __uint_as_float(smax_bits & ~1u);
+    const float det = A * C - B * B;
+    const bool trust = smax >= 0.0f && A > 0.0f && C > 0.0f && det > 1.0e-3f * (A * C) &&
+                       det < 3.0e38f && fabsf(gx) < 1.0e6f && fabsf(gy) < 1.0e6f;
+    float s2A = 0.f, umax = 0.f, vmax = 0.f, vsr = 0.f, rA = 0.f, m = 0.f;
+    if (trust) {
+        const float s2 = 2.0f * smax * 1.002f + 1.0e-3f;
+        const float rdet = __builtin_amdgcn_rcpf(det) * 1.0001f;   // (1-ulp reciprocal: rounded up)
+        umax = __builtin_amdgcn_sqrtf(s2 * C * rdet) * 1.0001f;
+        vmax = __builtin_amdgcn_sqrtf(s2 * A * rdet) * 1.0001f;
+        vsr = -B * umax * __builtin_amdgcn_rcpf(C);
+        rA = __builtin_amdgcn_rcpf(A);
+        s2A = s2 * A;
+        m = umax * 1.0e-3f + 2.0e-3f;
+    }
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ylo = max(4 * r, y0), yhi = min(4 * r + 3, y1);
+        if (ylo > yhi) continue;
+        uint32_t cm = cols_rect;
+        if (trust) {
+            const float vlo = fmaxf((float)(ty0 + ylo) - gy, -vmax);
+            const float vhi = fminf((float)(ty0 + yhi) - gy, vmax);
+            if (vlo > vhi) continue;   // the slab misses the ellipse
+            const float vr = __builtin_amdgcn_fmed3f(vsr, vlo, vhi);
+            const float vl = __builtin_amdgcn_fmed3f(-vsr, vlo, vhi);
+            const float dR = fmaxf(s2A - det * vr * vr, 0.0f);
+            const float dL = fmaxf(s2A - det * vl * vl, 0.0f);
+            const float uR = (__builtin_amdgcn_sqrtf(dR) - B * vr) * rA;
+            const float uL = (-__builtin_amdgcn_sqrtf(dL) - B * vl) * rA;
+            // (|u| m covers the relative error of the 1-ulp reciprocal / square roots as well)
+            int clo = f2i_sat(ceilf(gx + (uL - (m + 1.0e-4f * fabsf(uL))))) - tx0;
+            int chi = f2i_sat(floorf(gx + (uR + (m + 1.0e-4f * fabsf(uR))))) - tx0;
+            clo = max(clo, x0);
+            chi = min(chi, x1);
+            if (clo > chi) continue;
+            cm = ((2u << (chi >> 2)) - 1u) & ~((1u << (clo >> 2)) - 1u);
+        }
+        mask |= cm << (4 * r);
+    }
+    return mask;
+}
+
 // XCD-aware block -> tile mapping: consecutive blocks round-robin over the 8 XCDs, so give each
 // XCD a contiguous band of tiles (neighbouring tiles share Gaussians -> shared L2 lines).
 __device__ __forceinline__ int xcd_swizzle(int block, int num_blocks) {

@@ -16,6 +16,7 @@
 #include <torch/torch.h>
 
 #include <cstdint>
+#include <memory>
 #include <tuple>
 #include <vector>
 
@@ -45,22 +46,43 @@ public:
                                                  torch::autograd::tensor_list grad_outputs);
 };
 
-// Packs the per-Gaussian 2-D records and ENQUEUES tile counting, scan, scatter and the per-tile sorts
-// with an id-list capacity guessed from the previous call (no host synchronisation).  Returns
-// { packed[N,12], gaussianIdsSorted[capacity] i32, tileBins[tiles,2] i32, count (pinned host i32[2]),
-//   tileOrder[tiles] i32 (tiles by descending list length) }.
-// After enqueuing the compositing kernel the caller runs validateBinning(count, ids): it waits for
-// the scan kernel's event (not for the stream) and returns false if the guess was too small —
-// repeat both steps then.
+// Per-tile depth-ordered lists of one frame, as the compositing kernels consume them.
+//   packed[N,12]               the 48-byte 2-D records (gs_pack_splats / gs_gaussian_forward)
+//   gaussianIdsSorted[cap] i32 + blockMasks[cap] i16 (which 4x4-pixel blocks of its tile an entry
+//                              reaches, gs_block_masks), tileBins[tiles,2] i32,
+//   tileOrder[tiles] i32       tiles by descending list length,
+//   count                      pinned host i32[2]: {M, longest list}, stored by the scan kernel,
+//   listStats                  the same two numbers once validateBinning has run.
+struct BinnedLists {
+    torch::Tensor packed, gaussianIdsSorted, blockMasks, tileBins, tileOrder, count;
+    int32_t listStats[2] = {0, 0};
+    int width = 0, height = 0, device = 0;
+    std::shared_ptr<void> scanDone;   // event recorded behind the scan kernel
+};
+
+// binAndSortPacked packs the per-Gaussian 2-D records and ENQUEUES tile counting, scan, scatter, the
+// per-tile sorts and the coverage masks with an id-list capacity taken from the running maximum of the
+// intersection counts seen so far for this (device, image size) — no host synchronisation.
+// binPackedRecords does the same for records that already exist (gs_gaussian_forward).
+// After enqueuing the compositing kernel the caller runs validateBinning(lists): it waits for the
+// scan kernel's event (not for the stream), stores the frame's {M, longest list} in `lists` and returns
+// false if the capacity was too small — repeat both steps then (the capacity has grown).
 // (The reference's binAndSortGaussians, rasterize_gaussians.hpp:11-20, blocks on cumsum().item()
-// before it can allocate, and takes radius-square tile counts; this one derives them from the
-// CPU pixel rectangle — DESIGN.md.)
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-binAndSortGaussians(
+// before it can allocate, and takes radius-square tile counts; its five-tuple contract — caller-side
+// cumulative counts, one global sort — is served at the launcher level, bindings_hip_native.h.)
+BinnedLists binAndSortPacked(
     const torch::Tensor &xys, const torch::Tensor &depths, const torch::Tensor &radii,
     const torch::Tensor &conics, const torch::Tensor &colors, const torch::Tensor &opacity,
     const torch::Tensor &cov2d, int imgHeight, int imgWidth, bool opacityIsLogit = false);
-bool validateBinning(const torch::Tensor &countHost, const torch::Tensor &gaussianIdsSorted);
+BinnedLists binPackedRecords(const torch::Tensor &packed, const torch::Tensor &depths, int imgHeight,
+                             int imgWidth);
+bool validateBinning(BinnedLists &lists);
+// Speculative-binning state: forget every capacity (e.g. after loading another scene); counters
+// {binning calls, forwards repeated because the capacity was too small} since the last reset; the
+// capacity currently held for an image size.
+void gsplatResetBinningState();
+std::tuple<int64_t, int64_t> gsplatBinningCounters();
+int64_t gsplatBinningCapacity(int device, int imgWidth, int imgHeight);
 
 class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
 public:

@@ -17,6 +17,9 @@
 
 #include <atomic>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "../../include/gsplat_hip.h"
 #include "../../include/gsplat_train.h"
@@ -178,51 +181,77 @@ tensor_list ProjectGaussians::backward(AutogradContext *ctx, tensor_list grad_ou
 }
 
 // ---- binning ------------------------------------------------------------------------------------
-static std::atomic<int64_t> g_capacityHint{0};
-// event recorded right after the scan kernel of the binning in flight on this thread
-static thread_local std::shared_ptr<at::cuda::CUDAEvent> g_scanDone;
-// {M, longest tile list} of the last validated frame: scheduling hint for the compositing kernels
-static int32_t g_listStats[2] = {0, 0};
+// State of the speculative binning, one record per (device, image width, image height): training
+// renders at 1/4, 1/2 and full resolution (model.cpp:249-251) and validates at full resolution, and
+// each of those sees its own intersection counts.
+//   capacity   entries the id list is given without asking the device: the RUNNING MAXIMUM of
+//              1.125 M + 1024 over every frame validated so far.  It never shrinks by itself
+//              (gsplatResetBinningState does that): with OpenSplat's random camera order a hint that
+//              followed the LAST frame would repeat the forward for every camera whose M exceeds its
+//              predecessor's by more than 12.5 %;
+//   listStats  {M, longest tile list} of the last validated frame of this key: only a hint for the
+//              binning of the NEXT frame (which size classes of the per-tile sort to launch).  The
+//              compositing launches of a frame use that frame's OWN statistics, which travel with its
+//              BinnedLists and, for the backward, in the autograd node's saved_data.
+// The reference blocks on cumsum().item() instead (rasterize_gaussians.cpp:62-63).
+struct BinState {
+    int64_t capacity = 0;
+    int32_t listStats[2] = {0, 0};
+};
+static std::mutex g_binMutex;
+static std::map<std::tuple<int, int, int>, BinState> g_binStates;
+static std::atomic<int64_t> g_binCalls{0}, g_binRepeats{0};
+
+static BinState readBinState(int device, int W, int H) {
+    std::lock_guard<std::mutex> lock(g_binMutex);
+    return g_binStates[std::make_tuple(device, W, H)];
+}
 
 // Binning of already-packed records (gs_pack_splats or gs_gaussian_forward): count + scan, scatter,
-// per-tile sort.  -> (packed, idsSorted[capacity], tileBins, mHost[2] pinned, tileOrder)
-static std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binPacked(const Tensor &packed,
-                                                                    const Tensor &depths, int H, int W) {
+// per-tile sort, coverage masks — all enqueued, nothing waited for.
+BinnedLists binPackedRecords(const Tensor &packed, const Tensor &depths, int H, int W) {
     const int64_t N = depths.size(0);
     auto i32 = depths.options().dtype(torch::kInt32);
     gs_stream_t s = current_stream();
-    // The id list is sized from the last intersection count this process saw (+12.5 %) and the
-    // count of THIS call is only read back after the caller has enqueued the compositing kernel
-    // (validateBinning): the stream never idles waiting for the host, where the reference blocks
-    // in the middle of the forward (rasterize_gaussians.cpp:62-63).  A stale guess costs one repeat.
+    BinnedLists b;
+    b.packed = packed;
+    b.width = W; b.height = H;
+    b.device = depths.get_device();
+    const BinState st = readBinState(b.device, W, H);
+    // The id list is sized from the intersection counts this process has seen for this image size and
+    // the count of THIS call is only read back after the caller has enqueued the compositing kernel
+    // (validateBinning): the stream never idles waiting for the host.  A guess that was too small
+    // costs one repeat.
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    Tensor tileBins = torch::empty({tiles, 2}, i32);
-    Tensor mHost = torch::zeros({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
-    const int64_t cap = std::max<int64_t>(g_capacityHint.load(), 1024);
-    Tensor idsSorted = torch::empty({cap}, i32);
+    b.tileBins = torch::empty({tiles, 2}, i32);
+    b.count = torch::zeros({2}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    const int64_t cap = std::max<int64_t>(st.capacity, 1024);
+    b.gaussianIdsSorted = torch::empty({cap}, i32);
+    b.blockMasks = torch::empty({cap}, depths.options().dtype(torch::kInt16));
     size_t wsBytes = gs_bin_workspace_bytes((int)N, cap, W, H);
     Tensor ws = torch::empty({(int64_t)wsBytes}, depths.options().dtype(torch::kUInt8));
     // tiles by descending list length: the compositing launches start with the long lists
-    Tensor tileOrder = torch::empty({tiles}, i32);
-    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), tileBins.data_ptr<int32_t>(),
-                             tileOrder.data_ptr<int32_t>(), mHost.data_ptr<int32_t>(),
+    b.tileOrder = torch::empty({tiles}, i32);
+    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), b.tileBins.data_ptr<int32_t>(),
+                             b.tileOrder.data_ptr<int32_t>(), b.count.data_ptr<int32_t>(),
                              ws.data_ptr(), wsBytes, s),
                  "gs_bin_scan");
     // validateBinning waits for this event (the scan kernel has stored the count), not for the stream
     auto scanDone = std::make_shared<at::cuda::CUDAEvent>();
     scanDone->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
-    g_scanDone = scanDone;
+    b.scanDone = scanDone;
     check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
-                             tileBins.data_ptr<int32_t>(), idsSorted.data_ptr<int32_t>(),
-                             g_listStats, ws.data_ptr(), wsBytes, s),
+                             b.tileBins.data_ptr<int32_t>(), b.gaussianIdsSorted.data_ptr<int32_t>(),
+                             reinterpret_cast<uint16_t *>(b.blockMasks.data_ptr<int16_t>()),
+                             st.listStats, ws.data_ptr(), wsBytes, s),
                  "gs_bin_sort");
-    return std::make_tuple(packed, idsSorted, tileBins, mHost, tileOrder);
+    g_binCalls++;
+    return b;
 }
 
-std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
-    const Tensor &xys, const Tensor &depths, const Tensor &radii, const Tensor &conics,
-    const Tensor &colors, const Tensor &opacity, const Tensor &cov2d, int imgHeight, int imgWidth,
-    bool opacityIsLogit) {
+BinnedLists binAndSortPacked(const Tensor &xys, const Tensor &depths, const Tensor &radii,
+                             const Tensor &conics, const Tensor &colors, const Tensor &opacity,
+                             const Tensor &cov2d, int imgHeight, int imgWidth, bool opacityIsLogit) {
     const int64_t N = xys.size(0);
     const int W = imgWidth, H = imgHeight;
     auto f32 = xys.options().dtype(torch::kFloat32);
@@ -238,22 +267,48 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> binAndSortGaussians(
                                 opacityIsLogit ? GS_FLAG_LOGIT_OPACITY : 0u, s),
                  "gs_pack_splats");
 
-    return binPacked(packed, depths, H, W);
+    return binPackedRecords(packed, depths, H, W);
 }
 
-// Waits until the scan kernel of the preceding binAndSortGaussians has stored its intersection
-// count in pinned memory (an event wait: kernels enqueued behind it keep running, the host goes on
-// enqueuing afterwards) and checks it against the capacity the id list was given.
-// false -> the lists were truncated: repeat binning + compositing.
-bool validateBinning(const Tensor &mHost, const Tensor &idsSorted) {
-    if (g_scanDone) g_scanDone->synchronize();
+// Waits until the scan kernel of `b` has stored its intersection count in pinned memory (an event
+// wait: kernels enqueued behind it keep running, the host goes on enqueuing afterwards), records the
+// frame's statistics in `b` and in the per-(device, size) state, and checks the count against the
+// capacity the id list was given.  false -> the lists were truncated: repeat binning + compositing.
+bool validateBinning(BinnedLists &b) {
+    if (b.scanDone) std::static_pointer_cast<at::cuda::CUDAEvent>(b.scanDone)->synchronize();
     else c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().synchronize();
-    const int64_t M = mHost.data_ptr<int32_t>()[0];
-    g_listStats[0] = (int32_t)M;
-    g_listStats[1] = mHost.data_ptr<int32_t>()[1];
-    g_capacityHint.store(M + M / 8 + 1024);
-    return M <= idsSorted.size(0);
+    const int64_t M = b.count.data_ptr<int32_t>()[0];
+    b.listStats[0] = (int32_t)M;
+    b.listStats[1] = b.count.data_ptr<int32_t>()[1];
+    {
+        std::lock_guard<std::mutex> lock(g_binMutex);
+        BinState &st = g_binStates[std::make_tuple(b.device, b.width, b.height)];
+        st.capacity = std::max<int64_t>(st.capacity, M + M / 8 + 1024);   // running maximum
+        st.listStats[0] = b.listStats[0];
+        st.listStats[1] = b.listStats[1];
+    }
+    const bool ok = M <= b.gaussianIdsSorted.size(0);
+    if (!ok) g_binRepeats++;
+    return ok;
+}
 
+void gsplatResetBinningState() {
+    std::lock_guard<std::mutex> lock(g_binMutex);
+    g_binStates.clear();
+    g_binCalls = 0;
+    g_binRepeats = 0;
+}
+
+std::tuple<int64_t, int64_t> gsplatBinningCounters() {
+    return std::make_tuple(g_binCalls.load(), g_binRepeats.load());
+}
+
+int64_t gsplatBinningCapacity(int device, int imgWidth, int imgHeight) {
+    return readBinState(device, imgWidth, imgHeight).capacity;
+}
+
+static const uint16_t *maskptr(const Tensor &m) {
+    return reinterpret_cast<const uint16_t *>(m.data_ptr<int16_t>());
 }
 
 // ---- RasterizeGaussians -------------------------------------------------------------------------
@@ -290,25 +345,29 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     auto f32 = xys.options();
     Tensor outImg = torch::empty({H, W, 3}, f32), finalTs = torch::empty({H, W}, f32);
     Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
-    Tensor packed, idsSorted, tileBins, tileOrder;
+    BinnedLists b;
     for (;;) {
-        auto b = binAndSortGaussians(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
-        packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
-        tileOrder = std::get<4>(b);
-        check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
-                                          tileBins.data_ptr<int32_t>(), fptr(packed), bg,
-                                          fptr_mut(outImg), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), nullptr, g_listStats,
-                                          tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr, flags, current_stream()),
+        b = binAndSortPacked(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
+        check_status(gs_rasterize_forward(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
+                                          maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
+                                          fptr(b.packed), bg, fptr_mut(outImg), fptr_mut(finalTs),
+                                          finalIdx.data_ptr<int32_t>(), nullptr, nullptr,
+                                          b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
+                                          flags, current_stream()),
                      "gs_rasterize_forward");
-        if (validateBinning(std::get<3>(b), idsSorted)) break;
+        if (validateBinning(b)) break;
     }
+    Tensor packed = b.packed, idsSorted = b.gaussianIdsSorted, tileBins = b.tileBins, tileOrder = b.tileOrder;
 
+    // this frame's own list statistics steer the backward's wave geometry
+    ctx->saved_data["listM"] = (int64_t)b.listStats[0];
+    ctx->saved_data["listLongest"] = (int64_t)b.listStats[1];
     ctx->saved_data["imgWidth"] = imgWidth;
     ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["flags"] = (int64_t)flags;
     ctx->saved_data["numPoints"] = N;
-    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold, tileOrder});
+    ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold, tileOrder,
+                            b.blockMasks});
     return outImg;
 }
 
@@ -318,6 +377,9 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     variable_list saved = ctx->get_saved_variables();
     Tensor idsSorted = saved[0], tileBins = saved[1], packed = saved[2];
     Tensor finalTs = saved[3], finalIdx = saved[4], bgHold = saved[5], tileOrder = saved[6];
+    Tensor blockMasks = saved[7];
+    const int32_t listStats[2] = {(int32_t)ctx->saved_data["listM"].toInt(),
+                                  (int32_t)ctx->saved_data["listLongest"].toInt()};
     c10::DeviceGuard guard(packed.device());
     Tensor v_outImg = grad_outputs[0].contiguous();
     GS_CHECK_F32(v_outImg);
@@ -328,11 +390,12 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
     Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
     check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
+                                       maskptr(blockMasks),
                                        tileBins.data_ptr<int32_t>(), fptr(packed), bg,
                                        fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
                                        nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
                                        nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
-                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes, g_listStats,
+                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes, listStats,
                                        tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
                                        (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
                  "gs_rasterize_backward");
@@ -440,20 +503,21 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
     Tensor bgHold;
     const float *bg = vec3_arg(background, bgHold);
-    Tensor packed, idsSorted, tileBins, tileOrder;
+    BinnedLists b;
     for (;;) {
-        auto b = binPacked(packedAll, depths, H, W);
-        packed = std::get<0>(b); idsSorted = std::get<1>(b); tileBins = std::get<2>(b);
-        tileOrder = std::get<4>(b);
-        check_status(gs_rasterize_forward(W, H, idsSorted.data_ptr<int32_t>(),
-                                          tileBins.data_ptr<int32_t>(), fptr(packed), bg,
-                                          fptr_mut(imgRaw), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), g_listStats,
-                                          tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
+        b = binPackedRecords(packedAll, depths, H, W);
+        check_status(gs_rasterize_forward(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
+                                          maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
+                                          fptr(b.packed), bg, fptr_mut(imgRaw), fptr_mut(finalTs),
+                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), nullptr,
+                                          b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
                                           flags, s),
                      "gs_rasterize_forward");
-        if (validateBinning(std::get<3>(b), idsSorted)) break;
+        if (validateBinning(b)) break;
     }
+    Tensor packed = b.packed, idsSorted = b.gaussianIdsSorted, tileBins = b.tileBins, tileOrder = b.tileOrder;
+    ctx->saved_data["listM"] = (int64_t)b.listStats[0];
+    ctx->saved_data["listLongest"] = (int64_t)b.listStats[1];
 
     ctx->saved_data["imgWidth"] = imgWidth; ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
@@ -468,7 +532,7 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
                             gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold,
-                            tileOrder, opacityLogits});
+                            tileOrder, opacityLogits, b.blockMasks});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};
@@ -488,17 +552,20 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     const float *bg = bgHold.data_ptr<float>();
     const float *cp = cpHold.data_ptr<float>();
     auto f32 = means.options();
-    Tensor opacityLogits = sv[17];
+    Tensor opacityLogits = sv[17], blockMasks = sv[18];
+    const int32_t listStats[2] = {(int32_t)ctx->saved_data["listM"].toInt(),
+                                  (int32_t)ctx->saved_data["listLongest"].toInt()};
     Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : Tensor();
     const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
     Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
     const uint32_t flags = (uint32_t)ctx->saved_data["flags"].toInt();
     // compositing backward: gradients stay in the 64-byte records of `ws` ...
     check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
+                                       maskptr(blockMasks),
                                        tileBins.data_ptr<int32_t>(), fptr(packed), bg, fptr(finalTs),
                                        finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
                                        fptr(imgRaw), nullptr, nullptr, nullptr, nullptr, ws.data_ptr(),
-                                       wsBytes, g_listStats,
+                                       wsBytes, listStats,
                                        tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
                                        flags | GS_FLAG_KEEP_RECORDS, s),
                  "gs_rasterize_backward");
@@ -887,7 +954,19 @@ static std::vector<Tensor> op_grad_exchange_factored_selftest(Tensor geometry, T
     return {v_dc, v_rest, gathered};
 }
 
+static void op_binning_reset() { gsplatResetBinningState(); }
+static std::vector<int64_t> op_binning_counters() {
+    auto c = gsplatBinningCounters();
+    return {std::get<0>(c), std::get<1>(c)};
+}
+static int64_t op_binning_capacity(int64_t device, int64_t w, int64_t h) {
+    return gsplatBinningCapacity((int)device, (int)w, (int)h);
+}
+
 TORCH_LIBRARY(opensplat_amd, m) {
+    m.def("binning_reset() -> ()", &op_binning_reset);
+    m.def("binning_counters() -> int[]", &op_binning_counters);
+    m.def("binning_capacity(int device, int img_width, int img_height) -> int", &op_binning_capacity);
     m.def("grad_exchange_selftest(Tensor(a!) flat, int buckets) -> Tensor(a!)", &op_grad_exchange_selftest);
     m.def("grad_exchange_factored_selftest(Tensor(a!) geometry, Tensor message, Tensor means, int K, "
           "int degrees_to_use) -> Tensor[]", &op_grad_exchange_factored_selftest);

@@ -52,6 +52,23 @@ def set_fast_exp(enabled: bool) -> None:
     _ops.set_fast_exp(bool(enabled))
 
 
+def binning_reset() -> None:
+    """Forget the id-list capacities of the speculative binning (gsplatResetBinningState)."""
+    _ops.binning_reset()
+
+
+def binning_counters():
+    """-> (binning calls, forwards repeated because the id-list capacity was too small) since the
+    last binning_reset()."""
+    c = _ops.binning_counters()
+    return int(c[0]), int(c[1])
+
+
+def binning_capacity(device: int, img_width: int, img_height: int) -> int:
+    """Id-list capacity currently held for (device, image size): the running maximum of 1.125 M + 1024."""
+    return int(_ops.binning_capacity(int(device), int(img_width), int(img_height)))
+
+
 def deg_from_sh(num_bases: int) -> int:  # spherical_harmonics.cpp:3-16
     return {1: 0, 4: 1, 9: 2, 16: 3}.get(int(num_bases), 4)
 

@@ -111,6 +111,22 @@ class Restated(_Base):
                                       vmnp, vsp, vqp)
         return dict(v_means=vmn, v_scales=vs, v_quats=vq)
 
+    def project_gpu_semantics(self, o, means, viewmat, projmat, cx, cy, H, W, clip=0.01):
+        """DESIGN.md P2 + P3 applied to a project_forward() result `o` (copy returned): near-plane
+        cull (forward.cu:49-52) and the principal-point offset (helpers.cuh:13-15).  Adds
+        'visible' (bool [N]) and 'xys_gpu_formula' (helpers.cuh's own expression)."""
+        N = len(means)
+        o = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+        m, mp = _f(means); vm, vmp = _f(viewmat); pm, pmp = _f(projmat)
+        vis, vp = _io((N,)); xg, xgp = _fo((N, 2))
+        self.lib.orc_project_gpu_semantics(C.c_int(N), mp, vmp, pmp, C.c_float(cx), C.c_float(cy),
+                                           C.c_int(H), C.c_int(W), C.c_float(clip),
+                                           o["xys"].ctypes.data_as(_f32p),
+                                           o["radii"].ctypes.data_as(_i32p), vp, xgp)
+        o["visible"] = vis.astype(bool)
+        o["xys_gpu_formula"] = xg
+        return o
+
     def sh_forward(self, degrees_to_use, dirs, coeffs):
         N, K = coeffs.shape[0], coeffs.shape[1]
         d, dp = _f(dirs); c, cp = _f(coeffs); out, op = _fo((N, 3))

@@ -176,6 +176,42 @@ int orc_project_forward(int N, const float *means, const float *scales, float gl
     return 0;
 }
 
+/* The two behaviours the product takes from the reference's GPU path rather than from gsplat-cpu
+ * (DESIGN.md P2, P3), restated so that they can be checked; applied IN PLACE to the outputs of
+ * orc_project_forward:
+ *   near-plane cull  rasterizer/gsplat/forward.cu:49-52 + helpers.cuh:225-233: p_view.z <= clip_thresh
+ *                    -> radii = 0, num_tiles_hit = 0, the Gaussian takes no part in the frame
+ *                    (visible[n] = 0; the caller leaves it out of the compositing, its gradients are 0);
+ *   principal point  helpers.cuh:13-15,112-122: pixel = 0.5 W x_ndc + cx - 0.5, which is gsplat-cpu's
+ *                    0.5 ((x_ndc + 1) W - 1) (gsplat_cpu.cpp:123-124; it ignores cx, cy) moved by
+ *                    (cx - W/2): xys += (cx - W/2, cy - H/2), the offset being exactly 0 for a centred
+ *                    principal point.
+ * xys_gpu_formula (nullable) receives helpers.cuh's own expression, rw = 1 / (w + 1e-6) included, so
+ * that a test can bound the distance between the two forms. */
+int orc_project_gpu_semantics(int N, const float *means, const float *viewmat, const float *projmat,
+                              float cx, float cy, int H, int W, float clip, float *xys,
+                              int32_t *radii, int32_t *visible, float *xys_gpu_formula) {
+    const float *vm = viewmat, *pm = projmat;
+    for (int n = 0; n < N; n++) {
+        const float *m = means + 3 * n;
+        float pz = vm[8] * m[0] + vm[9] * m[1] + vm[10] * m[2] + vm[11];   /* transform_4x3, row 2 */
+        int vis = !(pz <= clip);
+        visible[n] = vis;
+        if (!vis) radii[n] = 0;
+        xys[2 * n + 0] = xys[2 * n + 0] + (cx - 0.5f * (float)W);
+        xys[2 * n + 1] = xys[2 * n + 1] + (cy - 0.5f * (float)H);
+        if (xys_gpu_formula) {
+            float h[4];
+            for (int i = 0; i < 4; i++)
+                h[i] = pm[4 * i + 0] * m[0] + pm[4 * i + 1] * m[1] + pm[4 * i + 2] * m[2] + pm[4 * i + 3];
+            float rw = 1.0f / (h[3] + 1e-6f);
+            xys_gpu_formula[2 * n + 0] = 0.5f * (float)W * (h[0] * rw) + cx - 0.5f;
+            xys_gpu_formula[2 * n + 1] = 0.5f * (float)H * (h[1] * rw) + cy - 0.5f;
+        }
+    }
+    return 0;
+}
+
 /* VJP of orc_project_forward w.r.t. (means, scales, quats) for cotangents on xys and conics —
  * what libtorch autograd computes through gsplat_cpu.cpp:48-131 (the CPU path has no hand-written
  * backward; project_gaussians.cpp:94-123 is a plain differentiable function).  v_depth_view

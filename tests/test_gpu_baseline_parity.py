@@ -162,7 +162,8 @@ def check_chain(name, s, pipe, ref, grad_tol=2e-5, sel=None):
 # ---- (a) the fused path and SplatRender at medium size ------------------------------------------
 
 @pytest.mark.parametrize("K,deg,N,W,H", [(16, 3, 20000, 400, 240), (4, 1, 6000, 203, 117),
-                                         (1, 0, 3000, 128, 96), (9, 2, 8000, 320, 200)])
+                                         (1, 0, 3000, 128, 96), (9, 2, 8000, 320, 200),
+                                         (25, 4, 7000, 320, 200)])
 def test_timed_fused_path_matches_oracle(K, deg, N, W, H, restated):
     s = scenes.camera_scene(N, W, H, K=K, seed=300 + K, znear=1.0, zfar=100.0, yaw_deg=3.0,
                             degrees_to_use=deg, sigma_px=(0.6, 5.0))

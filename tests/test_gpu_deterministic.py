@@ -59,7 +59,8 @@ def test_deterministic_mode_needs_its_larger_workspace():
         b = out["binned"]
         o = {k: torch.empty(n, device="cuda") for k, n in (("a", (s.N, 2)), ("b", (s.N, 3)), ("c", (s.N, 3)), ("d", (s.N,)))}
         cabi._check(l.gs_rasterize_backward(
-            C.c_int(s.W), C.c_int(s.H), C.c_int(s.N), cabi._p(b.gaussian_ids_sorted), cabi._p(b.tile_bins),
+            C.c_int(s.W), C.c_int(s.H), C.c_int(s.N), cabi._p(b.gaussian_ids_sorted), cabi._p(b.block_masks),
+            cabi._p(b.tile_bins),
             cabi._p(b.packed), cabi._vec3(s.background), cabi._p(out["final_Ts"]), cabi._p(out["final_idx"]),
             cabi._p(v), None, None, cabi._p(o["a"]), cabi._p(o["b"]), cabi._p(o["c"]), cabi._p(o["d"]),
             cabi._p(small), C.c_size_t(small.numel()), None, None, C.c_uint32(cabi.GS_FLAG_DETERMINISTIC),

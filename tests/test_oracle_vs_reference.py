@@ -12,6 +12,8 @@ CASES = {
     "camera_wide_fov_clamp": lambda: scenes.camera_scene(500, 64, 64, K=1, seed=6, sigma_px=(2, 9),
                                                          znear=1.0, zfar=100.0),
     "ragged_edges": lambda: scenes.camera_scene(700, 37, 23, K=4, seed=8, znear=1.0, zfar=50.0),
+    # degree 4: numShBases returns 25 for any degree > 3 (gsplat_cpu.cpp:409-422)
+    "camera_sh4": lambda: scenes.camera_scene(2000, 128, 80, K=25, seed=9, znear=1.0, zfar=100.0),
 }
 
 
