@@ -172,10 +172,12 @@ int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
                    uint32_t flags /* GS_FLAG_LOGIT_OPACITY */, gs_stream_t stream);
 
 /* Workspace (bytes, 256-byte aligned base) sufficient for gs_bin_scan (any num_isects) and for
- * gs_bin_sort with capacity num_isects, for a W x H image.  gs_bin_scan leaves per-workgroup
- * segment offsets in it that the FOLLOWING gs_bin_sort continues from: give both calls the same
- * workspace (same base pointer; it may be larger for the second call) and do not touch it in
- * between. */
+ * gs_bin_sort with capacity num_isects, for N Gaussians and a W x H image.  gs_bin_scan leaves
+ * per-workgroup segment offsets and a 16-byte block-row table per Gaussian in it that the FOLLOWING
+ * gs_bin_sort continues from: give both calls the same workspace (same base pointer; it may be
+ * larger for the second call), the same N, W and H, and do not touch it in between.  gs_bin_sort
+ * returns GS_ERR_WORKSPACE for a workspace address no gs_bin_scan of the same (N, W, H) has been
+ * given (the library remembers the last scan of each workspace address on the host). */
 size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H);
 
 /* Counts the intersections of every 16x16 tile (rectangles of the packed records) and scans the

@@ -29,6 +29,8 @@
 // alpha-threshold ellipse box (k_pack_splats), not by the GPU reference's radius square;
 // tile_bins is [tiles, 2] (the reference allocates [M, 2], bindings.cu:324-326).
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "gs_gaussian.h"
 
@@ -124,13 +126,25 @@ __device__ __forceinline__ void for_each_tile(const TileRect &r, bool valid, int
 // table of all tile counters in LDS (4 B x tiles: 32 KiB at 1080p, 127 KiB at 4K, of the CU's
 // 160 KiB) and flush the non-zero ones with coalesced global atomics at the end.
 // k_count_tiles_global is the fallback for images with more tiles than fit in LDS.
+// The count kernels also leave, per Gaussian, the 16-byte table of its block-row extents
+// (block_rows_table, gs_device.h) from which the per-tile sorts assemble the coverage masks: these
+// kernels wait on loads and LDS atomics, their VALUs are idle (1.1 of 8 busy before).
+__device__ __forceinline__ uint4 rows_of_record(const float4 *__restrict__ packed, int n) {
+    const float4 p0 = packed[3 * (size_t)n + 0], p1 = packed[3 * (size_t)n + 1];
+    const uint32_t ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
+    return block_rows_table(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z), __float_as_uint(p1.w), ry);
+}
+
 __global__ void __launch_bounds__(256)
 k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
-                     int32_t *__restrict__ counts) {
+                     int32_t *__restrict__ counts, uint4 *__restrict__ rows) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = n < N;
     TileRect r = {0, 0, 0, 0};
-    if (valid) r = tile_rect(packed, n);
+    if (valid) {
+        r = tile_rect(packed, n);
+        rows[n] = rows_of_record(packed, n);
+    }
     for_each_tile(r, valid, tiles_x, 0u, 0,
                   [&](int tile, uint32_t, int) { atomicAdd(&counts[tile], 1); });
 }
@@ -141,7 +155,7 @@ k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
 // and reserve its ranges with a second round of returning atomics (48 -> 33 us at C2).
 __global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
-              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base) {
+              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base, uint4 *__restrict__ rows) {
     extern __shared__ int32_t h[];
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
@@ -156,6 +170,7 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
         if (valid) r = tile_rect(packed, n);
         for_each_tile(r, valid, tiles_x, 0u, 0,
                       [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
+        if (valid) rows[n] = rows_of_record(packed, n);
     }
     __syncthreads();
     int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
@@ -338,6 +353,26 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
     }
 }
 
+// ---- coverage mask of one sorted list entry (gathers the record; see block_mask16) -----------------
+__device__ __forceinline__ uint16_t entry_mask(const float4 *__restrict__ packed, int32_t id, int tx0,
+                                               int ty0) {
+    const size_t g = (size_t)id;
+    const float4 p0 = packed[3 * g + 0], p1 = packed[3 * g + 1];
+    const uint32_t ry = __float_as_uint(reinterpret_cast<const float *>(packed)[12 * g + 11]);
+    return (uint16_t)block_mask16(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z),
+                                  __float_as_uint(p1.w), ry, tx0, ty0);
+}
+
+// the same from the per-Gaussian row table the count kernel left (16-byte gather, a few integer
+// operations); Gaussians too large for a table take the long way
+__device__ __forceinline__ uint16_t entry_mask_rows(const uint4 *__restrict__ rows,
+                                                    const float4 *__restrict__ packed, int32_t id,
+                                                    int tx0, int ty0) {
+    const uint4 w = rows[(size_t)id];
+    if (w.x == kNoRowTable) return entry_mask(packed, id, tx0, ty0);
+    return (uint16_t)mask_from_rows(w, tx0 / GS_TILE, ty0 / GS_TILE);
+}
+
 // ---- 4. per-tile sort --------------------------------------------------------------------------
 // Bitonic network over P = next power of two >= n keys, in the all-ascending formulation: each
 // merge phase starts with a "flip" step (i <-> mirror position inside the 2k block) followed by
@@ -417,8 +452,10 @@ __device__ __forceinline__ void block_minmax(uint32_t &mn, uint32_t &mx, uint32_
 
 template <int CAP, int B, int NT>
 __global__ void __launch_bounds__(NT)
-k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
-                    uint64_t *__restrict__ keys, int32_t *__restrict__ ids_sorted) {
+k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles_x, const int2 *__restrict__ bins,
+                    uint64_t *__restrict__ keys, const float4 *__restrict__ packed,
+                    const uint4 *__restrict__ rows, int32_t *__restrict__ ids_sorted,
+                    uint16_t *__restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *out = reinterpret_cast<uint64_t *>(smem);           // CAP keys
     int32_t *cnt = reinterpret_cast<int32_t *>(out + CAP);         // B counters / cursors
@@ -428,12 +465,17 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
     const int n = min(range.y, capacity) - start;
     if (n <= lo_n) return;
     const int tid = threadIdx.x;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * GS_TILE, ty0 = ((int)blockIdx.x / tiles_x) * GS_TILE;
     if (n > hi_n) {  // longer than the LDS capacity: bitonic network in place in global memory
         int P = 2;
         while (P < n) P <<= 1;
         GlobalKeys m{keys + start, n};
         bitonic_sort(m, P, tid, NT);
-        for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+        for (int i = tid; i < n; i += NT) {
+            const int32_t id = (int32_t)(uint32_t)keys[start + i];
+            ids_sorted[start + i] = id;
+            masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
+        }
         return;
     }
     const uint64_t *src = keys + start;
@@ -533,7 +575,11 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
         }
         __syncthreads();
     }
-    for (int i = tid; i < n; i += NT) ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
+    for (int i = tid; i < n; i += NT) {
+        const int32_t id = (int32_t)(uint32_t)out[i];
+        ids_sorted[start + i] = id;
+        masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
+    }
 }
 
 // Single-wave variant for the common short segments (n <= 64*PL keys): the keys are loaded ONCE
@@ -553,9 +599,10 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
 
 template <int PL, int B>
 __global__ void __launch_bounds__(64)
-k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer, int tiles_x,
                    int2 *__restrict__ bins, uint64_t *__restrict__ keys,
-                   int32_t *__restrict__ ids_sorted) {
+                   const float4 *__restrict__ packed, const uint4 *__restrict__ rows,
+                   int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks) {
     constexpr int CAP = 64 * PL, PER = B / 64;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
@@ -569,6 +616,7 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
         bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
     if (n <= lo_n) return;
     const int lane = threadIdx.x;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * GS_TILE, ty0 = ((int)blockIdx.x / tiles_x) * GS_TILE;
     if (n > hi_n) {
         // a longer segment: normally another launch's job.  When the host skipped those launches
         // (the previous frame had no long list) this wave sorts it in place in global memory —
@@ -578,7 +626,11 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
         while (P < n) P <<= 1;
         GlobalKeys m{keys + start, n};
         bitonic_sort(m, P, lane, 64);
-        for (int i = lane; i < n; i += 64) ids_sorted[start + i] = (int32_t)(uint32_t)keys[start + i];
+        for (int i = lane; i < n; i += 64) {
+            const int32_t id = (int32_t)(uint32_t)keys[start + i];
+            ids_sorted[start + i] = id;
+            masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
+        }
         return;
     }
     const uint64_t *src = keys + start;
@@ -653,10 +705,20 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
         }
         __syncthreads();
     }
+    // the sorted ids, and beside each its coverage mask of the tile's 4x4-pixel blocks: the PL record
+    // gathers of a lane are independent (all in flight together), the masks are computed with every
+    // lane busy — as a kernel of its own (one wave looping over a tile's list) this took 46 us at C2
+    int32_t idv[PL];
 #pragma unroll
     for (int j = 0; j < PL; j++) {
         const int i = j * 64 + lane;
-        if (i < n) ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
+        idv[j] = (i < n) ? (int32_t)(uint32_t)out[i] : -1;
+        if (i < n) ids_sorted[start + i] = idv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        const int i = j * 64 + lane;
+        if (i < n) masks[start + i] = entry_mask_rows(rows, packed, idv[j], tx0, ty0);
     }
 }
 
@@ -674,11 +736,7 @@ k_block_masks(int tiles_x, const int2 *__restrict__ bins, const int32_t *__restr
     const int2 range = bins[tile];
     const int tx0 = (tile % tiles_x) * GS_TILE, ty0 = (tile / tiles_x) * GS_TILE;
     for (int i = range.x + (int)threadIdx.x; i < range.y; i += 64) {
-        const size_t g = (size_t)ids[i];
-        const float4 p0 = packed[3 * g + 0], p1 = packed[3 * g + 1];
-        const uint32_t ry = __float_as_uint(reinterpret_cast<const float *>(packed)[12 * g + 11]);
-        masks[i] = (uint16_t)block_mask16(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z),
-                                          __float_as_uint(p1.w), ry, tx0, ty0);
+        masks[i] = entry_mask(packed, ids[i], tx0, ty0);
     }
 }
 
@@ -697,9 +755,28 @@ static int persistent_blocks(int N) {
 // per-(workgroup, tile) offsets in wg_base for the gs_bin_sort that follows: BOTH CALLS MUST BE GIVEN
 // THE SAME WORKSPACE (the offsets of the key array move with the capacity, wg_base does not).
 struct BinLayout {
-    size_t counters, total_dev, wg_base, keys, total;
+    size_t counters, total_dev, wg_base, rows, keys, total;
 };
-static BinLayout bin_layout(int64_t capacity, int W, int H) {
+// What gs_bin_scan remembers (on the host, per workspace address) so that gs_bin_sort can tell that the
+// workspace it is handed holds the scan's leftovers — per-workgroup offsets, row tables — for the same
+// problem; a mismatch is GS_ERR_WORKSPACE instead of silently corrupt lists.
+struct BinStamp {
+    int N, W, H, blocks;
+};
+static std::mutex g_stamp_mutex;
+static std::unordered_map<const void *, BinStamp> g_stamps;
+static void stamp_workspace(const void *ws, const BinStamp &st) {
+    std::lock_guard<std::mutex> lock(g_stamp_mutex);
+    if (g_stamps.size() > 256) g_stamps.clear();   // (workspaces come and go with the allocator)
+    g_stamps[ws] = st;
+}
+static bool workspace_matches(const void *ws, const BinStamp &st) {
+    std::lock_guard<std::mutex> lock(g_stamp_mutex);
+    auto it = g_stamps.find(ws);
+    return it != g_stamps.end() && it->second.N == st.N && it->second.W == st.W &&
+           it->second.H == st.H && it->second.blocks == st.blocks;
+}
+static BinLayout bin_layout(int N, int64_t capacity, int W, int H) {
     const size_t tiles = (size_t)((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
     BinLayout L;
     L.counters = 0;
@@ -707,7 +784,8 @@ static BinLayout bin_layout(int64_t capacity, int W, int H) {
     L.wg_base = L.total_dev + 256;
     // per-(workgroup, tile) offsets handed from the count to the scatter kernel (LDS variants only)
     const size_t base_bytes = tiles * 4 <= kMaxTileLds ? align_up((size_t)256 * tiles * 4) : 0;
-    L.keys = L.wg_base + base_bytes;
+    L.rows = L.wg_base + base_bytes;
+    L.keys = L.rows + align_up((size_t)(N > 0 ? N : 1) * 16);
     L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 8) + 256;
     return L;
 }
@@ -733,7 +811,7 @@ extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const int32
 
 extern "C" size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H) {
     if (N < 0 || num_isects < 0 || W <= 0 || H <= 0) return 0;
-    return gs::bin_layout(num_isects, W, H).total;
+    return gs::bin_layout(N, num_isects, W, H).total;
 }
 
 extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
@@ -748,7 +826,7 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
-    const gs::BinLayout L = gs::bin_layout(0, W, H);
+    const gs::BinLayout L = gs::bin_layout(N, 0, W, H);
     if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
     char *base = static_cast<char *>(workspace);
     int32_t *counts = reinterpret_cast<int32_t *>(base + L.counters);
@@ -763,13 +841,16 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
             const int blocks = gs::persistent_blocks(N);
             hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
                                reinterpret_cast<const float4 *>(packed), counts,
-                               reinterpret_cast<int32_t *>(base + L.wg_base));
+                               reinterpret_cast<int32_t *>(base + L.wg_base),
+                               reinterpret_cast<uint4 *>(base + L.rows));
         } else {
             hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
-                               tiles_x, reinterpret_cast<const float4 *>(packed), counts);
+                               tiles_x, reinterpret_cast<const float4 *>(packed), counts,
+                               reinterpret_cast<uint4 *>(base + L.rows));
         }
         GS_LAUNCH_CHECK();
     }
+    gs::stamp_workspace(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N)});
     {
         const size_t lds = sizeof(int32_t) * ((size_t)tiles + tiles / 32 + 1);
         const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
@@ -816,9 +897,13 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
-    const gs::BinLayout L = gs::bin_layout(capacity, W, H);
+    const gs::BinLayout L = gs::bin_layout(N, capacity, W, H);
     if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
+    // the scan's per-workgroup offsets and row tables must be the ones of THIS problem
+    if (!gs::workspace_matches(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N)}))
+        return GS_ERR_WORKSPACE;
     char *base = static_cast<char *>(workspace);
+    const uint4 *rows = reinterpret_cast<const uint4 *>(base + L.rows);
     int32_t *fill = reinterpret_cast<int32_t *>(base + L.counters);
     uint64_t *keys = reinterpret_cast<uint64_t *>(base + L.keys);
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
@@ -842,6 +927,8 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory
     int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    // Every class also writes the coverage masks of its segments (entry_mask_rows).
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory.  The launches for the longer classes are skipped when the
@@ -849,7 +936,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     const bool only_short = list_stats && list_stats[0] > 0 && list_stats[1] <= 400;
     if (!only_short) {
         hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, 0, bins_rw, keys, gaussian_ids_sorted);
+                           capacity, 0, 0, tiles_x, bins_rw, keys, pk, rows, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
         constexpr int CAP = 8192, B = 4096, NT = 256;
         const size_t lds = 8 * CAP + 4 * B + 64;
@@ -857,15 +944,14 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
             reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
-                           CAP, capacity, bins, keys, gaussian_ids_sorted);
+                           CAP, capacity, tiles_x, bins, keys, pk, rows, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
     hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                       1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted);
+                       1, only_short ? 1 : 0, tiles_x, bins_rw, keys, pk, rows, gaussian_ids_sorted, block_masks);
     GS_LAUNCH_CHECK();
-    // (after the short class: tile_bins is clamped to the capacity by now)
-    return gs_block_masks(W, H, gaussian_ids_sorted, tile_bins, packed, block_masks, stream);
+    return GS_OK;
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,

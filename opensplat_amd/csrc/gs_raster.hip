@@ -355,6 +355,11 @@ constexpr int kBackwardPixelsPerLane = 2;      // WaveGeom of the backward when 
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 5
 #endif
+// 1: the next chunk's records are gathered into registers while the current chunk is walked (twelve
+// more live registers; 0 measured faster with the mask-driven staging: 345 -> 336 us at C2)
+#ifndef GS_BWD_PREFETCH
+#define GS_BWD_PREFETCH 0
+#endif
 template <bool EXACT, bool DET, int PX>
 // (four pixels per lane at 96 VGPRs keep eight values in scratch, touched once per CHUNK, not per step:
 // 356 us against 363 us with four waves per SIMD and none)
@@ -429,27 +434,39 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     if (wave_last < range.x) return;  // (also covers empty tiles / no contributors)
 
     if (lane == 0) stage_sentinel(&stage[kChunk]);
+    stage[lane].p0 = make_float4(0.f, 0.f, 0.f, 0.f);   // finite until staged (see the flush)
+    stage[lane].p1 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < kAcc; i++) acc[i * kAccStride + lane] = 0.0f;
 
     // walk the list back to front in chunks; slot 0 of a chunk is its furthest-back entry.  Only
     // entries whose coverage mask touches one of the wave's blocks are gathered and staged.
     const int ox = wx0 & (GS_TILE - 1), oy = wy0 & (GS_TILE - 1);
+#if GS_BWD_PREFETCH
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+#endif
     int ng = 0;
     uint32_t ntouch = 0u;
     if (wave_last - lane >= range.x) {
         ng = ids[wave_last - lane];
         ntouch = touch_from_mask<PX>(masks[wave_last - lane], ox, oy);
+#if GS_BWD_PREFETCH
         if (ntouch) {
             n0 = packed[3 * (size_t)ng + 0]; n1 = packed[3 * (size_t)ng + 1]; n2 = packed[3 * (size_t)ng + 2];
         }
+#endif
     }
     for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
         __syncthreads();
         const uint32_t touch = ntouch;
         bool binds_t = false;   // this lane's entry needs the per-pixel rectangle test
         if (touch) {
+#if !GS_BWD_PREFETCH
+            // the record is gathered here, at the head of its chunk (only id and mask run one chunk
+            // ahead): the other waves of the SIMD cover the latency, and twelve registers are free
+            const float4 n0 = packed[3 * (size_t)ng + 0], n1 = packed[3 * (size_t)ng + 1],
+                         n2 = packed[3 * (size_t)ng + 2];
+#endif
             stage[lane].p0 = n0;
             stage[lane].p1 = n1;
             stage[lane].p2 = n2;
@@ -477,9 +494,11 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         if (hi - kChunk - lane >= range.x) {
             ng = ids[hi - kChunk - lane];
             ntouch = touch_from_mask<PX>(masks[hi - kChunk - lane], ox, oy);
+#if GS_BWD_PREFETCH
             if (ntouch) {
                 n0 = packed[3 * (size_t)ng + 0]; n1 = packed[3 * (size_t)ng + 1]; n2 = packed[3 * (size_t)ng + 2];
             }
+#endif
         }
         bool flushed_any = false;  // wave-uniform
         auto walk = [&](auto binds_tag) {
@@ -593,7 +612,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         // ---- flush: moments -> gradient components (once per entry), then one atomic lane per
         //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
         wave_sync();
-        if (touch) {  // (a slot that was not staged holds no record, and its sums are zero)
+        // (a slot whose entry was not staged this chunk has zero sums and holds a finite record — an
+        // older one, or the zeros written at the start: 0 * finite = 0, nothing is flushed for it)
+        if (hi - lane >= range.x) {
             const float Ux = acc[0 * kAccStride + lane], Uy = acc[1 * kAccStride + lane];
             const float Uxx = acc[2 * kAccStride + lane], Uxy = acc[3 * kAccStride + lane];
             const float Uyy = acc[4 * kAccStride + lane];
