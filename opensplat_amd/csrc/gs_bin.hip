@@ -126,25 +126,13 @@ __device__ __forceinline__ void for_each_tile(const TileRect &r, bool valid, int
 // table of all tile counters in LDS (4 B x tiles: 32 KiB at 1080p, 127 KiB at 4K, of the CU's
 // 160 KiB) and flush the non-zero ones with coalesced global atomics at the end.
 // k_count_tiles_global is the fallback for images with more tiles than fit in LDS.
-// The count kernels also leave, per Gaussian, the 16-byte table of its block-row extents
-// (block_rows_table, gs_device.h) from which the per-tile sorts assemble the coverage masks: these
-// kernels wait on loads and LDS atomics, their VALUs are idle (1.1 of 8 busy before).
-__device__ __forceinline__ uint4 rows_of_record(const float4 *__restrict__ packed, int n) {
-    const float4 p0 = packed[3 * (size_t)n + 0], p1 = packed[3 * (size_t)n + 1];
-    const uint32_t ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
-    return block_rows_table(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z), __float_as_uint(p1.w), ry);
-}
-
 __global__ void __launch_bounds__(256)
 k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
-                     int32_t *__restrict__ counts, uint4 *__restrict__ rows) {
+                     int32_t *__restrict__ counts) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = n < N;
     TileRect r = {0, 0, 0, 0};
-    if (valid) {
-        r = tile_rect(packed, n);
-        rows[n] = rows_of_record(packed, n);
-    }
+    if (valid) r = tile_rect(packed, n);
     for_each_tile(r, valid, tiles_x, 0u, 0,
                   [&](int tile, uint32_t, int) { atomicAdd(&counts[tile], 1); });
 }
@@ -155,7 +143,7 @@ k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
 // and reserve its ranges with a second round of returning atomics (48 -> 33 us at C2).
 __global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
-              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base, uint4 *__restrict__ rows) {
+              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base) {
     extern __shared__ int32_t h[];
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
@@ -170,7 +158,6 @@ k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
         if (valid) r = tile_rect(packed, n);
         for_each_tile(r, valid, tiles_x, 0u, 0,
                       [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
-        if (valid) rows[n] = rows_of_record(packed, n);
     }
     __syncthreads();
     int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
@@ -298,26 +285,96 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
 }
 
 // ---- 3. scatter --------------------------------------------------------------------------------
-// key = order-preserving uint32 image of the depth float (flip all bits of negatives, set the
-// sign bit of non-negatives) << 32 | Gaussian id.  The reference uses the raw bit pattern, valid
-// only for depth > 0 (forward.cu:132); the map sorts identically there and stays correct for ANY
-// key, which lets tests drive the sort with the CPU reference's as-read keys.
-__global__ void __launch_bounds__(256)
-k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
-                 const float *__restrict__ depths, const int2 *__restrict__ bins,
-                 int32_t *__restrict__ fill, uint64_t *__restrict__ keys) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = n < N;
+// One 16-byte record per intersection: { depth key, Gaussian id, coverage mask, - }.
+//   depth key = order-preserving uint32 image of the depth float (flip all bits of negatives, set
+//   the sign bit of non-negatives).  The reference uses the raw bit pattern, valid only for depth > 0
+//   (forward.cu:132); the map sorts identically there and stays correct for ANY key, which lets tests
+//   drive the sort with the CPU reference's as-read keys.
+//   coverage mask = which of the tile's sixteen 4x4-pixel blocks the Gaussian can reach
+//   (block_mask16, gs_device.h).  It is formed HERE, where a lane holds its Gaussian's record in
+//   registers: the block-row table of the Gaussian once (block_rows_table), then a few integer
+//   operations per tile (mask_from_rows) — the kernel waits on its scattered stores, its VALUs were
+//   idle (0.8 of 8 busy).  As a kernel of its own over the sorted lists the same masks cost 46 us at
+//   C2, gathered per entry in the sorts' epilogue 32 us (404 / 290 us at C3: 19 M random gathers).
+// A 16-byte scattered store leaves L2 as one 32-byte write, exactly like the 8-byte store it replaces.
+struct SplatForMask {
+    float x, y, A, B, C;
+    uint32_t smax, rx, ry;
+};
+
+template <typename Emit>
+__device__ __forceinline__ void scatter_tiles(const float4 *__restrict__ packed,
+                                              const float *__restrict__ depths, int n, bool valid,
+                                              int tiles_x, Emit emit) {
     TileRect r = {0, 0, 0, 0};
     uint32_t db = 0;
+    SplatForMask g = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
+    uint4 w = make_uint4(kNoRowTable, 0u, 0u, 0u);
     if (valid) {
-        r = tile_rect(packed, n);
+        const float4 p0 = packed[3 * (size_t)n + 0], p1 = packed[3 * (size_t)n + 1];
+        g.x = p0.x; g.y = p0.y; g.A = p0.z; g.B = p0.w; g.C = p1.x;
+        g.smax = __float_as_uint(p1.z);
+        g.rx = __float_as_uint(p1.w);
+        g.ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
+        const int x0 = g.rx & 0xFFFF, x1 = g.rx >> 16, y0 = g.ry & 0xFFFF, y1 = g.ry >> 16;
+        r.tx0 = x0 / GS_TILE; r.tx1 = (x1 + GS_TILE - 1) / GS_TILE;
+        r.ty0 = y0 / GS_TILE; r.ty1 = (y1 + GS_TILE - 1) / GS_TILE;
+        if (x1 <= x0 || y1 <= y0) r.tx1 = r.tx0, r.ty1 = r.ty0;
         db = __float_as_uint(depths[n]);
         db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
     }
-    for_each_tile(r, valid, tiles_x, db, n, [&](int tile, uint32_t d, int g) {
+    const int cnt = valid ? r.count() : 0;
+    // small rectangles: the lane walks its own tiles, masks from the Gaussian's block-row table
+    if (__builtin_amdgcn_ballot_w64(cnt > 0 && cnt <= kLaneTiles) != 0ull) {
+        if (cnt > 0 && cnt <= kLaneTiles)
+            w = block_rows_table(g.x, g.y, g.A, g.B, g.C, g.smax, g.rx, g.ry);
+        if (cnt > 0 && cnt <= kLaneTiles) {
+            for (int ty = r.ty0; ty < r.ty1; ty++)
+                for (int tx = r.tx0; tx < r.tx1; tx++) {
+                    const uint32_t m = w.x != kNoRowTable
+                                           ? mask_from_rows(w, tx, ty)
+                                           : block_mask16(g.x, g.y, g.A, g.B, g.C, g.smax, g.rx, g.ry,
+                                                          tx * GS_TILE, ty * GS_TILE);
+                    emit(ty * tiles_x + tx, db, n, m);
+                }
+        }
+    }
+    // a rectangle with more than kLaneTiles tiles is walked by the whole wave (one lane looping over
+    // thousands of tiles would stall the other 63): every lane takes tiles of the broadcast record
+    uint64_t big = __builtin_amdgcn_ballot_w64(cnt > kLaneTiles);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+#define GS_BCAST_I(v) __builtin_amdgcn_readlane((int)(v), src)
+#define GS_BCAST_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src))
+        const int tx0 = GS_BCAST_I(r.tx0), tx1 = GS_BCAST_I(r.tx1);
+        const int ty0 = GS_BCAST_I(r.ty0), ty1 = GS_BCAST_I(r.ty1);
+        const uint32_t d = (uint32_t)GS_BCAST_I(db);
+        const int id = GS_BCAST_I(n);
+        const float bx = GS_BCAST_F(g.x), by = GS_BCAST_F(g.y), bA = GS_BCAST_F(g.A);
+        const float bB = GS_BCAST_F(g.B), bC = GS_BCAST_F(g.C);
+        const uint32_t bs = (uint32_t)GS_BCAST_I(g.smax), brx = (uint32_t)GS_BCAST_I(g.rx);
+        const uint32_t bry = (uint32_t)GS_BCAST_I(g.ry);
+#undef GS_BCAST_I
+#undef GS_BCAST_F
+        const int wd = tx1 - tx0, total = wd * (ty1 - ty0);
+        for (int i = lane; i < total; i += 64) {
+            const int tx = tx0 + i % wd, ty = ty0 + i / wd;
+            emit(ty * tiles_x + tx, d, id,
+                 block_mask16(bx, by, bA, bB, bC, bs, brx, bry, tx * GS_TILE, ty * GS_TILE));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
+                 const float *__restrict__ depths, const int2 *__restrict__ bins,
+                 int32_t *__restrict__ fill, uint4 *__restrict__ keys) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    scatter_tiles(packed, depths, n, n < N, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
         const int pos = bins[tile].x + atomicAdd(&fill[tile], 1);
-        if (pos < capacity) keys[pos] = ((uint64_t)d << 32) | (uint32_t)g;
+        if (pos < capacity) keys[pos] = make_uint4(d, (uint32_t)g, m, 0u);
     });
 }
 
@@ -328,7 +385,7 @@ k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict_
 __global__ void __launch_bounds__(kPersistentThreads)
 k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restrict__ packed,
           const float *__restrict__ depths, const int2 *__restrict__ bins,
-          const int32_t *__restrict__ wg_base, uint64_t *__restrict__ keys) {
+          const int32_t *__restrict__ wg_base, uint4 *__restrict__ keys) {
     extern __shared__ int32_t h[];
     const int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = bins[t].x + my_base[t];
@@ -338,22 +395,15 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
     for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
          chunk += (blockDim.x >> 6) * gridDim.x) {
         const int n = chunk * 64 + (threadIdx.x & 63);
-        const bool valid = n < N;
-        TileRect r = {0, 0, 0, 0};
-        uint32_t db = 0;
-        if (valid) {
-            r = tile_rect(packed, n);
-            db = __float_as_uint(depths[n]);
-            db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
-        }
-        for_each_tile(r, valid, tiles_x, db, n, [&](int tile, uint32_t d, int g) {
+        scatter_tiles(packed, depths, n, n < N, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
             const int pos = atomicAdd(&h[tile], 1);
-            if (pos < capacity) keys[pos] = ((uint64_t)d << 32) | (uint32_t)g;
+            if (pos < capacity) keys[pos] = make_uint4(d, (uint32_t)g, m, 0u);
         });
     }
 }
 
 // ---- coverage mask of one sorted list entry (gathers the record; see block_mask16) -----------------
+// (for lists sorted elsewhere: gs_block_masks)
 __device__ __forceinline__ uint16_t entry_mask(const float4 *__restrict__ packed, int32_t id, int tx0,
                                                int ty0) {
     const size_t g = (size_t)id;
@@ -363,17 +413,10 @@ __device__ __forceinline__ uint16_t entry_mask(const float4 *__restrict__ packed
                                   __float_as_uint(p1.w), ry, tx0, ty0);
 }
 
-// the same from the per-Gaussian row table the count kernel left (16-byte gather, a few integer
-// operations); Gaussians too large for a table take the long way
-__device__ __forceinline__ uint16_t entry_mask_rows(const uint4 *__restrict__ rows,
-                                                    const float4 *__restrict__ packed, int32_t id,
-                                                    int tx0, int ty0) {
-    const uint4 w = rows[(size_t)id];
-    if (w.x == kNoRowTable) return entry_mask(packed, id, tx0, ty0);
-    return (uint16_t)mask_from_rows(w, tx0 / GS_TILE, ty0 / GS_TILE);
-}
-
 // ---- 4. per-tile sort --------------------------------------------------------------------------
+// The sort key of a record is (depth key << 32 | id); the coverage mask travels with it.
+__device__ __forceinline__ uint64_t rec_key(const uint4 r) { return ((uint64_t)r.x << 32) | r.y; }
+
 // Bitonic network over P = next power of two >= n keys, in the all-ascending formulation: each
 // merge phase starts with a "flip" step (i <-> mirror position inside the 2k block) followed by
 // half-cleaners, and every compare-exchange moves the smaller key to the lower index.  Padding
@@ -385,42 +428,63 @@ __device__ __forceinline__ void bitonic_sort(Mem &m, int P, int tid, int nthread
         for (int i = tid; i < (P >> 1); i += nthreads) {
             const int lo = ((i & ~(half - 1)) << 1) | (i & (half - 1));
             const int hi = lo ^ (k - 1);
-            const uint64_t a = m.get(lo), b = m.get(hi);
-            if (a > b) {
-                m.set(lo, b);
-                m.set(hi, a);
-            }
+            if (m.key(lo) > m.key(hi)) m.swap(lo, hi);
         }
         __syncthreads();
         for (int j = k >> 2; j > 0; j >>= 1) {
             for (int i = tid; i < (P >> 1); i += nthreads) {
                 const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const int hi = lo | j;
-                const uint64_t a = m.get(lo), b = m.get(hi);
-                if (a > b) {
-                    m.set(lo, b);
-                    m.set(hi, a);
-                }
+                if (m.key(lo) > m.key(hi)) m.swap(lo, hi);
             }
             __syncthreads();
         }
     }
 }
 
-struct LdsKeys {
-    uint64_t *p;
-    __device__ __forceinline__ uint64_t get(int i) const { return p[i]; }
-    __device__ __forceinline__ void set(int i, uint64_t v) { p[i] = v; }
-};
-// global-memory variant: indices >= n read as the padding key and are never written back
-struct GlobalKeys {
-    uint64_t *p;
+// keys + masks in LDS; positions >= n read as the padding key and are never swapped (a padding key
+// is never smaller than anything)
+struct LdsRecs {
+    uint64_t *k;
+    uint16_t *m;
     int n;
-    __device__ __forceinline__ uint64_t get(int i) const { return i < n ? p[i] : ~0ull; }
-    __device__ __forceinline__ void set(int i, uint64_t v) {
-        if (i < n) p[i] = v;
+    __device__ __forceinline__ uint64_t key(int i) const { return i < n ? k[i] : ~0ull; }
+    __device__ __forceinline__ void swap(int i, int j) {
+        const uint64_t a = k[i];
+        k[i] = k[j];
+        k[j] = a;
+        const uint16_t b = m[i];
+        m[i] = m[j];
+        m[j] = b;
     }
 };
+// the records in place in global memory
+struct GlobalRecs {
+    uint4 *p;
+    int n;
+    __device__ __forceinline__ uint64_t key(int i) const { return i < n ? rec_key(p[i]) : ~0ull; }
+    __device__ __forceinline__ void swap(int i, int j) {
+        const uint4 a = p[i];
+        p[i] = p[j];
+        p[j] = a;
+    }
+};
+
+// a segment too long for the on-chip paths: network in place, then ids and masks out
+template <int NT>
+__device__ __forceinline__ void sort_in_global(uint4 *__restrict__ recs, int n, int tid,
+                                               int32_t *__restrict__ ids_out,
+                                               uint16_t *__restrict__ masks_out) {
+    int P = 2;
+    while (P < n) P <<= 1;
+    GlobalRecs m{recs, n};
+    bitonic_sort(m, P, tid, NT);
+    for (int i = tid; i < n; i += NT) {
+        const uint4 r = recs[i];
+        ids_out[i] = (int32_t)r.y;
+        masks_out[i] = (uint16_t)r.z;
+    }
+}
 
 // ---- 4b. bucket sort ---------------------------------------------------------------------------
 // The keys of one tile are (nearly) uniformly spread between the tile's nearest and farthest
@@ -428,11 +492,11 @@ struct GlobalKeys {
 // its own bucket: O(n) LDS work instead of the bitonic network's O(n log^2 n).
 //   1. min / max of the 32-bit depth keys (wave reductions, combined through LDS);
 //   2. bucket = (depth key - min) >> shift  (shift chosen so that bucket < B; monotone in the key);
-//      LDS histogram, exclusive scan, scatter of the 64-bit keys through LDS cursors;
+//      LDS histogram, exclusive scan, scatter of the 64-bit keys (+ masks) through LDS cursors;
 //   3. every bucket holding more than one key is put in order by a single lane (insertion sort on
 //      the full (depth, id) key).  If some bucket is longer than kMaxBucket keys (many equal
 //      depths — pathological) the whole segment is re-sorted with the bitonic network instead.
-// CAP: segment capacity in keys; B: buckets; NT: threads.  LDS: 8*CAP + 4*B (+ a few words).
+// CAP: segment capacity in keys; B: buckets; NT: threads.  LDS: 10*CAP + 4*B (+ a few words).
 constexpr int kMaxBucket = 24;
 
 template <int NT>
@@ -450,39 +514,46 @@ __device__ __forceinline__ void block_minmax(uint32_t &mn, uint32_t &mx, uint32_
     }
 }
 
+// insertion sort of out[s0, e) / outm[s0, e) by key (a bucket of at most kMaxBucket keys)
+__device__ __forceinline__ void insertion_sort_bucket(uint64_t *out, uint16_t *outm, int s0, int e) {
+    for (int i = s0 + 1; i < e; i++) {
+        const uint64_t k = out[i];
+        const uint16_t km = outm[i];
+        int q = i - 1;
+        while (q >= s0 && out[q] > k) {
+            out[q + 1] = out[q];
+            outm[q + 1] = outm[q];
+            q--;
+        }
+        out[q + 1] = k;
+        outm[q + 1] = km;
+    }
+}
+
 template <int CAP, int B, int NT>
 __global__ void __launch_bounds__(NT)
-k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles_x, const int2 *__restrict__ bins,
-                    uint64_t *__restrict__ keys, const float4 *__restrict__ packed,
-                    const uint4 *__restrict__ rows, int32_t *__restrict__ ids_sorted,
+k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
+                    uint4 *__restrict__ keys, int32_t *__restrict__ ids_sorted,
                     uint16_t *__restrict__ masks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *out = reinterpret_cast<uint64_t *>(smem);           // CAP keys
     int32_t *cnt = reinterpret_cast<int32_t *>(out + CAP);         // B counters / cursors
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words (16 reserved)
+    uint16_t *outm = reinterpret_cast<uint16_t *>(scratch + 16);   // CAP masks
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
     if (n <= lo_n) return;
     const int tid = threadIdx.x;
-    const int tx0 = ((int)blockIdx.x % tiles_x) * GS_TILE, ty0 = ((int)blockIdx.x / tiles_x) * GS_TILE;
     if (n > hi_n) {  // longer than the LDS capacity: bitonic network in place in global memory
-        int P = 2;
-        while (P < n) P <<= 1;
-        GlobalKeys m{keys + start, n};
-        bitonic_sort(m, P, tid, NT);
-        for (int i = tid; i < n; i += NT) {
-            const int32_t id = (int32_t)(uint32_t)keys[start + i];
-            ids_sorted[start + i] = id;
-            masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
-        }
+        sort_in_global<NT>(keys + start, n, tid, ids_sorted + start, masks + start);
         return;
     }
-    const uint64_t *src = keys + start;
+    const uint4 *src = keys + start;
     // 1. range of the depth keys
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
     for (int i = tid; i < n; i += NT) {
-        const uint32_t d = (uint32_t)(src[i] >> 32);
+        const uint32_t d = src[i].x;
         mn = min(mn, d);
         mx = max(mx, d);
     }
@@ -493,10 +564,7 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles_x, const int
     // 2. histogram
     for (int i = tid; i < B; i += NT) cnt[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        const uint32_t d = (uint32_t)(src[i] >> 32);
-        atomicAdd(&cnt[(d - mn) >> shift], 1);
-    }
+    for (int i = tid; i < n; i += NT) atomicAdd(&cnt[(src[i].x - mn) >> shift], 1);
     __syncthreads();
     //    exclusive scan of the B counters: each thread owns B/NT consecutive ones
     constexpr int PER = B / NT;
@@ -533,58 +601,36 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles_x, const int
     if (longest > kMaxBucket) atomicOr(flag, 1u);
     // 3. scatter into bucket order
     for (int i = tid; i < n; i += NT) {
-        const uint64_t k = src[i];
-        const uint32_t d = (uint32_t)(k >> 32);
-        const int pos = atomicAdd(&cnt[(d - mn) >> shift], 1);
-        out[pos] = k;
+        const uint4 r = src[i];
+        const int pos = atomicAdd(&cnt[(r.x - mn) >> shift], 1);
+        out[pos] = rec_key(r);
+        outm[pos] = (uint16_t)r.z;
     }
     __syncthreads();
     if (*flag) {
-        // many equal / clustered depths: bitonic network on the LDS copy (padding keys sort last)
+        // many equal / clustered depths: bitonic network on the LDS copy (virtual padding)
         int P = 2;
         while (P < n) P <<= 1;
-        for (int i = n + tid; i < P && i < CAP; i += NT) out[i] = ~0ull;
-        __syncthreads();
-        if (P <= CAP) {
-            LdsKeys m{out};
-            bitonic_sort(m, P, tid, NT);
-        } else {  // n > CAP/2 and not a power of two: virtual padding beyond CAP is never touched
-            struct Padded {
-                uint64_t *p; int n;
-                __device__ __forceinline__ uint64_t get(int i) const { return i < n ? p[i] : ~0ull; }
-                __device__ __forceinline__ void set(int i, uint64_t v) { if (i < n) p[i] = v; }
-            } m{out, n};
-            bitonic_sort(m, P, tid, NT);
-        }
+        LdsRecs m{out, outm, n};
+        bitonic_sort(m, P, tid, NT);
     } else {
         // order inside buckets: cursor[b] is now the END of bucket b, the end of b-1 its start
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            const int b = tid * PER + j;
-            const int e = cnt[b];
-            const int s0 = e - local[j];
-            for (int i = s0 + 1; i < e; i++) {  // insertion sort (local[j] <= kMaxBucket)
-                const uint64_t k = out[i];
-                int q = i - 1;
-                while (q >= s0 && out[q] > k) {
-                    out[q + 1] = out[q];
-                    q--;
-                }
-                out[q + 1] = k;
-            }
+            const int e = cnt[tid * PER + j];
+            insertion_sort_bucket(out, outm, e - local[j], e);
         }
         __syncthreads();
     }
     for (int i = tid; i < n; i += NT) {
-        const int32_t id = (int32_t)(uint32_t)out[i];
-        ids_sorted[start + i] = id;
-        masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
+        ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
+        masks[start + i] = outm[i];
     }
 }
 
-// Single-wave variant for the common short segments (n <= 64*PL keys): the keys are loaded ONCE
+// Single-wave variant for the common short segments (n <= 64*PL keys): the records are loaded ONCE
 // into registers (PL per lane), bucket b is owned by lane b % 64 (conflict-free LDS access), the
-// exclusive scan is B/64 DPP wave scans.  LDS: 8*64*PL + 4*B bytes (6 KiB for PL = 8, B = 512),
+// exclusive scan is B/64 DPP wave scans.  LDS: 10*64*PL + 4*B bytes (7 KiB for PL = 8, B = 512),
 // so that many tiles are resident per CU and their global-memory round trips overlap.
 __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
     // Hillis-Steele inside each 16-lane row (row_shr with zero fill), then the two row carries
@@ -599,13 +645,13 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
 
 template <int PL, int B>
 __global__ void __launch_bounds__(64)
-k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer, int tiles_x,
-                   int2 *__restrict__ bins, uint64_t *__restrict__ keys,
-                   const float4 *__restrict__ packed, const uint4 *__restrict__ rows,
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
+                   int2 *__restrict__ bins, uint4 *__restrict__ keys,
                    int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks) {
     constexpr int CAP = 64 * PL, PER = B / 64;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
+    __shared__ uint16_t outm[CAP];
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
@@ -616,34 +662,30 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
         bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
     if (n <= lo_n) return;
     const int lane = threadIdx.x;
-    const int tx0 = ((int)blockIdx.x % tiles_x) * GS_TILE, ty0 = ((int)blockIdx.x / tiles_x) * GS_TILE;
     if (n > hi_n) {
         // a longer segment: normally another launch's job.  When the host skipped those launches
         // (the previous frame had no long list) this wave sorts it in place in global memory —
         // slow, but only ever hit on the frame where a list first outgrows this class.
         if (!take_longer) return;
-        int P = 2;
-        while (P < n) P <<= 1;
-        GlobalKeys m{keys + start, n};
-        bitonic_sort(m, P, lane, 64);
-        for (int i = lane; i < n; i += 64) {
-            const int32_t id = (int32_t)(uint32_t)keys[start + i];
-            ids_sorted[start + i] = id;
-            masks[start + i] = entry_mask_rows(rows, packed, id, tx0, ty0);
-        }
+        sort_in_global<64>(keys + start, n, lane, ids_sorted + start, masks + start);
         return;
     }
-    const uint64_t *src = keys + start;
+    const uint4 *src = keys + start;
     uint64_t kk[PL];
+    uint32_t mm[PL / 2];   // the 16-bit masks, two to a register
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < PL / 2; j++) mm[j] = 0u;
 #pragma unroll
     for (int j = 0; j < PL; j++) {
         const int i = j * 64 + lane;
-        kk[j] = (i < n) ? src[i] : ~0ull;
+        uint4 r = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        if (i < n) r = src[i];
+        kk[j] = rec_key(r);
+        mm[j >> 1] |= (r.z & 0xFFFFu) << (16 * (j & 1));
         if (i < n) {
-            const uint32_t d = (uint32_t)(kk[j] >> 32);
-            mn = min(mn, d);
-            mx = max(mx, d);
+            mn = min(mn, r.x);
+            mx = max(mx, r.x);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -678,47 +720,30 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
         if (j * 64 + lane < n) {
             const int pos = atomicAdd(&cnt[((uint32_t)(kk[j] >> 32) - mn) >> shift], 1);
             out[pos] = kk[j];
+            outm[pos] = (uint16_t)(mm[j >> 1] >> (16 * (j & 1)));
         }
     __syncthreads();
     if (pathological) {
         int P = 2;
         while (P < n) P <<= 1;  // P <= CAP because n <= CAP and CAP is a power of two
-        for (int i = n + lane; i < P; i += 64) out[i] = ~0ull;
-        __syncthreads();
-        LdsKeys m{out};
+        LdsRecs m{out, outm, n};
         bitonic_sort(m, P, lane, 64);
     } else {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             if (local[j] < 2) continue;
             const int e = cnt[j * 64 + lane];  // cursor == end of the bucket
-            const int s0 = e - local[j];
-            for (int i = s0 + 1; i < e; i++) {  // insertion sort (local[j] <= kMaxBucket)
-                const uint64_t k = out[i];
-                int q = i - 1;
-                while (q >= s0 && out[q] > k) {
-                    out[q + 1] = out[q];
-                    q--;
-                }
-                out[q + 1] = k;
-            }
+            insertion_sort_bucket(out, outm, e - local[j], e);
         }
         __syncthreads();
     }
-    // the sorted ids, and beside each its coverage mask of the tile's 4x4-pixel blocks: the PL record
-    // gathers of a lane are independent (all in flight together), the masks are computed with every
-    // lane busy — as a kernel of its own (one wave looping over a tile's list) this took 46 us at C2
-    int32_t idv[PL];
 #pragma unroll
     for (int j = 0; j < PL; j++) {
         const int i = j * 64 + lane;
-        idv[j] = (i < n) ? (int32_t)(uint32_t)out[i] : -1;
-        if (i < n) ids_sorted[start + i] = idv[j];
-    }
-#pragma unroll
-    for (int j = 0; j < PL; j++) {
-        const int i = j * 64 + lane;
-        if (i < n) masks[start + i] = entry_mask_rows(rows, packed, idv[j], tx0, ty0);
+        if (i < n) {
+            ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
+            masks[start + i] = outm[i];
+        }
     }
 }
 
@@ -750,12 +775,12 @@ static int persistent_blocks(int N) {
     return b < 256 ? (b < 1 ? 1 : b) : 256;
 }
 
-// workspace layout: [ counters: tiles i32 | total: 1 i32 (+pad) | wg_base: 256 x tiles i32 | keys:
-// capacity u64 ].  gs_bin_scan uses the counters as per-tile intersection counts and leaves the
+// workspace layout: [ counters: tiles i32 | total: 1 i32 (+pad) | wg_base: 256 x tiles i32 | records:
+// capacity x 16 B ].  gs_bin_scan uses the counters as per-tile intersection counts and leaves the
 // per-(workgroup, tile) offsets in wg_base for the gs_bin_sort that follows: BOTH CALLS MUST BE GIVEN
 // THE SAME WORKSPACE (the offsets of the key array move with the capacity, wg_base does not).
 struct BinLayout {
-    size_t counters, total_dev, wg_base, rows, keys, total;
+    size_t counters, total_dev, wg_base, keys, total;
 };
 // What gs_bin_scan remembers (on the host, per workspace address) so that gs_bin_sort can tell that the
 // workspace it is handed holds the scan's leftovers — per-workgroup offsets, row tables — for the same
@@ -784,9 +809,8 @@ static BinLayout bin_layout(int N, int64_t capacity, int W, int H) {
     L.wg_base = L.total_dev + 256;
     // per-(workgroup, tile) offsets handed from the count to the scatter kernel (LDS variants only)
     const size_t base_bytes = tiles * 4 <= kMaxTileLds ? align_up((size_t)256 * tiles * 4) : 0;
-    L.rows = L.wg_base + base_bytes;
-    L.keys = L.rows + align_up((size_t)(N > 0 ? N : 1) * 16);
-    L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 8) + 256;
+    L.keys = L.wg_base + base_bytes;
+    L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 16) + 256;
     return L;
 }
 
@@ -841,12 +865,10 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
             const int blocks = gs::persistent_blocks(N);
             hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
                                reinterpret_cast<const float4 *>(packed), counts,
-                               reinterpret_cast<int32_t *>(base + L.wg_base),
-                               reinterpret_cast<uint4 *>(base + L.rows));
+                               reinterpret_cast<int32_t *>(base + L.wg_base));
         } else {
             hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
-                               tiles_x, reinterpret_cast<const float4 *>(packed), counts,
-                               reinterpret_cast<uint4 *>(base + L.rows));
+                               tiles_x, reinterpret_cast<const float4 *>(packed), counts);
         }
         GS_LAUNCH_CHECK();
     }
@@ -903,9 +925,8 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     if (!gs::workspace_matches(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N)}))
         return GS_ERR_WORKSPACE;
     char *base = static_cast<char *>(workspace);
-    const uint4 *rows = reinterpret_cast<const uint4 *>(base + L.rows);
     int32_t *fill = reinterpret_cast<int32_t *>(base + L.counters);
-    uint64_t *keys = reinterpret_cast<uint64_t *>(base + L.keys);
+    uint4 *keys = reinterpret_cast<uint4 *>(base + L.keys);
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const size_t lds = sizeof(int32_t) * (size_t)tiles;
     if (lds <= gs::kMaxTileLds) {
@@ -927,8 +948,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory
     int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
-    const float4 *pk = reinterpret_cast<const float4 *>(packed);
-    // Every class also writes the coverage masks of its segments (entry_mask_rows).
+    // Every class also moves the coverage masks (third word of the records) along with the keys.
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
     // longer: in place in global memory.  The launches for the longer classes are skipped when the
@@ -936,20 +956,20 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     const bool only_short = list_stats && list_stats[0] > 0 && list_stats[1] <= 400;
     if (!only_short) {
         hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, 0, tiles_x, bins_rw, keys, pk, rows, gaussian_ids_sorted, block_masks);
+                           capacity, 0, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
         constexpr int CAP = 8192, B = 4096, NT = 256;
-        const size_t lds = 8 * CAP + 4 * B + 64;
+        const size_t lds = 8 * CAP + 4 * B + 64 + 2 * CAP;
         GS_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
-                           CAP, capacity, tiles_x, bins, keys, pk, rows, gaussian_ids_sorted, block_masks);
+                           CAP, capacity, bins, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
     hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                       1, only_short ? 1 : 0, tiles_x, bins_rw, keys, pk, rows, gaussian_ids_sorted, block_masks);
+                       1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
