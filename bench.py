@@ -397,6 +397,95 @@ def algorithmic_bytes(N, K, M, P):
     return total, per_stage
 
 
+def kernel_tables(N, K, M, P, stage_ms, kernel_ms, profiled_name):
+    """(kernels, kernels_profiled, roofline_valu) for the JSON line.
+
+    kernels           what THIS run measured with HIP events on the launch stream: the four one-kernel
+                      stages and the binning stage (count + scan + scatter + per-tile sorts), each with
+                      its algorithmic bytes (SURVEY.md §8d split) and the HBM fraction
+    kernels_profiled  every gs:: kernel from the committed rocprofv3 passes of the same command
+                      (profiles/kernels*.json, scripts/summarize_profile.py): average duration, counter
+                      traffic, VALU issue occupancy
+    roofline_valu     the two compositing kernels are bound by VALU issue, not by HBM: of the issue slots
+                      they fill (valu_busy_frac) the fraction of lanes doing needed work (live_lane_frac,
+                      instrumented build) — useful_frac is their product, the number the kernel work of
+                      this repo moves"""
+    alg = {
+        "gaussian_fwd": ("k_sh_project_pack16 / k_gaussian_forward", N * (232 + 12) + N * (44 + 68)
+                         if K == 16 else N * (44 + 12 * K + 112)),
+        "bin_sort": ("k_count_tiles + k_scan_tiles + k_scatter + k_bucket_sort_*", N * 52 + 24 * M),
+        "rasterize_fwd": ("k_rasterize_forward", 40 * M + 20 * P),
+        "rasterize_bwd": ("k_rasterize_backward (+ record memset)", 40 * M + 20 * P + 36 * N),
+        "gaussian_bwd": ("k_gaussian_backward", N * (124 + 44 + 12 * K)),
+    }
+    kernels = []
+    for st, (kname, nbytes) in alg.items():
+        if st not in stage_ms:
+            continue
+        ms = stage_ms[st]
+        if st == "rasterize_fwd" and kernel_ms.get("k_rasterize_forward"):
+            ms = kernel_ms["k_rasterize_forward"]
+        if st == "rasterize_bwd" and kernel_ms.get("k_rasterize_backward"):
+            ms = kernel_ms["k_rasterize_backward"]
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+        kernels.append({"stage": st, "kernel": kname, "ms": ms, "algorithmic_bytes": nbytes,
+                        "hbm_GBs": gbs, "hbm_frac": None if gbs is None else gbs / HBM_PEAK_GBS,
+                        "timed_by": "HIP events, this run"})
+    prof, rv = None, None
+    path = os.path.join(ROOT, "profiles", profiled_name) if profiled_name else None
+    if path and os.path.exists(path):
+        try:
+            d = json.load(open(path))
+            prof = {"source": "profiles/%s (rocprofv3, tag %s)" % (profiled_name, d.get("tag")),
+                    "kernels": d["kernels"]}
+            rv = []
+            for k, e in sorted(d["kernels"].items()):
+                if k.startswith("k_rasterize_") and "valu_busy_of_8" in e:
+                    busy = min(e["valu_busy_of_8"] / 8.0, 1.0)
+                    live = e.get("live_lane_frac")
+                    rv.append({"kernel": k, "valu_busy_frac": busy, "live_lane_frac": live,
+                               "useful_frac": None if live is None else busy * live,
+                               "steps_per_list_entry": e.get("steps_per_list_entry"),
+                               "block_entries_per_list_entry": e.get("block_entries_per_list_entry")})
+        except Exception:
+            prof, rv = None, None
+    return kernels, prof, rv
+
+
+def operator_binning_probe(scene, dev, passes=3):
+    """The speculative binning as the C++ OPERATORS run it (RasterizeGaussians::apply through
+    torch.ops, torch_ops.cpp): the eight C4 cameras in shuffled order, `passes` times — forwards
+    repeated because the id-list capacity (running maximum per device and image size) was too small,
+    in the first pass and afterwards.  Outside the timed region."""
+    import torch
+
+    from opensplat_amd import ops, scenes
+
+    s = scene
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    means, scales, quats, opac = t(s.means), t(s.scales), t(s.quats), t(s.opacities)
+    colors = torch.rand((s.N, 3), device=dev)
+    bg = t(np.asarray(s.background, np.float32))
+    ops.binning_reset()
+    rs = np.random.RandomState(0)
+    per_pass = []
+    with torch.no_grad():
+        for _ in range(passes):
+            before = ops.binning_counters()[1]
+            for c in rs.permutation(8):
+                vm, pm = scenes.yaw_camera(s.W, s.H, scenes.C4_YAWS[c])
+                p = ops.project_gaussians(means, scales, 1.0, quats, t(vm), t(pm), s.fx, s.fy, s.cx, s.cy,
+                                          s.H, s.W)
+                ops.rasterize_gaussians(p[0], p[1], p[2], p[3], p[4], colors, opac, s.H, s.W, bg, p[6])
+            per_pass.append(ops.binning_counters()[1] - before)
+    torch.cuda.synchronize()
+    calls, repeats = ops.binning_counters()
+    return {"cameras": 8, "passes": passes, "order": "shuffled", "forwards": calls - repeats,
+            "repeated_forwards_per_pass": per_pass,
+            "capacity": ops.binning_capacity(dev.index or 0, s.W, s.H),
+            "policy": "running maximum of 1.125 M + 1024 per (device, width, height)"}
+
+
 def cpu_baseline(scene, n_sample):
     """OpenSplat's gsplat-cpu (oracle/_ref) or, if that build is absent, the C restatement."""
     import oracle
@@ -536,6 +625,24 @@ def main():
             last = j == cpr - 1
             pipe.step(ev if last else None, kev if last else None, accumulate=j > 0, exchange=last, slot=j)
 
+    if world > 1:
+        # who runs where, over what: printed (stderr) BEFORE anything is timed, so that a hang or a
+        # mis-mapped device is visible in the log of a multi-GPU run
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = "unknown"
+        info = [None] * world
+        torch.distributed.all_gather_object(info, {"rank": rank, "local_rank": local, "device": str(dev),
+                                                   "name": torch.cuda.get_device_name(dev),
+                                                   "pid": os.getpid()})
+        if rank == 0:
+            print("bench.py: backend=%s RCCL=%s world=%d exchange=%s cameras_per_rank=%d"
+                  % (backend, ver, world, "factored" if factored else "flat", cpr), file=sys.stderr)
+            for i in info:
+                print("bench.py:   rank %(rank)d -> %(device)s (%(name)s), local_rank %(local_rank)d, pid %(pid)d" % i,
+                      file=sys.stderr)
+            sys.stderr.flush()
     for _ in range(args.warmup):
         one_step()
     misses_warmup = pipe.misses
@@ -612,6 +719,9 @@ def main():
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
+        kernels, kernels_profiled, roofline_valu = kernel_tables(
+            N, K, M, P, stage_ms, kernel_ms,
+            None if not tname else ("kernels.json" if tname == "traffic.json" else "kernels_c3.json"))
         out = {
             "metric": "forward+backward rasterizations/sec at 1M Gaussians 1080p",
             "value": world * cpr * args.steps / elapsed,
@@ -627,7 +737,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "gaussians": N, "width": scene.W, "height": scene.H,
                        "sh_bases": K, "tile": 16, "intersections_M": M,
-                       "exp": "hardware v_exp_f32" if args.fast_exp else "glibc-bit-exact expf (parity mode)",
+                       "exp": ("hardware v_exp_f32 — NOT the parity mode: at C2 1 pixel of 2 073 600 changes "
+                               "its contributor set (1.4e-3), the others stay within 3.6e-7, gradients "
+                               "within 1.1e-3 of max|g| instead of 8e-7 (tests/test_gpu_parity_r03.py, "
+                               "profiles/parity_r03.json)") if args.fast_exp
+                       else "glibc-bit-exact expf (parity mode)",
                        "per_gaussian_stages": "separate kernels" if args.stage_kernels else
                        "fused (gs_gaussian_forward / gs_gaussian_backward)",
                        "parallelism": "camera-per-rank dp%d" % world,
@@ -641,6 +755,9 @@ def main():
                                  "required; traffic = rocprofv3 FETCH_SIZE x 1.18 (factor calibrated on "
                                  "48-byte record gathers, profiles/calib_r02.json) + WRITE_SIZE per "
                                  "launch from profiles/"},
+            "roofline_valu": roofline_valu,
+            "kernels": kernels,
+            "kernels_profiled": kernels_profiled,
             "kernel_ms": kernel_ms,
             # pixel x Gaussian evaluations per second of the compositing kernels, counted
             # as 256 pixels per (tile, Gaussian) list entry (the upper bound both kernels are sized by)
@@ -661,12 +778,20 @@ def main():
             "grad_bytes_allreduced": (0 if world == 1 else 11 * N * 4 if pipe.fx is not None
                                       else pipe.grads.nbytes),
             "allreduce_ms_rank0": stage_ms.get("allreduce", 0.0),
+            # the whole exchange (all-reduce [+ all-gather + SH backward over the gathered cameras]) as
+            # timed by HIP events on rank 0, apart from ms_per_step
+            "exchange_ms": stage_ms.get("allreduce", 0.0) if world > 1 else 0.0,
             # speculative binning: forwards repeated because the id list (sized from the previous
             # call, +12.5 %) was too small — during warm-up / inside the timed region
             "speculative_binning": {"misses_warmup": misses_warmup,
                                     "misses_timed": pipe.misses - misses_warmup,
                                     "id_list_capacity": pipe.ws.capacity},
         }
+        if world == 1 and plain and not sequence:
+            try:
+                out["speculative_binning"]["operator_path"] = operator_binning_probe(scene, dev)
+            except Exception as e:
+                out["speculative_binning"]["operator_path"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_gaussians)

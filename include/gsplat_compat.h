@@ -36,10 +36,10 @@ int gs_compat_map_intersects(int N, const float *xys, const float *depths, const
                              int64_t *isect_ids, int32_t *gaussian_ids, gs_stream_t stream);
 
 /* Replaces get_tile_bin_edges_tensor (bindings.h:106-109, forward.cu:148-176): [start, end) of
- * every tile's run in the sorted key list.  tile_bins [rows, 2] int32 must be zeroed by the caller
- * and have rows > the largest tile id present. */
+ * every tile's run in the sorted key list.  tile_bins [tile_bins_rows, 2] int32 must be zeroed by
+ * the caller; tile ids >= tile_bins_rows are skipped (the reference writes them unchecked). */
 int gs_compat_tile_bin_edges(int64_t num_intersects, const int64_t *isect_ids_sorted,
-                             int32_t *tile_bins, gs_stream_t stream);
+                             int32_t *tile_bins, int64_t tile_bins_rows, gs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,9 @@ int gs_dist_init(GsDistComm **comm, int world_size, int rank, const uint8_t id[G
                  int device);
 
 /* In-place sum over all ranks of buf[0 .. count), fp32, enqueued on `stream`; returns at once.
- * world_size 1: a no-op. */
+ * world_size 1: a no-op — unless the environment variable GSPLAT_DIST_FORCE_COLLECTIVES was set to a
+ * non-zero value when the communicator was created: RCCL's collective is then enqueued anyway (test
+ * aid for one-GPU boxes; the same holds for gs_dist_allgather). */
 int gs_dist_allreduce_sum(GsDistComm *comm, float *buf, size_t count, gs_stream_t stream);
 
 /* The same as n_buckets collectives over consecutive slices (boundaries on multiples of 1024

@@ -268,7 +268,12 @@ int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
 size_t gs_rasterize_backward_workspace_bytes(int N);
 /* workspace size under GS_FLAG_DETERMINISTIC: the float records followed by 64-bit fixed-point
  * accumulators (scale 2^40), into which the per-wave partial sums are added with integer atomics —
- * integer addition commutes, so the result does not depend on the order the waves arrive in. */
+ * integer addition commutes, so the result does not depend on the order the waves arrive in.
+ * Quantisation: each flushed partial sum (one per entry, wave and 64-entry chunk) is rounded to the
+ * nearest multiple of 2^-40 = 9.1e-13 and saturates at +-2^22; with cotangents of order 1 / (3 H W)
+ * (a mean-reduced image loss: 1.6e-7 at 1080p) a Gaussian's weakest contributions therefore carry a
+ * relative error of up to a few 1e-6 each — a debugging aid for race detection (a difference between
+ * two runs under the flag is a race, not summation order), not a precision mode. */
 size_t gs_rasterize_backward_workspace_bytes_det(int N);
 
 int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,

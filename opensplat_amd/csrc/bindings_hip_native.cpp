@@ -181,7 +181,7 @@ Tensor get_tile_bin_edges_tensor(int num_intersects, const Tensor &isect_ids_sor
     Tensor bins = torch::zeros({(int64_t)num_intersects + 65536, 2},
                                isect_ids_sorted.options().dtype(torch::kInt32));
     ok(gs_compat_tile_bin_edges(num_intersects, isect_ids_sorted.data_ptr<int64_t>(),
-                                bins.data_ptr<int32_t>(), stream()),
+                                bins.data_ptr<int32_t>(), bins.size(0), stream()),
        "gs_compat_tile_bin_edges");
     return bins;
 }

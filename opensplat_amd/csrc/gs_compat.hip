@@ -60,17 +60,21 @@ k_compat_map_intersects(int N, const float2 *__restrict__ xys, const float *__re
 }
 
 __global__ void __launch_bounds__(256)
-k_compat_tile_bin_edges(int64_t M, const int64_t *__restrict__ ids, int2 *__restrict__ bins) {
+k_compat_tile_bin_edges(int64_t M, int64_t rows, const int64_t *__restrict__ ids,
+                        int2 *__restrict__ bins) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    const int tile = (int)(ids[i] >> 32);
-    if (i == 0) bins[tile].x = 0;
-    if (i == M - 1) bins[tile].y = (int)M;
+    // a tile id outside the table is never written (the reference's kernel writes it unchecked,
+    // forward.cu:148-176, into a table of num_intersects rows, bindings.cu:324-326)
+    const int64_t tile = ids[i] >> 32;
+    const bool in = tile >= 0 && tile < rows;
+    if (i == 0 && in) bins[tile].x = 0;
+    if (i == M - 1 && in) bins[tile].y = (int)M;
     if (i > 0) {
-        const int prev = (int)(ids[i - 1] >> 32);
+        const int64_t prev = ids[i - 1] >> 32;
         if (prev != tile) {
-            bins[prev].y = (int)i;
-            bins[tile].x = (int)i;
+            if (prev >= 0 && prev < rows) bins[prev].y = (int)i;
+            if (in) bins[tile].x = (int)i;
         }
     }
 }
@@ -105,13 +109,14 @@ extern "C" int gs_compat_map_intersects(int N, const float *xys, const float *de
 }
 
 extern "C" int gs_compat_tile_bin_edges(int64_t num_intersects, const int64_t *isect_ids_sorted,
-                                        int32_t *tile_bins, gs_stream_t stream) {
-    if (num_intersects < 0) return GS_ERR_INVALID_ARGUMENT;
+                                        int32_t *tile_bins, int64_t tile_bins_rows,
+                                        gs_stream_t stream) {
+    if (num_intersects < 0 || tile_bins_rows < 0) return GS_ERR_INVALID_ARGUMENT;
     if (num_intersects == 0) return GS_OK;
     if (!isect_ids_sorted || !tile_bins) return GS_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(gs::k_compat_tile_bin_edges, dim3((unsigned)((num_intersects + 255) / 256)),
-                       dim3(256), 0, (hipStream_t)stream, num_intersects, isect_ids_sorted,
-                       reinterpret_cast<int2 *>(tile_bins));
+                       dim3(256), 0, (hipStream_t)stream, num_intersects, tile_bins_rows,
+                       isect_ids_sorted, reinterpret_cast<int2 *>(tile_bins));
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

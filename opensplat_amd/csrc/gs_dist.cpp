@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -13,6 +14,10 @@
 struct GsDistComm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
+    // GSPLAT_DIST_FORCE_COLLECTIVES=1 (read at gs_dist_init): a one-rank communicator really enqueues
+    // ncclAllReduce / ncclAllGather instead of taking the world == 1 shortcuts — so that RCCL's
+    // kernels run at least once on a one-GPU test box (tests/test_gpu_dist_cabi.py)
+    bool force = false;
 };
 
 namespace {
@@ -52,6 +57,8 @@ extern "C" int gs_dist_init(GsDistComm **comm, int world_size, int rank, const u
     c->world = world_size;
     c->rank = rank;
     c->device = device;
+    const char *f = std::getenv("GSPLAT_DIST_FORCE_COLLECTIVES");
+    c->force = f && f[0] && f[0] != '0';
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     const ncclResult_t r = ncclCommInitRank(&c->comm, world_size, u, rank);
@@ -65,7 +72,7 @@ extern "C" int gs_dist_init(GsDistComm **comm, int world_size, int rank, const u
 
 extern "C" int gs_dist_allreduce_sum(GsDistComm *comm, float *buf, size_t count, gs_stream_t stream) {
     if (!comm || (!buf && count)) return GS_ERR_INVALID_ARGUMENT;
-    if (count == 0 || comm->world == 1) return GS_OK;
+    if (count == 0 || (comm->world == 1 && !comm->force)) return GS_OK;
     const ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, comm->comm, (hipStream_t)stream);
     if (r != ncclSuccess) return fail_nccl(r, "ncclAllReduce");
     return GS_OK;
@@ -96,7 +103,7 @@ extern "C" int gs_dist_allgather(GsDistComm *comm, const float *send, float *rec
                                  gs_stream_t stream) {
     if (!comm || ((!send || !recv) && count)) return GS_ERR_INVALID_ARGUMENT;
     if (count == 0) return GS_OK;
-    if (comm->world == 1) {
+    if (comm->world == 1 && !comm->force) {
         if (send == recv) return GS_OK;
         const hipError_t e = hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice,
                                             (hipStream_t)stream);

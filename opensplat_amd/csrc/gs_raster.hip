@@ -641,7 +641,11 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 if (v != 0.0f) {
                     const size_t o = (size_t)sid[ent] * kGradRec + fcomp;
                     if (DET)
-                        atomicAdd(gfix + o, (unsigned long long)(long long)(v * kFixScale));
+                        // round to nearest (a truncating convert biases every sum towards zero) and
+                        // saturate at +-2^62 (a float beyond int64 is undefined in the convert): the
+                        // quantum is 2^-40 = 9.1e-13 per flushed partial sum, |sums| up to 2^22
+                        atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
+                                                fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
                     else
                         atomicAdd(gacc + o, v);
                 }

@@ -128,6 +128,42 @@ def main():
     tname = "traffic_f2.json" if tag.startswith("f2") else \
         ("traffic_%s.json" % tag.split("_", 1)[1] if "_" in tag else "traffic.json")
     (dst / tname).write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
+    # every gs:: kernel of the step in one small file that bench.py attaches to its JSON line
+    # (`kernels_profiled`, `roofline_valu`): rocprofv3 average duration, measured HBM bytes, the VALU
+    # issue occupancy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, 8 = every SIMD issuing all the time as
+    # the counters are normalised on gfx950) and — from the instrumented build's work counters
+    # (scripts/work_stats.py -> profiles/work_stats_<tag>_<cfg>.json) — the fraction of lanes that do
+    # needed work in a compositing step.
+    kern = {}
+    for name in avg:
+        m = re.search(r"gs::(k_\w+)(<[^>(]*>)?", name)
+        if not m:
+            continue
+        key = m.group(1) + (m.group(2) or "")
+        d = out.get(name[:200], {})
+        e = {"calls": calls[name], "avg_us": avg[name] / 1e3}
+        if "hbm_read_bytes_corrected" in d:
+            e["hbm_read_bytes"] = d["hbm_read_bytes_corrected"]
+        if "hbm_write_bytes" in d:
+            e["hbm_write_bytes"] = d["hbm_write_bytes"]
+        if d.get("SQ_BUSY_CYCLES"):
+            e["valu_busy_of_8"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_BUSY_CYCLES"]
+            e["valu_insts_per_launch"] = d.get("SQ_INSTS_VALU")
+        if d.get("SQ_WAVE_CYCLES"):
+            e["wait_any_frac"] = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
+        kern[key] = e
+    cfg = tag.split("_", 1)[1] if "_" in tag else "c2"
+    ws = dst / ("work_stats_%s_%s.json" % (tag.split("_")[0], cfg))
+    if ws.exists():
+        w = json.loads(ws.read_text())
+        for k, side in (("k_rasterize_forward", "forward"), ("k_rasterize_backward", "backward")):
+            for key in kern:
+                if key.startswith(k):
+                    kern[key]["live_lane_frac"] = w[side]["live_lanes_per_needing_step"] / 64.0
+                    kern[key]["steps_per_list_entry"] = w[side]["steps_per_list_entry"]
+                    kern[key]["block_entries_per_list_entry"] = w[side]["block_entries"] / max(w["M"], 1)
+    kname = "kernels.json" if "_" not in tag else "kernels_%s.json" % cfg
+    (dst / kname).write_text(json.dumps({"tag": tag, "kernels": kern}, indent=1, sort_keys=True) + "\n")
     print("\n".join(lines))
 
 

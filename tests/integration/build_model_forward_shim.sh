@@ -12,7 +12,8 @@ mkdir -p $OUT/overlay/gsplat $OUT/overlay/gsplat-cpu
 python3 $ROOT/integration/apply_hip_native.py $REF --out $OUT/overlay
 cp $REF/rasterizer/gsplat/config.h $OUT/overlay/gsplat/
 cp $REF/rasterizer/gsplat-cpu/bindings.h $OUT/overlay/gsplat-cpu/
-CXXFLAGS="-std=c++17 -O1 -w -D_GLIBCXX_USE_CXX11_ABI=1 -DUSE_HIP -DUSE_HIP_NATIVE -D__HIP_PLATFORM_AMD__=1 \
+ABI=${GS_CXX11_ABI:-$(python3 -c "import torch;print(int(torch._C._GLIBCXX_USE_CXX11_ABI))")}
+CXXFLAGS="-std=c++17 -O1 -w -D_GLIBCXX_USE_CXX11_ABI=$ABI -DUSE_HIP -DUSE_HIP_NATIVE -D__HIP_PLATFORM_AMD__=1 \
   -I$OUT/overlay -I$CSRC -I$TORCH/include -I$TORCH/include/torch/csrc/api/include -I/opt/rocm/include"
 pids=""
 for f in project_gaussians rasterize_gaussians spherical_harmonics; do

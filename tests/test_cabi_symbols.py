@@ -134,7 +134,7 @@ def test_every_header_under_include_is_exported():
     assert l.gs_compat_tiles_hit(-1, one, one, 4, 4, one, null) == -1
     assert l.gs_compat_tiles_hit(0, null, null, 4, 4, null, null) == 0
     assert l.gs_compat_map_intersects(5, one, one, one, null, 4, 4, one, one, null) == -1
-    assert l.gs_compat_tile_bin_edges(ctypes.c_int64(0), null, null, null) == 0
+    assert l.gs_compat_tile_bin_edges(ctypes.c_int64(0), null, null, ctypes.c_int64(0), null) == 0
 
 
 def test_launcher_level_functions_are_registered():

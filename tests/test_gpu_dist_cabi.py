@@ -47,6 +47,48 @@ def test_one_rank_communicator_through_the_c_abi():
     assert l.gs_dist_destroy(comm) == 0
 
 
+def test_rccl_collectives_really_execute_on_a_one_rank_communicator(monkeypatch):
+    """GSPLAT_DIST_FORCE_COLLECTIVES=1: the world == 1 shortcuts are off, ncclAllReduce and ncclAllGather
+    are enqueued on the stream and run on the GPU (inside this repo RCCL had never executed
+    a collective).  Over one rank the sum is the identity and the gather a copy — checked, along with
+    in-place gathering and the bucketed form; the libtorch class takes the same path."""
+    import torch
+
+    from opensplat_amd import cabi, ops  # noqa: F401
+
+    monkeypatch.setenv("GSPLAT_DIST_FORCE_COLLECTIVES", "1")
+    l = cabi.dist_lib()
+    ident = (C.c_uint8 * 128)()
+    assert l.gs_dist_unique_id(ident) == 0
+    comm = C.c_void_p(0)
+    assert l.gs_dist_init(C.byref(comm), 1, 0, ident, 0) == 0, l.gs_dist_last_error()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(11 * 1_000_000, device="cuda")          # the geometry block of C2: 44 MB
+    ref = x.clone()
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    assert l.gs_dist_allreduce_sum(comm, C.c_void_p(x.data_ptr()), x.numel(), s) == 0, l.gs_dist_last_error()
+    t1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    assert t0.elapsed_time(t1) > 0.005          # a kernel ran: the shortcut returns in ~0 ms of stream time
+    assert l.gs_dist_allreduce_sum_buckets(comm, C.c_void_p(x.data_ptr()), x.numel(), 4, None, s) == 0
+    msg = torch.randn(4 + 3 * 100_000, device="cuda")
+    out = torch.zeros_like(msg)
+    assert l.gs_dist_allgather(comm, C.c_void_p(msg.data_ptr()), C.c_void_p(out.data_ptr()), msg.numel(), s) == 0
+    assert l.gs_dist_allgather(comm, C.c_void_p(msg.data_ptr()), C.c_void_p(msg.data_ptr()), msg.numel(), s) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(out, msg)
+    assert l.gs_dist_destroy(comm) == 0
+    # the libtorch class (GradExchange) creates its own communicator: the variable applies there too
+    y = torch.randn(59 * 1001, device="cuda")
+    yr = y.clone()
+    z = torch.ops.opensplat_amd.grad_exchange_selftest(y, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(z, yr)
+
+
 def test_grad_exchange_class_of_the_libtorch_surface():
     import torch
 
