@@ -361,16 +361,95 @@ def decode_jpeg(blob: bytes) -> np.ndarray:
     return out
 
 
+def exif_orientation(blob: bytes) -> int:
+    """EXIF Orientation (tag 0x0112 of IFD0 in a JPEG's APP1 "Exif" segment), 1 when absent or
+    malformed — what cv::imread reads before rotating the decoded picture (grfmt_jpeg / exif.cpp)."""
+    import struct
+
+    pos, n = 2, len(blob)
+    while pos + 4 <= n and blob[pos] == 0xFF:
+        marker = blob[pos + 1]
+        if marker in (0xD8, 0x01) or 0xD0 <= marker <= 0xD7:
+            pos += 2
+            continue
+        if marker == 0xDA or marker == 0xD9:            # start of scan / end: no EXIF further on
+            break
+        seglen = struct.unpack(">H", blob[pos + 2:pos + 4])[0]
+        seg = blob[pos + 4:pos + 2 + seglen]
+        pos += 2 + seglen
+        if marker != 0xE1 or seg[:6] != b"Exif\x00\x00":
+            continue
+        t = seg[6:]
+        if len(t) < 8 or t[:2] not in (b"II", b"MM"):
+            return 1
+        e = "<" if t[:2] == b"II" else ">"
+        if struct.unpack(e + "H", t[2:4])[0] != 42:
+            return 1
+        ifd = struct.unpack(e + "I", t[4:8])[0]
+        if ifd + 2 > len(t):
+            return 1
+        cnt = struct.unpack(e + "H", t[ifd:ifd + 2])[0]
+        for k in range(cnt):
+            ent = t[ifd + 2 + 12 * k: ifd + 14 + 12 * k]
+            if len(ent) < 12:
+                return 1
+            tag, typ, num = struct.unpack(e + "HHI", ent[:8])
+            if tag == 0x0112 and typ == 3 and num == 1:
+                v = struct.unpack(e + "H", ent[8:10])[0]
+                return v if 1 <= v <= 8 else 1
+        return 1
+    return 1
+
+
+def apply_exif_orientation(img: np.ndarray, orientation: int) -> np.ndarray:
+    """OpenCV's ExifTransform (imgcodecs/src/loadsave.cpp): transpose and / or flips per orientation."""
+    if orientation == 2:
+        img = img[:, ::-1]
+    elif orientation == 3:
+        img = img[::-1, ::-1]
+    elif orientation == 4:
+        img = img[::-1]
+    elif orientation == 5:
+        img = img.transpose(1, 0, 2)
+    elif orientation == 6:
+        img = img.transpose(1, 0, 2)[:, ::-1]
+    elif orientation == 7:
+        img = img.transpose(1, 0, 2)[::-1, ::-1]
+    elif orientation == 8:
+        img = img.transpose(1, 0, 2)[::-1]
+    return np.ascontiguousarray(img)
+
+
+def _decode_jpeg_any(blob: bytes) -> np.ndarray:
+    """Baseline JPEGs go through the in-tree decoder (bit-exact against libjpeg).  Progressive,
+    arithmetic-coded, 12-bit or CMYK files — which it refuses — are handed to Pillow when that is
+    installed (it wraps the same libjpeg cv::imread uses); without it the error says what to do."""
+    try:
+        return decode_jpeg(blob)
+    except ValueError as e:
+        try:
+            import io
+
+            from PIL import Image
+        except ImportError:
+            raise ValueError("%s — this file needs a full JPEG decoder: install Pillow, or re-encode the "
+                             "capture as baseline JPEG / PNG" % e) from None
+        im = Image.open(io.BytesIO(blob))
+        im.draft("RGB", im.size)
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
 def read_image_u8(path: str) -> np.ndarray:
-    """[H, W, 3] uint8 RGB from baseline JPEG, PNG, binary PPM (P6) or .npy (uint8 or float in
-    [0, 1]) — imreadRGB (cv_utils.cpp:3-14) without OpenCV."""
+    """[H, W, 3] uint8 RGB from JPEG, PNG, binary PPM (P6) or .npy (uint8 or float in [0, 1]) —
+    imreadRGB (cv_utils.cpp:3-14) without OpenCV, including the EXIF orientation cv::imread applies to
+    JPEGs."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
         a = np.load(path)
         return a if a.dtype == np.uint8 else np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
     blob = open(path, "rb").read()
     if ext in (".jpg", ".jpeg", ".jpe") or blob[:2] == b"\xff\xd8":
-        return decode_jpeg(blob)
+        return apply_exif_orientation(_decode_jpeg_any(blob), exif_orientation(blob))
     if ext == ".png":
         return _decode_png(blob)
     if ext in (".ppm", ".pnm") and blob[:2] == b"P6":
@@ -393,114 +472,162 @@ def read_image_u8(path: str) -> np.ndarray:
 
 
 def downscale_area(img_u8: np.ndarray, factor: int) -> np.ndarray:
-    """Integer-factor box average (what cv::INTER_AREA computes for integer factors), uint8 out."""
+    """Camera::getImage's pyramid level (input_data.cpp:112): cv::resize to (cols / factor, rows / factor)
+    with INTER_AREA."""
     if factor <= 1:
         return img_u8
-    return resize_area(img_u8, int(round(img_u8.shape[1] / factor)), int(round(img_u8.shape[0] / factor)),
-                       scale=float(factor))
+    return resize_area(img_u8, img_u8.shape[1] // factor, img_u8.shape[0] // factor)
 
 
 def _area_table(ssize: int, dsize: int, scale: float):
-    """1-D INTER_AREA decomposition: for every destination index the source indices it covers and
-    their weights (cell [d * scale, (d + 1) * scale), partial pixels weighted by their overlap)."""
-    idx, wts = [], []
-    for d in range(dsize):
-        f1 = d * scale
-        f2 = min(f1 + scale, float(ssize))
-        cell = min(scale, ssize - f1)
-        s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
-        s2 = min(s2, ssize - 1) if s2 >= ssize else s2
-        s1 = min(s1, s2)
-        ii, ww = [], []
-        if s1 - f1 > 1e-3:
-            ii.append(s1 - 1); ww.append((s1 - f1) / cell)
-        for sx in range(s1, s2):
-            ii.append(sx); ww.append(1.0 / cell)
-        if f2 - s2 > 1e-3 and s2 < ssize:
-            ii.append(s2); ww.append(min(min(f2 - s2, 1.0), cell) / cell)
-        idx.append(ii); wts.append(ww)
-    return idx, wts
+    """computeResizeAreaTab (OpenCV resize.cpp): (dst index, src index, weight) triples in OpenCV's
+    order; the weights are float32 like OpenCV's."""
+    tab = []
+    for dx in range(dsize):
+        fsx1 = dx * scale
+        fsx2 = fsx1 + scale
+        cell = min(scale, ssize - fsx1)
+        sx1, sx2 = int(np.ceil(fsx1)), int(np.floor(fsx2))
+        sx2 = min(sx2, ssize - 1)
+        sx1 = min(sx1, sx2)
+        if sx1 - fsx1 > 1e-3:
+            tab.append((dx, sx1 - 1, np.float32((sx1 - fsx1) / cell)))
+        for sx in range(sx1, sx2):
+            tab.append((dx, sx, np.float32(1.0 / cell)))
+        if fsx2 - sx2 > 1e-3:
+            tab.append((dx, sx2, np.float32(min(min(fsx2 - sx2, 1.0), cell) / cell)))
+    return tab
 
 
-def resize_area(img_u8: np.ndarray, dst_w: int, dst_h: int, scale: float | None = None) -> np.ndarray:
-    """cv::resize(..., INTER_AREA) for down-scaling ([H, W, C] uint8).  scale = source pixels per
-    destination pixel (both axes); default src / dst per axis, as cv::resize derives it from dsize.
+def _round_half_even_u8(a):
+    return np.clip(np.rint(a), 0, 255).astype(np.uint8)          # saturate_cast<uchar>(float) = cvRound
 
-    Integer scales: the mean of the scale x scale box — (sum + 2) >> 2 for 2 x 2 boxes, round-to-nearest-
-    even of sum / area otherwise (the two code paths of OpenCV's ResizeAreaFast for 8-bit images);
-    other scales: area-weighted mean in float32.  PARITY UNPINNED: written from OpenCV's documented
-    behaviour, no OpenCV in this environment to generate fixtures from."""
-    sh, sw = img_u8.shape[:2]
-    sx = scale if scale is not None else sw / float(dst_w)
-    sy = scale if scale is not None else sh / float(dst_h)
-    ix, iy = int(round(sx)), int(round(sy))
-    src = img_u8.astype(np.float32)
-    if abs(sx - ix) < 1e-9 and abs(sy - iy) < 1e-9 and ix >= 1 and iy >= 1:
-        fw, fh = min(dst_w, sw // ix), min(dst_h, sh // iy)
-        out = np.zeros((dst_h, dst_w, img_u8.shape[2]), np.uint8)
-        box = img_u8[:fh * iy, :fw * ix].astype(np.uint32).reshape(fh, iy, fw, ix, -1).sum((1, 3))
-        if ix == 2 and iy == 2:
-            out[:fh, :fw] = ((box + 2) >> 2).astype(np.uint8)
-        else:
-            out[:fh, :fw] = np.rint(box.astype(np.float32) * np.float32(1.0 / (ix * iy))).astype(np.uint8)
-        # a last partial row / column (source size not a multiple of the factor): mean of what is left
-        for dy in range(dst_h):
-            for dx in range(dst_w):
-                if dy < fh and dx < fw:
-                    continue
-                blk = src[dy * iy:min((dy + 1) * iy, sh), dx * ix:min((dx + 1) * ix, sw)]
-                if blk.size:
-                    out[dy, dx] = np.rint(blk.reshape(-1, blk.shape[-1]).sum(0) / np.float32(blk.shape[0] * blk.shape[1]))
+
+def resize_area(img_u8: np.ndarray, dst_w: int | None = None, dst_h: int | None = None,
+                inv_scale: float | None = None) -> np.ndarray:
+    """cv::resize(src, dst, dsize, inv_scale, inv_scale, INTER_AREA) for down-scaling, [H, W, 3] uint8.
+
+    Either the destination size is given (Camera::getImage, input_data.cpp:112) or the scale factor
+    (Camera::loadImage: cv::Size(), 1 / downscaleFactor as float, input_data.cpp:54-61; the size is then
+    cvRound(src * inv_scale)).  Follows OpenCV 4.5.4's resize.cpp step for step: integer scale ratios
+    (|scale - round(scale)| < DBL_EPSILON) take ResizeAreaFast — (a + b + c + d + 2) >> 2 for 2 x 2
+    boxes (the SIMD path), float32 sum * (1 / area) rounded half-to-even otherwise, partial boxes at the
+    right / bottom edge averaged over the pixels they hold; every other ratio takes ResizeArea with
+    computeResizeAreaTab's float32 weights, accumulated in float32 in OpenCV's order.
+    PINNED TO THE PUBLISHED ALGORITHM (oracle/image_oracle.c restates the same sources in C and
+    tests/test_image.py requires bit equality); no OpenCV build was available to pin against."""
+    sh, sw, cn = img_u8.shape
+    if dst_w is None or dst_h is None or dst_w <= 0 or dst_h <= 0:
+        inv_x = inv_y = float(inv_scale)
+        dst_w, dst_h = int(np.rint(sw * inv_x)), int(np.rint(sh * inv_y))
+    else:
+        inv_x, inv_y = dst_w / float(sw), dst_h / float(sh)
+    sx, sy = 1.0 / inv_x, 1.0 / inv_y
+    if not (sx >= 1 and sy >= 1):
+        raise ValueError("resize_area only down-scales (INTER_AREA up-scaling is bilinear in OpenCV)")
+    ix, iy = int(np.rint(sx)), int(np.rint(sy))
+    eps = np.finfo(np.float64).eps
+    out = np.zeros((dst_h, dst_w, cn), np.uint8)
+    if abs(sx - ix) < eps and abs(sy - iy) < eps:
+        area = ix * iy
+        scale = np.float32(1.0) / np.float32(area)
+        fw = min(sw // ix, dst_w)                     # columns whose box is complete
+        fh = min(sh // iy, dst_h)                     # rows whose box is complete (w = dwidth1 there)
+        if fw and fh:
+            box = img_u8[:fh * iy, :fw * ix].astype(np.int32).reshape(fh, iy, fw, ix, cn).sum((1, 3))
+            out[:fh, :fw] = ((box + 2) >> 2).astype(np.uint8) if (ix == 2 and iy == 2) else \
+                _round_half_even_u8(box.astype(np.float32) * scale)
+        src = img_u8.astype(np.int32)
+
+        def partial(dy0, dy1, dx0, dx1):              # boxes clipped by the image edge: mean of what is there
+            for dy in range(dy0, dy1):
+                y0 = dy * iy
+                if y0 >= sh:
+                    continue                          # (row stays zero)
+                ys = src[y0:min(y0 + iy, sh)]
+                for dx in range(dx0, dx1):
+                    x0 = dx * ix
+                    if x0 >= sw:
+                        continue
+                    blk = ys[:, x0:min(x0 + ix, sw)]
+                    cnt = blk.shape[0] * blk.shape[1]
+                    out[dy, dx] = _round_half_even_u8(blk.sum((0, 1)).astype(np.float32) / np.float32(cnt))
+        partial(0, fh, fw, dst_w)                     # right edge of the complete rows
+        partial(fh, dst_h, 0, dst_w)                  # rows below the last complete one: every box partial
         return out
-    xi, xw = _area_table(sw, dst_w, sx)
-    yi, yw = _area_table(sh, dst_h, sy)
-    rows = np.zeros((sh, dst_w, img_u8.shape[2]), np.float32)
-    for d in range(dst_w):
-        for i, w in zip(xi[d], xw[d]):
-            rows[:, d] += src[:, i] * np.float32(w)
-    out = np.zeros((dst_h, dst_w, img_u8.shape[2]), np.float32)
-    for d in range(dst_h):
-        for i, w in zip(yi[d], yw[d]):
-            out[d] += rows[i] * np.float32(w)
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    xtab = _area_table(sw, dst_w, sx)
+    ytab = _area_table(sh, dst_h, sy)
+    src = img_u8.astype(np.float32)
+    buf = np.zeros((sh, dst_w, cn), np.float32)       # the x pass of every source row
+    for dx, si, alpha in xtab:
+        buf[:, dx] += src[:, si] * alpha
+    acc = np.zeros((dst_h, dst_w, cn), np.float32)
+    first = np.ones(dst_h, bool)
+    for dy, si, beta in ytab:
+        if first[dy]:
+            acc[dy] = beta * buf[si]
+            first[dy] = False
+        else:
+            acc[dy] += beta * buf[si]
+    return _round_half_even_u8(acc)
 
 
 # ---- lens undistortion (cv::getOptimalNewCameraMatrix + cv::undistort, input_data.cpp:66-80) ----------
+def _dist8(dist):
+    """(k1, k2, p1, p2, k3[, k4, k5, k6]) -> 8 float64 coefficients that went through float32, like
+    Camera::undistortionParameters' std::vector<float> (input_data.cpp:123-126)."""
+    d = np.zeros(8, np.float64)
+    d[:len(dist)] = np.asarray(dist, np.float32).astype(np.float64)
+    return d
+
+
 def _distort(x, y, dist):
-    """Brown-Conrady model OpenCV uses: normalised pinhole (x, y) -> distorted normalised coordinates.
-    dist = (k1, k2, p1, p2, k3)."""
-    k1, k2, p1, p2, k3 = dist
-    r2 = x * x + y * y
-    kr = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2
-    xd = x * kr + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
-    yd = y * kr + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    """Brown-Conrady model as initUndistortRectifyMap evaluates it: normalised pinhole (x, y) ->
+    distorted normalised coordinates."""
+    k1, k2, p1, p2, k3, k4, k5, k6 = _dist8(dist)
+    x2, y2 = x * x, y * y
+    r2, _2xy = x2 + y2, 2 * x * y
+    kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
     return xd, yd
 
 
 def undistort_points(u, v, K, dist, newK=None, iters: int = 5):
-    """cv::undistortPoints: distorted pixel coordinates -> ideal pixel coordinates of camera newK
-    (normalised coordinates when newK is None); fixed-point iteration, 5 rounds like OpenCV."""
-    k1, k2, p1, p2, k3 = dist
+    """cvUndistortPointsInternal with TermCriteria(COUNT, 5): distorted pixel coordinates -> ideal pixel
+    coordinates of camera newK (normalised coordinates when newK is None).  float64 throughout."""
+    k = _dist8(dist)
+    K = np.asarray(K, np.float64)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
-    x0 = (np.asarray(u, np.float64) - cx) / fx
-    y0 = (np.asarray(v, np.float64) - cy) / fy
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    u, v = np.asarray(u, np.float64), np.asarray(v, np.float64)
+    x0, y0 = (u - cx) * ifx, (v - cy) * ify
     x, y = x0.copy(), y0.copy()
+    done = np.zeros(x.shape, bool)                   # points that hit icdist < 0 keep their start value
     for _ in range(iters):
         r2 = x * x + y * y
-        icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
-        dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
-        dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
-        x = (x0 - dx) * icdist
-        y = (y0 - dy) * icdist
+        icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        bad = (icdist < 0) & ~done
+        dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        xn, yn = (x0 - dx) * icdist, (y0 - dy) * icdist
+        x = np.where(done, x, np.where(bad, x0, xn))
+        y = np.where(done, y, np.where(bad, y0, yn))
+        done |= bad
     if newK is None:
         return x, y
-    return x * newK[0, 0] + newK[0, 2], y * newK[1, 1] + newK[1, 2]
+    P = np.asarray(newK, np.float64)
+    xx, yy = P[0, 0] * x + P[0, 1] * y + P[0, 2], P[1, 0] * x + P[1, 1] * y + P[1, 2]
+    ww = 1.0 / (P[2, 0] * x + P[2, 1] * y + P[2, 2])
+    return xx * ww, yy * ww
 
 
 def _inner_outer_rect(K, dist, newK, W, H, n: int = 9):
-    """icvGetRectangles: the 9 x 9 grid of image points undistorted; inner = largest rectangle inside
-    the undistorted border, outer = its bounding box.  (x, y, w, h) each."""
-    gx, gy = np.meshgrid(np.arange(n) * (W / (n - 1.0)), np.arange(n) * (H / (n - 1.0)))
+    """icvGetRectangles (OpenCV 4.5.4 calibration.cpp): the 9 x 9 grid over [0, W-1] x [0, H-1]
+    undistorted; inner = largest rectangle inside the undistorted border, outer = its bounding box.
+    (x, y, w, h) each, float64."""
+    gx, gy = np.meshgrid(np.arange(n, dtype=np.float64) * (W - 1) / (n - 1),
+                         np.arange(n, dtype=np.float64) * (H - 1) / (n - 1))
     px, py = undistort_points(gx, gy, K, dist, newK)
     ix0, ix1 = px[:, 0].max(), px[:, -1].min()
     iy0, iy1 = py[0, :].max(), py[-1, :].min()
@@ -509,57 +636,87 @@ def _inner_outer_rect(K, dist, newK, W, H, n: int = 9):
 
 
 def optimal_new_camera_matrix(K, dist, W: int, H: int, alpha: float = 0.0):
-    """cv::getOptimalNewCameraMatrix(K, dist, (W, H), alpha, (W, H), &roi): the camera matrix whose
-    image shows (alpha = 0) only valid pixels of the undistorted image, and the valid-pixel ROI
-    (x, y, w, h).  PARITY UNPINNED (see resize_area)."""
-    K = np.asarray(K, np.float64)
+    """cv::getOptimalNewCameraMatrix(K, dist, (W, H), alpha, Size(), &roi) as OpenCV 4.5.4 computes it:
+    the camera matrix whose image shows (alpha = 0) only valid pixels of the undistorted image —
+    returned in K's type, float32 — and the valid-pixel ROI (x, y, w, h): the inner rectangle under the
+    float64 matrix, each component rounded to nearest (cv::Rect r = inner), clipped to the image.
+    PINNED TO THE PUBLISHED ALGORITHM (oracle/image_oracle.c)."""
+    K = np.asarray(K, np.float32).astype(np.float64)
     inner, outer = _inner_outer_rect(K, dist, None, W, H)
     fx0, fy0 = (W - 1) / inner[2], (H - 1) / inner[3]
     cx0, cy0 = -fx0 * inner[0], -fy0 * inner[1]
     fx1, fy1 = (W - 1) / outer[2], (H - 1) / outer[3]
     cx1, cy1 = -fx1 * outer[0], -fy1 * outer[1]
-    newK = np.eye(3)
-    newK[0, 0] = fx0 * (1 - alpha) + fx1 * alpha
-    newK[1, 1] = fy0 * (1 - alpha) + fy1 * alpha
-    newK[0, 2] = cx0 * (1 - alpha) + cx1 * alpha
-    newK[1, 2] = cy0 * (1 - alpha) + cy1 * alpha
-    inner2, _ = _inner_outer_rect(K, dist, newK, W, H)
-    x, y = int(np.ceil(inner2[0])), int(np.ceil(inner2[1]))
-    w, h = int(np.floor(inner2[2])), int(np.floor(inner2[3]))
+    M = K.copy()
+    M[0, 0] = fx0 * (1 - alpha) + fx1 * alpha
+    M[1, 1] = fy0 * (1 - alpha) + fy1 * alpha
+    M[0, 2] = cx0 * (1 - alpha) + cx1 * alpha
+    M[1, 2] = cy0 * (1 - alpha) + cy1 * alpha
+    inner2, _ = _inner_outer_rect(K, dist, M, W, H)
+    x, y, w, h = (int(np.rint(c)) for c in inner2)
     x0, y0 = max(x, 0), max(y, 0)
     x1, y1 = min(x + w, W), min(y + h, H)
-    roi = (x0, y0, max(x1 - x0, 0), max(y1 - y0, 0))
-    return newK.astype(np.float32), roi
+    roi = (x0, y0, x1 - x0, y1 - y0) if (x1 > x0 and y1 > y0) else (0, 0, 0, 0)
+    return M.astype(np.float32), roi
+
+
+def _invert3(S):
+    """cv::invert for a 3 x 3 double matrix (closed form, lapack.cpp)."""
+    S = S.ravel()
+    d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6])
+    d = 1.0 / d
+    return np.array([(S[4] * S[8] - S[5] * S[7]) * d, (S[2] * S[7] - S[1] * S[8]) * d, (S[1] * S[5] - S[2] * S[4]) * d,
+                     (S[5] * S[6] - S[3] * S[8]) * d, (S[0] * S[8] - S[2] * S[6]) * d, (S[2] * S[3] - S[0] * S[5]) * d,
+                     (S[3] * S[7] - S[4] * S[6]) * d, (S[1] * S[6] - S[0] * S[7]) * d, (S[0] * S[4] - S[1] * S[3]) * d])
 
 
 def undistort_image(img_u8: np.ndarray, K, dist, newK) -> np.ndarray:
-    """cv::undistort(src, dst, K, dist, newK): for every pixel of the ideal camera newK the source
-    position under the distortion model, sampled bilinearly with the source coordinates quantised
-    to 1/32 pixel (OpenCV's fixed-point remap) and a zero border.  PARITY UNPINNED."""
-    H, W = img_u8.shape[:2]
-    K = np.asarray(K, np.float64)
-    newK = np.asarray(newK, np.float64)
-    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
-    x = (uu - newK[0, 2]) / newK[0, 0]
-    y = (vv - newK[1, 2]) / newK[1, 1]
-    xd, yd = _distort(x, y, dist)
-    su = K[0, 0] * xd + K[0, 2]
-    sv = K[1, 1] * yd + K[1, 2]
-    iu = np.rint(np.clip(su, -4.0, W + 4.0) * 32.0).astype(np.int64)     # INTER_TAB_SIZE = 32
-    iv = np.rint(np.clip(sv, -4.0, H + 4.0) * 32.0).astype(np.int64)
-    x0, y0, fxq, fyq = iu >> 5, iv >> 5, iu & 31, iv & 31
-    src = np.zeros((H + 2, W + 2, img_u8.shape[2]), np.int64)            # zero border
+    """cv::undistort(src, dst, K, dist, newK) as OpenCV 4.5.4 computes it: row stripes of
+    (1 << 12) / W rows, per stripe initUndistortRectifyMap with the new matrix shifted to the stripe
+    (its inverse in closed form, the ray of pixel j accumulated from pixel 0 in float64), source
+    coordinates rounded to 1/32 pixel and split into an int16 pixel and a 5 + 5 bit fraction, then
+    remap(INTER_LINEAR, BORDER_CONSTANT 0) with the fixed-point weights (2^15 scale).
+    PINNED TO THE PUBLISHED ALGORITHM (oracle/image_oracle.c)."""
+    H, W, cn = img_u8.shape
+    A = np.asarray(K, np.float32).astype(np.float64)
+    Ar = np.asarray(newK, np.float32).astype(np.float64).copy()
+    fx, fy, u0, v0a = A[0, 0], A[1, 1], A[0, 2], A[1, 2]
+    stripe0 = min(max(1, (1 << 12) // max(W, 1)), H)
+    v0 = Ar[1, 2]
+    src = np.zeros((H + 2, W + 2, cn), np.int64)                         # zero border
     src[1:-1, 1:-1] = img_u8
+    out = np.empty_like(img_u8)
+    jj = np.arange(W)
+    for y in range(0, H, stripe0):
+        n = min(stripe0, H - y)
+        Ar[1, 2] = v0 - y
+        ir = _invert3(Ar)
+        i = np.arange(n, dtype=np.float64)[:, None]
 
-    def tap(yy, xx):
-        ok = (yy >= -1) & (yy <= H) & (xx >= -1) & (xx <= W)
-        return src[np.clip(yy + 1, 0, H + 1), np.clip(xx + 1, 0, W + 1)] * ok[..., None]
-    w00 = ((32 - fxq) * (32 - fyq))[..., None]
-    w01 = (fxq * (32 - fyq))[..., None]
-    w10 = ((32 - fxq) * fyq)[..., None]
-    w11 = (fxq * fyq)[..., None]
-    acc = tap(y0, x0) * w00 + tap(y0, x0 + 1) * w01 + tap(y0 + 1, x0) * w10 + tap(y0 + 1, x0 + 1) * w11
-    return ((acc + 512) >> 10).astype(np.uint8)
+        def ray(a, b, step):                                              # _x = i * a + b, then += step per pixel
+            first = i * a + b
+            seq = np.concatenate([first, np.full((n, W - 1), step)], axis=1)
+            return np.cumsum(seq, axis=1)
+        _x, _y, _w = ray(ir[1], ir[2], ir[0]), ray(ir[4], ir[5], ir[3]), ray(ir[7], ir[8], ir[6])
+        w = 1.0 / _w
+        x, yy = _x * w, _y * w
+        xd, yd = _distort(x, yy, dist)
+        u, v = fx * xd + u0, fy * yd + v0a
+        iu, iv = np.rint(u * 32).astype(np.int64), np.rint(v * 32).astype(np.int64)
+        wrap = lambda a: ((a + 32768) & 0xFFFF) - 32768                  # (short)
+        sx, sy = wrap(iu >> 5), wrap(iv >> 5)
+        fxq, fyq = iu & 31, iv & 31
+
+        def tap(ty, tx):
+            ok = (ty >= 0) & (ty < H) & (tx >= 0) & (tx < W)
+            return src[np.clip(ty + 1, 0, H + 1), np.clip(tx + 1, 0, W + 1)] * ok[..., None]
+        w00 = ((32 - fxq) * (32 - fyq) * 32)[..., None]
+        w01 = (fxq * (32 - fyq) * 32)[..., None]
+        w10 = ((32 - fxq) * fyq * 32)[..., None]
+        w11 = (fxq * fyq * 32)[..., None]
+        acc = tap(sy, sx) * w00 + tap(sy, sx + 1) * w01 + tap(sy + 1, sx) * w10 + tap(sy + 1, sx + 1) * w11
+        out[y:y + n] = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+    return out
 
 
 def load_image(cam: Camera, downscale: float = 1.0, ignore_distortion: bool = False) -> None:
@@ -575,8 +732,7 @@ def load_image(cam: Camera, downscale: float = 1.0, ignore_distortion: bool = Fa
     fx, fy, cx, cy = (f32(getattr(cam, k)) * rescale for k in ("fx", "fy", "cx", "cy"))
     if downscale > 1.0:
         sf = f32(1.0) / f32(downscale)
-        dw, dh = int(np.rint(img.shape[1] * float(sf))), int(np.rint(img.shape[0] * float(sf)))
-        img = resize_area(img, dw, dh, scale=float(downscale))
+        img = resize_area(img, inv_scale=float(sf))        # cv::resize(img, img, Size(), sf, sf, INTER_AREA)
         fx, fy, cx, cy = fx * sf, fy * sf, cx * sf, cy * sf
     if cam.has_distortion() and not ignore_distortion:
         K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)

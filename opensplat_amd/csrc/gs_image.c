@@ -547,19 +547,17 @@ int gs_jpeg_decode_rgb(const uint8_t *data, size_t size, uint8_t *out, size_t ou
         }
     }
     if (rc == GS_IMG_OK) {
-        /* colour conversion tables (16-bit fixed point) */
-        static int crr[256], cbb[256];
-        static long crg[256], cbg[256];
-        static int tables = 0;
-        if (!tables) {
-            for (int i = 0; i < 256; i++) {
-                const long x = i - 128;
-                crr[i] = (int)((91881L * x + 32768L) >> 16);      /* FIX(1.40200) */
-                cbb[i] = (int)((116130L * x + 32768L) >> 16);     /* FIX(1.77200) */
-                crg[i] = -46802L * x;                             /* FIX(0.71414) */
-                cbg[i] = -22554L * x + 32768L;                    /* FIX(0.34414), + ONE_HALF */
-            }
-            tables = 1;
+        /* colour conversion tables (16-bit fixed point), per call and on the stack: 4 KiB and 256
+         * iterations are nothing next to a decode, and a decoder called from several loader threads
+         * (ctypes releases the GIL) must not share lazily initialised statics */
+        int crr[256], cbb[256];
+        long crg[256], cbg[256];
+        for (int i = 0; i < 256; i++) {
+            const long x = i - 128;
+            crr[i] = (int)((91881L * x + 32768L) >> 16);      /* FIX(1.40200) */
+            cbb[i] = (int)((116130L * x + 32768L) >> 16);     /* FIX(1.77200) */
+            crg[i] = -46802L * x;                             /* FIX(0.71414) */
+            cbg[i] = -22554L * x + 32768L;                    /* FIX(0.34414), + ONE_HALF */
         }
         const size_t roww = (size_t)(mcus_x * mcu_w + 16);
         uint8_t *rows = (uint8_t *)malloc(roww * 4);

@@ -182,6 +182,44 @@ class Restated(_Base):
         return y
 
 
+    # ---- SURVEY.md §8 row f3 (oracle/image_oracle.c: OpenCV 4.5.4's published algorithms) ---------
+    def resize_area(self, img_u8, dst_w=0, dst_h=0, inv_scale=0.0):
+        sh, sw = img_u8.shape[:2]
+        src = np.ascontiguousarray(img_u8, np.uint8)
+        ow, oh = C.c_int(), C.c_int()
+        args = (C.c_int(sw), C.c_int(sh), None, C.c_int(dst_w), C.c_int(dst_h), C.c_double(inv_scale),
+                C.c_double(inv_scale), C.byref(ow), C.byref(oh))
+        rc = self.lib.orc_resize_area_u8c3(src.ctypes.data_as(C.c_void_p), *args)
+        assert rc == 0, "not a down-scale"
+        out = np.zeros((oh.value, ow.value, 3), np.uint8)
+        rc = self.lib.orc_resize_area_u8c3(src.ctypes.data_as(C.c_void_p), C.c_int(sw), C.c_int(sh),
+                                           out.ctypes.data_as(C.c_void_p), C.c_int(dst_w), C.c_int(dst_h),
+                                           C.c_double(inv_scale), C.c_double(inv_scale), C.byref(ow), C.byref(oh))
+        assert rc == 0
+        return out
+
+    @staticmethod
+    def _dist8(dist):
+        d = np.zeros(8, np.float32)
+        d[:len(dist)] = np.asarray(dist, np.float32)
+        return d
+
+    def optimal_new_camera_matrix(self, K, dist, W, H, alpha=0.0):
+        K9, kp = _f(np.asarray(K, np.float32).reshape(9)); d8, dp = _f(self._dist8(dist))
+        nk, nkp = _fo((9,)); roi, rp = _io((4,))
+        self.lib.orc_optimal_new_camera_matrix(kp, dp, C.c_int(W), C.c_int(H), C.c_double(alpha), nkp, rp)
+        return nk.reshape(3, 3), tuple(int(v) for v in roi)
+
+    def undistort(self, img_u8, K, dist, newK):
+        H, W = img_u8.shape[:2]
+        src = np.ascontiguousarray(img_u8, np.uint8)
+        K9, kp = _f(np.asarray(K, np.float32).reshape(9)); d8, dp = _f(self._dist8(dist))
+        N9, np_ = _f(np.asarray(newK, np.float32).reshape(9))
+        out = np.zeros_like(src)
+        self.lib.orc_undistort_u8c3(src.ctypes.data_as(C.c_void_p), C.c_int(W), C.c_int(H), kp, dp, np_,
+                                    out.ctypes.data_as(C.c_void_p))
+        return out
+
     # ---- SURVEY.md §8 row f2 (oracle/train_oracle.c) ------------------------------------------
     def ssim_window(self):
         g, gp = _fo((11,)); w2, wp = _fo((11, 11))

@@ -3,9 +3,12 @@
 * baseline JPEG decoder (gs_image.c) — bit-exact against libjpeg's output (the library cv::imread
   uses): stored fixtures (tests/golden/make_golden_jpeg.py) and, where Pillow is importable, a live
   sweep over sizes / qualities / subsamplings;
-* INTER_AREA down-scaling, lens undistortion, optimal new camera matrix: written from OpenCV's
-  documented behaviour, PARITY UNPINNED (no OpenCV here) — checked against exact arithmetic and
-  against an analytically distorted picture instead."""
+* INTER_AREA down-scaling, lens undistortion, optimal new camera matrix: PINNED TO THE PUBLISHED
+  ALGORITHM — oracle/image_oracle.c restates OpenCV 4.5.4's sources (resize.cpp, calibration.cpp,
+  undistort.dispatch.cpp, imgwarp.cpp) in plain C and opensplat_amd/colmap.py must agree with it bit for
+  bit on random and on lens-distorted synthetic captures; not pinned to an OpenCV build (none offline).
+  Exact arithmetic and an analytically distorted picture check the meaning of the results;
+* EXIF orientation (cv::imread applies it) and the hand-over of non-baseline JPEGs to Pillow."""
 import io
 import os
 
@@ -72,10 +75,12 @@ def test_resize_area_integer_and_fractional_scales():
     assert np.abs(quarter.astype(np.float64) - exact).max() <= 0.5
     # size not a multiple of the factor: 63 x 47 -> 32 x 24 (cv::resize rounds the size), the last
     # row / column average what is left
-    odd = colmap.downscale_area(img[:47, :63], 2)
+    odd = colmap.resize_area(img[:47, :63], inv_scale=0.5)
     assert odd.shape == (24, 32, 3)
     assert np.array_equal(odd[:23, :31], half[:23, :31])
     assert np.abs(odd[23, 5].astype(int) - img[46:47, 10:12].reshape(-1, 3).mean(0)).max() <= 0.5
+    # Camera::getImage's pyramid (input_data.cpp:112) truncates the size instead: 63 x 47 -> 31 x 23
+    assert colmap.downscale_area(img[:47, :63], 2).shape == (23, 31, 3)
     # fractional scale (Camera::getImage with a size that does not divide): area-weighted mean;
     # constant images stay constant, the mean is preserved, and a brute-force integration agrees
     flat = np.full((30, 45, 3), 77, np.uint8)
@@ -121,10 +126,11 @@ def test_undistortion_recovers_the_ideal_pinhole_view():
     su, sv = K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]
     inside = (su >= 0) & (su <= W - 1) & (sv >= 0) & (sv <= H - 1)
     assert inside[y + 2:y + h - 2, x + 2:x + w - 2].all()
-    # no distortion: identity matrix up to the (W - 1) / W convention, full-frame ROI, image unchanged
+    # no distortion: the same matrix (the 9 x 9 grid spans [0, W-1] x [0, H-1] in OpenCV 4.5), full-frame
+    # ROI, image unchanged
     K0, roi0 = colmap.optimal_new_camera_matrix(K, (0, 0, 0, 0, 0), W, H)
     assert roi0[2] >= W - 1 and roi0[3] >= H - 1
-    assert abs(K0[0, 0] / K[0, 0] - (W - 1) / W) < 1e-3 and abs(K0[0, 2] - K[0, 2] * (W - 1) / W) < 0.51
+    assert np.abs(K0 - K).max() < 1e-3
     same = colmap.undistort_image(img, K, (0, 0, 0, 0, 0), K)
     assert np.array_equal(same, img)
 
@@ -147,3 +153,134 @@ def test_load_image_runs_the_reference_sequence_on_a_distorted_jpeg(tmp_path):
     colmap.load_image(plain)
     assert np.array_equal(np.rint(plain.image * 255).astype(np.uint8), g["q90_422_rgb"])
     assert (plain.fx, plain.cx, plain.width, plain.height) == (75.0, 41.5, 83, 61)
+
+
+# ---- pinned to the published algorithm: colmap.py against oracle/image_oracle.c ---------------------
+
+@pytest.mark.parametrize("sw,sh,kw", [(64, 48, dict(inv_scale=0.5)), (63, 47, dict(inv_scale=0.5)),
+                                      (65, 49, dict(inv_scale=0.25)), (97, 61, dict(inv_scale=float(np.float32(1.0) / np.float32(3.0)))),
+                                      (120, 90, dict(inv_scale=float(np.float32(1.0) / np.float32(1.5)))),
+                                      (101, 77, dict(dst_w=50, dst_h=38)), (96, 64, dict(dst_w=32, dst_h=16)),
+                                      (96, 64, dict(dst_w=24, dst_h=16)), (57, 43, dict(dst_w=19, dst_h=14)),
+                                      (640, 480, dict(inv_scale=0.125)), (31, 47, dict(dst_w=23, dst_h=15))])
+def test_resize_area_is_bit_exact_with_the_restated_opencv_algorithm(sw, sh, kw, restated):
+    rs = np.random.RandomState(sw * 1000 + sh)
+    img = rs.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+    img[: sh // 3] = (np.linspace(0, 255, sw)[None, :, None] * np.ones((sh // 3, 1, 3))).astype(np.uint8)
+    got = colmap.resize_area(img, **kw)
+    want = restated.resize_area(img, kw.get("dst_w", 0), kw.get("dst_h", 0), kw.get("inv_scale", 0.0))
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def _lens_capture(W, H, K, dist, seed):
+    """A textured scene seen through the lens: what a COLMAP OPENCV-model camera delivers."""
+    rs = np.random.RandomState(seed)
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    xn, yn = colmap.undistort_points(uu, vv, np.asarray(K, np.float64), dist, None, iters=30)
+    chans = []
+    for c in range(3):
+        a, b, ph = rs.uniform(20, 90), rs.uniform(20, 90), rs.uniform(0, 6)
+        chans.append(0.5 + 0.3 * np.sin(xn * a + ph) * np.cos(yn * b) + 0.15 * np.sin((xn + 2 * yn) * 37.0))
+    img = np.clip(np.rint(np.stack(chans, -1) * 255.0), 0, 255).astype(np.uint8)
+    return img ^ (rs.randint(0, 4, img.shape).astype(np.uint8))      # + sensor noise in the low bits
+
+
+LENSES = [
+    (240, 180, [[200.0, 0, 118.0], [0, 198.0, 91.0], [0, 0, 1]], (-0.18, 0.05, 0.002, -0.001, 0.01)),
+    (203, 117, [[150.5, 0, 101.25], [0, 149.75, 58.5], [0, 0, 1]], (0.12, -0.03, -0.0015, 0.0025, 0.0)),   # pincushion
+    (1300, 40, [[900.0, 0, 650.0], [0, 900.0, 20.0], [0, 0, 1]], (-0.05, 0.0, 0.0, 0.0, 0.0)),             # stripes of 3 rows
+    (64, 300, [[80.0, 0, 31.5], [0, 80.0, 150.0], [0, 0, 1]], (-0.25, 0.08, 0.0, 0.0, -0.01)),             # one 64-row stripe ... several
+]
+
+
+@pytest.mark.parametrize("W,H,K,dist", LENSES)
+def test_undistortion_is_bit_exact_with_the_restated_opencv_algorithm(W, H, K, dist, restated):
+    K = np.asarray(K, np.float32)
+    newK, roi = colmap.optimal_new_camera_matrix(K, dist, W, H)
+    newK_o, roi_o = restated.optimal_new_camera_matrix(K, dist, W, H)
+    assert newK.dtype == np.float32 and np.array_equal(newK, newK_o), (newK, newK_o)
+    assert tuple(roi) == tuple(roi_o), (roi, roi_o)
+    assert roi[2] > W // 2 and roi[3] > H // 2
+    img = _lens_capture(W, H, K, dist, seed=W + H)
+    got = colmap.undistort_image(img, K, dist, newK)
+    want = restated.undistort(img, K, dist, newK)
+    assert np.array_equal(got, want), int((got != want).sum())
+    # with alpha = 1 (all source pixels kept) parts of the frame lie outside the source: zero border
+    K1, _ = colmap.optimal_new_camera_matrix(K, dist, W, H, alpha=1.0)
+    K1o, _ = restated.optimal_new_camera_matrix(K, dist, W, H, alpha=1.0)
+    assert np.array_equal(K1, K1o)
+    g1, w1 = colmap.undistort_image(img, K, dist, K1), restated.undistort(img, K, dist, K1)
+    assert np.array_equal(g1, w1)
+
+
+def test_load_image_equals_the_restated_opencv_sequence(tmp_path, restated):
+    """Camera::loadImage (input_data.cpp:40-105) on a distorted capture stored as PNG: colmap.load_image
+    against the same three steps through the C restatement."""
+    W, H = 322, 242
+    K = np.array([[260.0, 0, 160.0], [0, 258.0, 120.5], [0, 0, 1]], np.float32)
+    dist = (-0.2, 0.06, 0.001, -0.0005, 0.0)
+    img = _lens_capture(W, H, K, dist, seed=5)
+    path = str(tmp_path / "cap.npy")
+    np.save(path, img)
+    cam = colmap.Camera(width=W, height=H, fx=260.0, fy=258.0, cx=160.0, cy=120.5, k1=dist[0], k2=dist[1],
+                        p1=dist[2], p2=dist[3], k3=dist[4], file_path=path)
+    colmap.load_image(cam, downscale=2.0)
+    f32 = np.float32
+    sf = f32(1.0) / f32(2.0)
+    small = restated.resize_area(img, inv_scale=float(sf))
+    Ks = np.array([[f32(260.0) * sf, 0, f32(160.0) * sf], [0, f32(258.0) * sf, f32(120.5) * sf], [0, 0, 1]], np.float32)
+    newK, roi = restated.optimal_new_camera_matrix(Ks, dist, small.shape[1], small.shape[0])
+    und = restated.undistort(small, Ks, dist, newK)
+    x, y, w, h = roi
+    want = und[y:y + h, x:x + w].astype(np.float32) / np.float32(255.0)
+    assert cam.image.shape == want.shape and np.array_equal(cam.image, want)
+    assert (cam.fx, cam.fy, cam.cx, cam.cy) == tuple(float(v) for v in (newK[0, 0], newK[1, 1], newK[0, 2], newK[1, 2]))
+
+
+# ---- EXIF orientation, non-baseline JPEGs ----------------------------------------------------------------
+
+def _with_exif(jpeg: bytes, orientation: int, big_endian: bool) -> bytes:
+    import struct
+
+    e = ">" if big_endian else "<"
+    tiff = (b"MM" if big_endian else b"II") + struct.pack(e + "HI", 42, 8) + struct.pack(e + "H", 2)
+    tiff += struct.pack(e + "HHIHH", 0x010F, 3, 1, 7, 0)                 # some other tag first
+    tiff += struct.pack(e + "HHIHH", 0x0112, 3, 1, orientation, 0) + struct.pack(e + "I", 0)
+    seg = b"Exif\x00\x00" + tiff
+    return jpeg[:2] + b"\xff\xe1" + struct.pack(">H", len(seg) + 2) + seg + jpeg[2:]
+
+
+@pytest.mark.parametrize("big_endian", [False, True])
+def test_exif_orientation_is_applied_like_cv_imread(tmp_path, big_endian):
+    g = np.load(GOLD)
+    blob, rgb = g["q90_422_file"].tobytes(), g["q90_422_rgb"]
+    assert colmap.exif_orientation(blob) == 1
+    T = lambda a: a.transpose(1, 0, 2)
+    want = {1: rgb, 2: rgb[:, ::-1], 3: rgb[::-1, ::-1], 4: rgb[::-1], 5: T(rgb), 6: T(rgb)[:, ::-1],
+            7: T(rgb)[::-1, ::-1], 8: T(rgb)[::-1]}
+    for o, ref in want.items():
+        b = _with_exif(blob, o, big_endian)
+        assert colmap.exif_orientation(b) == o
+        path = str(tmp_path / ("o%d.jpg" % o))
+        open(path, "wb").write(b)
+        assert np.array_equal(colmap.read_image_u8(path), ref), o
+    # orientation 6 = the camera was held rotated: a 90-degree clockwise turn brings the picture upright
+    assert np.array_equal(want[6], np.rot90(rgb, -1))
+    assert colmap.exif_orientation(_with_exif(blob, 9, big_endian)) == 1     # out of range: ignored
+    assert colmap.exif_orientation(blob[:2] + b"\xff\xe1\x00\x08Exif\x00\x00" + blob[2:]) == 1
+
+
+def test_progressive_jpeg_goes_to_pillow_or_says_what_to_do(tmp_path):
+    g = np.load(GOLD)
+    path = str(tmp_path / "prog.jpg")
+    open(path, "wb").write(g["progressive_file"].tobytes())
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        with pytest.raises(ValueError, match="Pillow"):
+            colmap.read_image_u8(path)
+        return
+    from PIL import Image
+    ref = np.asarray(Image.open(path).convert("RGB"))
+    assert np.array_equal(colmap.read_image_u8(path), ref)
