@@ -427,6 +427,8 @@ def _decode_jpeg_any(blob: bytes) -> np.ndarray:
     try:
         return decode_jpeg(blob)
     except ValueError as e:
+        if "unsupported" not in str(e):
+            raise                                      # corrupt / truncated: nothing to hand over
         try:
             import io
 
@@ -434,9 +436,11 @@ def _decode_jpeg_any(blob: bytes) -> np.ndarray:
         except ImportError:
             raise ValueError("%s — this file needs a full JPEG decoder: install Pillow, or re-encode the "
                              "capture as baseline JPEG / PNG" % e) from None
-        im = Image.open(io.BytesIO(blob))
-        im.draft("RGB", im.size)
-        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+        try:
+            im = Image.open(io.BytesIO(blob))
+            return np.asarray(im.convert("RGB"), dtype=np.uint8)
+        except Exception as pe:                        # Pillow's own exception types -> ours
+            raise ValueError("JPEG: %s" % pe) from None
 
 
 def read_image_u8(path: str) -> np.ndarray:
