@@ -450,6 +450,128 @@ class Reference(_Base):
                                cull_huge, samples_fn)
 
 
+    # ---- the reference's own Model, compiled in place (oracle/ref_model_shim.cpp) ------------------
+    def model(self, xyz, rgb_u8, **cfg):
+        return RefModel(self.lib, xyz, rgb_u8, **cfg)
+
+
+class RefModel:
+    """Handle on OpenSplat's `Model` (model.hpp, CPU device) inside oracle/_ref/libgsplat_ref.so:
+    forward / mainLoss / optimizersStep / schedulersStep / afterTrain / savePly / saveSplat are the
+    reference's compiled code.  TEST INFRASTRUCTURE."""
+
+    DEFAULTS = dict(numCameras=10, numDownscales=0, resolutionSchedule=3000, shDegree=3, shDegreeInterval=1000,
+                    refineEvery=100, warmupLength=500, resetAlphaEvery=30, densifyGradThresh=0.0002,
+                    densifySizeThresh=0.01, stopScreenSizeAt=4000, splitScreenSize=0.05, maxSteps=30000,
+                    keepCrs=False, scale=1.0, translation=None)
+
+    def __init__(self, lib, xyz, rgb_u8, **cfg):
+        c = dict(self.DEFAULTS)
+        c.update(cfg)
+        self.cfg, self.lib = c, lib
+        lib.refm_create.restype = C.c_void_p
+        lib.refm_last_error.restype = C.c_char_p
+        lib.refm_means_lr.restype = C.c_float
+        for f in (lib.refm_num_points, lib.refm_sh_bases, lib.refm_destroy, lib.refm_means_lr):
+            f.argtypes = [C.c_void_p]
+        lib.refm_downscale_factor.argtypes = [C.c_void_p, C.c_int]
+        x, xp = _f(xyz)
+        r = np.ascontiguousarray(rgb_u8, np.uint8)
+        tr = None if c["translation"] is None else _f(c["translation"])
+        h = lib.refm_create(C.c_int(len(x)), xp, r.ctypes.data_as(C.c_void_p), C.c_int(c["numCameras"]),
+                            C.c_int(c["numDownscales"]), C.c_int(c["resolutionSchedule"]), C.c_int(c["shDegree"]),
+                            C.c_int(c["shDegreeInterval"]), C.c_int(c["refineEvery"]), C.c_int(c["warmupLength"]),
+                            C.c_int(c["resetAlphaEvery"]), C.c_float(c["densifyGradThresh"]),
+                            C.c_float(c["densifySizeThresh"]), C.c_int(c["stopScreenSizeAt"]),
+                            C.c_float(c["splitScreenSize"]), C.c_int(c["maxSteps"]), C.c_int(int(c["keepCrs"])),
+                            C.c_float(c["scale"]), tr[1] if tr else None)
+        if not h:
+            raise RuntimeError("reference threw: " + lib.refm_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def __del__(self):
+        try:
+            self.lib.refm_destroy(self.h)
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("reference threw: " + self.lib.refm_last_error().decode())
+
+    @property
+    def N(self):
+        return int(self.lib.refm_num_points(self.h))
+
+    @property
+    def K(self):
+        return int(self.lib.refm_sh_bases(self.h))
+
+    @staticmethod
+    def _ptrs(arrs):
+        keep = [np.ascontiguousarray(a, np.float32) for a in arrs]
+        return keep, (_f32p * 6)(*[a.ctypes.data_as(_f32p) for a in keep])
+
+    def set_state(self, params, exp_avg=None, exp_avg_sq=None, adam_step=1):
+        N, K = params[0].shape[0], params[5].shape[1] + 1
+        kp, pp = self._ptrs(params)
+        if exp_avg is not None:
+            ka, pa = self._ptrs(exp_avg)
+            ks, ps = self._ptrs(exp_avg_sq)
+        else:
+            pa = ps = None
+        self._chk(self.lib.refm_set_state(self.h, C.c_int(N), C.c_int(K), pp, pa, ps, C.c_int64(adam_step)))
+
+    def get_state(self, moments=True):
+        N, K = self.N, self.K
+        shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, K - 1, 3)]
+        outs = [[np.zeros(sh, np.float32) for sh in shapes] for _ in range(3)]
+        ptr = [(_f32p * 6)(*[a.ctypes.data_as(_f32p) for a in o]) for o in outs]
+        self._chk(self.lib.refm_get_state(self.h, ptr[0], ptr[1] if moments else None, ptr[2] if moments else None))
+        return dict(params=outs[0], exp_avg=outs[1], exp_avg_sq=outs[2])
+
+    def after_train(self, step, radii, xys_grad, stats, height, width, seed=0):
+        """Model::afterTrain(step).  stats = (xysGradNorm, visCounts, max2DSize) or None.
+        -> (refined?, stats after the call or None)"""
+        N = len(radii)
+        r = np.ascontiguousarray(radii, np.int32)
+        g = _f(xys_grad) if xys_grad is not None else (None, None)
+        st = [(_f(a)) for a in stats] if stats is not None else [(None, None)] * 3
+        out = np.zeros((3, N), np.float32)
+        refined = C.c_int(0)
+        self._chk(self.lib.refm_after_train(self.h, C.c_int(step), C.c_int(N), r.ctypes.data_as(_i32p), g[1],
+                                            st[0][1], st[1][1], st[2][1], C.c_int(height), C.c_int(width),
+                                            C.c_uint64(seed), out.ctypes.data_as(_f32p), C.byref(refined)))
+        return bool(refined.value), (None if refined.value else (out[0], out[1], out[2]))
+
+    def save(self, path, step=0):
+        self._chk(self.lib.refm_save(self.h, str(path).encode(), C.c_int(step)))
+
+    def downscale_factor(self, step):
+        return int(self.lib.refm_downscale_factor(self.h, step))
+
+    def means_lr(self):
+        return float(self.lib.refm_means_lr(self.h))
+
+    def train_iteration(self, step, cam, gt, ssim_weight=0.2, seed=0, after_train=True):
+        """One iteration of opensplat.cpp:151-170 on the CPU.  cam: dict(width, height, fx, fy, cx, cy,
+        camToWorld [4,4]).  -> dict(loss, rgb, xys_grad, radii)."""
+        N = self.N
+        d = self.downscale_factor(step)
+        h, w = cam["height"] // d, cam["width"] // d     # model.cpp:88-89 (integer division of floats truncated)
+        g, gp = _f(gt)
+        assert g.shape == (h, w, 3), (g.shape, (h, w, 3))
+        c2w, cp = _f(cam["camToWorld"])
+        loss = C.c_float()
+        rgb, rp = _fo((h, w, 3)); xg, xgp = _fo((N, 2)); rad, radp = _io((N,))
+        self._chk(self.lib.refm_train_iteration(self.h, C.c_int(step), C.c_int(cam["width"]), C.c_int(cam["height"]),
+                                                C.c_float(cam["fx"]), C.c_float(cam["fy"]), C.c_float(cam["cx"]),
+                                                C.c_float(cam["cy"]), cp, gp, C.c_float(ssim_weight),
+                                                C.c_uint64(seed), C.byref(loss), rp, xgp, radp,
+                                                C.c_int(int(after_train))))
+        return dict(loss=float(loss.value), rgb=rgb, xys_grad=xg, radii=rad)
+
+
 def _densify_refine(fn, prob, grad_thresh, size_thresh, check_screen, split_screen, cull_huge, samples_fn):
     """Shared driver of orc_densify_refine / ref_densify_refine (same C signature).  samples_fn(n)
     -> float32 [2 n, 3] normal samples.  Returns dict(params, exp_avg, exp_avg_sq, counts)."""
