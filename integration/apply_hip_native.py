@@ -26,8 +26,20 @@ CMake (print with --cmake): a GPU_RUNTIME value HIP_NATIVE that defines USE_HIP 
 this repo's opensplat_amd/csrc to the include path and links libgsplat_torch.so + libgsplat_hip.so
 instead of building rasterizer/gsplat.
 
+--fused additionally patches model.cpp (macro USE_HIP_NATIVE_FUSED) so that OpenSplat's own `Model`
+runs on the fused operators: five insertions, each a guarded early return into
+opensplat_amd/csrc/model_fused.inl —
+    #include "model_fused.inl"                                  after model.cpp's own includes
+    Model::forward        -> gs_fused::render(...)              in front of the torch::cat of the SH
+                                                                coefficients (model.cpp:114)
+    Model::optimizersStep -> gs_fused::optimizers_step(*this)   model.cpp:236
+    Model::afterTrain     -> gs_fused::after_train(*this, step) model.cpp:311
+    Model::mainLoss       -> ::mainLoss(rgb, gt, ssimWeight)    model.cpp:780
+The CPU device keeps every original statement.
+
 tests/test_integration_build.py applies this script to a scratch copy of the reference and builds +
-runs a translation unit shaped like Model::forward against the result.
+runs a translation unit shaped like Model::forward against the result; tests/test_gpu_model_fused.py
+builds the patched model.cpp itself and trains with it on the GPU.
 """
 import argparse
 import os
@@ -92,11 +104,53 @@ def patch_gsplat_hpp(text: str) -> str:
     return pat.sub(r"#if (defined(USE_HIP) || defined(USE_CUDA)) && !defined(USE_HIP_NATIVE)\n\1", text, 1)
 
 
+FUSED_HUNKS = [
+    # (anchor text that must occur exactly once, text inserted IN FRONT of the anchor's line)
+    ('namespace fs = std::filesystem;',
+     '#ifdef USE_HIP_NATIVE_FUSED\n'
+     '// MI355X-native fused operators behind Model\'s own call sites (opensplat_amd/csrc)\n'
+     '#include "model_fused.inl"\n'
+     '#endif\n\n'),
+    ('    torch::Tensor colors =  torch::cat({featuresDc.index({Slice(), None, Slice()}), featuresRest}, 1);',
+     '#ifdef USE_HIP_NATIVE_FUSED\n'
+     '    if (device != torch::kCPU)\n'
+     '        return gs_fused::render(*this, viewMat, projMat, T, fx, fy, cx, cy, height, width, step);\n'
+     '#endif\n'),
+    ('  meansOpt->step();',
+     '#ifdef USE_HIP_NATIVE_FUSED\n'
+     '  if (device != torch::kCPU){ gs_fused::optimizers_step(*this); return; }\n'
+     '#endif\n'),
+    ('    // When radii.sum() == 0',
+     '#ifdef USE_HIP_NATIVE_FUSED\n'
+     '    if (device != torch::kCPU){ gs_fused::after_train(*this, step); return; }\n'
+     '#endif\n'),
+    ('    torch::Tensor ssimLoss = 1.0f - ssim.eval(rgb, gt);',
+     '#ifdef USE_HIP_NATIVE_FUSED\n'
+     '    if (rgb.is_cuda()) return ::mainLoss(rgb, gt, ssimWeight);\n'
+     '#endif\n'),
+]
+
+
+def patch_model_cpp(text: str) -> str:
+    if "USE_HIP_NATIVE_FUSED" in text:
+        return text
+    for anchor, insert in FUSED_HUNKS:
+        if text.count(anchor) != 1:
+            raise SystemExit("model.cpp: anchor %r found %d times (different OpenSplat version?)"
+                             % (anchor, text.count(anchor)))
+        i = text.index(anchor)
+        line_start = text.rfind("\n", 0, i) + 1
+        text = text[:line_start] + insert + text[line_start:]
+    return text
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("checkout", nargs="?", help="root of the OpenSplat source tree")
     ap.add_argument("--out", help="write the patched files here instead of editing in place")
     ap.add_argument("--cmake", action="store_true", help="print the CMakeLists.txt snippet and exit")
+    ap.add_argument("--fused", action="store_true",
+                    help="also patch model.cpp onto SplatRender / MainLoss / the fused Adam step / densify")
     a = ap.parse_args()
     if a.cmake or not a.checkout:
         print(CMAKE_SNIPPET)
@@ -109,9 +163,13 @@ def main():
         open(os.path.join(out, name), "w").write(fn(text, name))
     text = open(os.path.join(a.checkout, "gsplat.hpp")).read()
     open(os.path.join(out, "gsplat.hpp"), "w").write(patch_gsplat_hpp(text))
+    if a.fused:
+        text = open(os.path.join(a.checkout, "model.cpp")).read()
+        open(os.path.join(out, "model.cpp"), "w").write(patch_model_cpp(text))
     if a.out:   # the untouched headers the patched ones include
         shutil.copy(os.path.join(a.checkout, "tile_bounds.hpp"), out)
-    print("patched: %s" % ", ".join(HEADERS + SOURCES + ["gsplat.hpp"]), file=sys.stderr)
+    print("patched: %s" % ", ".join(HEADERS + SOURCES + ["gsplat.hpp"] + (["model.cpp"] if a.fused else [])),
+          file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -160,6 +160,12 @@ private:
     std::vector<double> lrs_;
     int64_t step_ = 0;
 };
+// The same launch over state the CALLER owns (e.g. the exp_avg / exp_avg_sq tensors inside six
+// torch::optim::Adam objects, model_fused.inl): params / expAvg / expAvgSq are updated in place;
+// `step` is the 1-based step count after this update.  Contiguous float32 GPU tensors.
+void fusedAdamStep(const std::vector<torch::Tensor> &params, const std::vector<torch::Tensor> &grads,
+                   const std::vector<torch::Tensor> &expAvg, const std::vector<torch::Tensor> &expAvgSq,
+                   const std::vector<double> &lrs, int64_t step);
 // OptimScheduler::getLearningRate (optim_scheduler.cpp:4-7)
 float schedulerLearningRate(float lrInit, float lrFinal, int maxSteps, int step);
 

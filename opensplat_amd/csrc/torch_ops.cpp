@@ -841,6 +841,13 @@ Tensor op_main_loss(const Tensor &rgb, const Tensor &gt, double ssimWeight) {
 // caller so that Python can hold them): the FusedAdam class is the C++ face of the same call.
 void op_adam_step(std::vector<Tensor> params, std::vector<Tensor> grads, std::vector<Tensor> expAvg,
                   std::vector<Tensor> expAvgSq, std::vector<double> lrs, int64_t step) {
+    fusedAdamStep(params, grads, expAvg, expAvgSq, lrs, step);
+}
+}  // namespace
+
+void fusedAdamStep(const std::vector<Tensor> &params, const std::vector<Tensor> &grads,
+                   const std::vector<Tensor> &expAvg, const std::vector<Tensor> &expAvgSq,
+                   const std::vector<double> &lrs, int64_t step) {
     const size_t n = params.size();
     TORCH_CHECK(grads.size() == n && expAvg.size() == n && expAvgSq.size() == n && lrs.size() == n,
                 "parallel lists of equal length expected");
@@ -860,6 +867,8 @@ void op_adam_step(std::vector<Tensor> params, std::vector<Tensor> grads, std::ve
     }
     check_status(gs_adam_step((int)n, groups, step, 0.9, 0.999, 1e-8, current_stream()), "gs_adam_step");
 }
+
+namespace {
 
 }  // namespace
 
