@@ -787,7 +787,7 @@ def main():
                                     "misses_timed": pipe.misses - misses_warmup,
                                     "id_list_capacity": pipe.ws.capacity},
         }
-        if world == 1 and plain and not sequence:
+        if world == 1 and plain and not sequence and not args.no_cpu_baseline:   # (profiling passes skip both)
             try:
                 out["speculative_binning"]["operator_path"] = operator_binning_probe(scene, dev)
             except Exception as e:

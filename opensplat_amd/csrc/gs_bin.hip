@@ -76,6 +76,14 @@ struct TileRect {
     int tx0, tx1, ty0, ty1;
     __device__ __forceinline__ int count() const { return (tx1 - tx0) * (ty1 - ty0); }
 };
+__device__ __forceinline__ TileRect tile_rect_of(uint32_t rx, uint32_t ry) {
+    int x0 = rx & 0xFFFF, x1 = rx >> 16, y0 = ry & 0xFFFF, y1 = ry >> 16;
+    TileRect r;
+    r.tx0 = x0 / GS_TILE; r.tx1 = (x1 + GS_TILE - 1) / GS_TILE;
+    r.ty0 = y0 / GS_TILE; r.ty1 = (y1 + GS_TILE - 1) / GS_TILE;
+    if (x1 <= x0 || y1 <= y0) r.tx1 = r.tx0, r.ty1 = r.ty0;
+    return r;
+}
 __device__ __forceinline__ TileRect tile_rect(const float4 *__restrict__ packed, int n) {
     uint32_t rx = __float_as_uint(packed[3 * (size_t)n + 1].w);
     uint32_t ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
@@ -145,19 +153,32 @@ __global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
               int32_t *__restrict__ counts, int32_t *__restrict__ wg_base) {
     extern __shared__ int32_t h[];
+    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
+    // few thousand Gaussians with huge rectangles still keep every CU's waves busy.  A wave walks ~4
+    // chunks at 1 M Gaussians: the rectangle of the NEXT chunk is requested before the current one is
+    // walked (and the first one before the table is cleared) — a chain of dependent round trips
+    // otherwise, which is what this kernel spends its time on.
+    const int stride = (blockDim.x >> 6) * gridDim.x, lane = threadIdx.x & 63;
+    int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    auto request = [&](int ch, uint32_t &rx, uint32_t &ry) {
+        const int64_t n = (int64_t)ch * 64 + lane;   // (the chunk beyond the last one may not fit an int)
+        const bool ok = n < N;
+        rx = ok ? __float_as_uint(packed[3 * (size_t)n + 1].w) : 0u;
+        ry = ok ? __float_as_uint(packed[3 * (size_t)n + 2].w) : 0u;
+        return ok;
+    };
+    uint32_t rx, ry;
+    bool valid = request(chunk, rx, ry);
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = 0;
     __syncthreads();
     // every iteration is taken by whole waves (for_each_tile uses wave-wide operations)
-    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
-    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
-    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
-         chunk += (blockDim.x >> 6) * gridDim.x) {
-        const int n = chunk * 64 + (threadIdx.x & 63);
-        const bool valid = n < N;
-        TileRect r = {0, 0, 0, 0};
-        if (valid) r = tile_rect(packed, n);
+    for (; (int64_t)chunk * 64 < N; chunk += stride) {
+        uint32_t nrx, nry;
+        const bool nvalid = request(chunk + stride, nrx, nry);
+        const TileRect r = tile_rect_of(rx, ry);
         for_each_tile(r, valid, tiles_x, 0u, 0,
                       [&](int tile, uint32_t, int) { atomicAdd(&h[tile], 1); });
+        rx = nrx; ry = nry; valid = nvalid;
     }
     __syncthreads();
     int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
@@ -199,6 +220,87 @@ static __device__ __forceinline__ int32_t block_scan_1024(int32_t v, int32_t *ws
     }
     __syncthreads();
     return v + ws[wave];
+}
+
+// Inclusive scan of one int per lane over a wave: Hillis-Steele inside each 16-lane row (row_shr with
+// zero fill), then the two row carries.
+__device__ __forceinline__ int wave_inclusive_scan_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// The scan for images whose counters fit in LDS (up to 36 864 tiles) — the usual case.  One 1024-thread
+// workgroup sits between two launches that fill the chip, so what counts is its LATENCY: every thread
+// reads its contiguous slice of counters straight from global memory (a wave's slices are contiguous:
+// coalesced), the prefix is a DPP wave scan + the sixteen wave totals through LDS, and the counting
+// sort for the longest-first tile order reuses the same pattern: five barriers in all (the general
+// kernel below: a dozen, plus a Hillis-Steele loop of shuffles) — 14 -> ~6 us at 1080p.
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_fast(int tiles, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+                  int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
+                  int32_t *__restrict__ order) {
+    extern __shared__ int32_t c_lds[];
+    __shared__ int32_t part[1024];
+    __shared__ int32_t wsum[16], wmax[16], psum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (tiles + 1023) / 1024;
+    const int lo = min(t * per, tiles), hi = min(lo + per, tiles);
+    int32_t sum = 0, longest = 0;
+    for (int i = lo; i < hi; i++) {
+        const int32_t c = counts[i];
+        c_lds[skew(i)] = c;
+        sum += c;
+        longest = max(longest, c);
+    }
+    const int32_t incl = wave_inclusive_scan_i(sum);
+    const int32_t wl = wave_max_i(longest);
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wmax[wave] = wl;
+    part[t] = 0;
+    __syncthreads();
+    int32_t base = 0, total = 0, longest_all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int32_t v = wsum[w];
+        base += w < wave ? v : 0;
+        total += v;
+        longest_all = max(longest_all, wmax[w]);
+    }
+    int32_t run = base + incl - sum;   // exclusive prefix of this thread's slice
+    for (int i = lo; i < hi; i++) {
+        const int32_t c = c_lds[skew(i)];
+        bins[i] = make_int2(run, run + c);
+        run += c;
+    }
+    if (t == 1023) {
+        *total_dev = total;
+        // pinned (device-mapped) host memory: the stores land there without a copy kernel
+        if (total_host) {
+            total_host[0] = total;
+            total_host[1] = longest_all;
+        }
+    }
+    if (!order) return;
+    // tiles by descending list length (counting sort on min(n >> shift, 1023), bucket 0 = longest)
+    int shift = 0;
+    while ((longest_all >> shift) >= 1024) shift++;
+    for (int i = lo; i < hi; i++) atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1);
+    __syncthreads();
+    const int32_t own = part[t];
+    const int32_t incl2 = wave_inclusive_scan_i(own);
+    if (lane == 63) psum[wave] = incl2;
+    __syncthreads();
+    int32_t base2 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) base2 += w < wave ? psum[w] : 0;
+    part[t] = base2 + incl2 - own;
+    __syncthreads();
+    for (int i = lo; i < hi; i++) order[atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1)] = i;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -302,25 +404,42 @@ struct SplatForMask {
     uint32_t smax, rx, ry;
 };
 
+// what a lane needs of its Gaussian: requested one chunk ahead of its use (scatter_request), the
+// dependent chain of round trips is otherwise what the kernel waits for
+struct ScatterIn {
+    float4 p0, p1;
+    float p2w, depth;
+    bool valid;
+};
+__device__ __forceinline__ ScatterIn scatter_request(const float4 *__restrict__ packed,
+                                                     const float *__restrict__ depths, int n, bool valid) {
+    ScatterIn in;
+    in.valid = valid;
+    in.p0 = in.p1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.p2w = in.depth = 0.f;
+    if (valid) {
+        in.p0 = packed[3 * (size_t)n + 0];
+        in.p1 = packed[3 * (size_t)n + 1];
+        in.p2w = packed[3 * (size_t)n + 2].w;
+        in.depth = depths[n];
+    }
+    return in;
+}
+
 template <typename Emit>
-__device__ __forceinline__ void scatter_tiles(const float4 *__restrict__ packed,
-                                              const float *__restrict__ depths, int n, bool valid,
-                                              int tiles_x, Emit emit) {
+__device__ __forceinline__ void scatter_tiles(const ScatterIn &in, int n, int tiles_x, Emit emit) {
+    const bool valid = in.valid;
     TileRect r = {0, 0, 0, 0};
     uint32_t db = 0;
     SplatForMask g = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
     uint4 w = make_uint4(kNoRowTable, 0u, 0u, 0u);
     if (valid) {
-        const float4 p0 = packed[3 * (size_t)n + 0], p1 = packed[3 * (size_t)n + 1];
-        g.x = p0.x; g.y = p0.y; g.A = p0.z; g.B = p0.w; g.C = p1.x;
-        g.smax = __float_as_uint(p1.z);
-        g.rx = __float_as_uint(p1.w);
-        g.ry = __float_as_uint(packed[3 * (size_t)n + 2].w);
-        const int x0 = g.rx & 0xFFFF, x1 = g.rx >> 16, y0 = g.ry & 0xFFFF, y1 = g.ry >> 16;
-        r.tx0 = x0 / GS_TILE; r.tx1 = (x1 + GS_TILE - 1) / GS_TILE;
-        r.ty0 = y0 / GS_TILE; r.ty1 = (y1 + GS_TILE - 1) / GS_TILE;
-        if (x1 <= x0 || y1 <= y0) r.tx1 = r.tx0, r.ty1 = r.ty0;
-        db = __float_as_uint(depths[n]);
+        g.x = in.p0.x; g.y = in.p0.y; g.A = in.p0.z; g.B = in.p0.w; g.C = in.p1.x;
+        g.smax = __float_as_uint(in.p1.z);
+        g.rx = __float_as_uint(in.p1.w);
+        g.ry = __float_as_uint(in.p2w);
+        r = tile_rect_of(g.rx, g.ry);
+        db = __float_as_uint(in.depth);
         db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
     }
     const int cnt = valid ? r.count() : 0;
@@ -372,7 +491,7 @@ k_scatter_global(int N, int tiles_x, int32_t capacity, const float4 *__restrict_
                  const float *__restrict__ depths, const int2 *__restrict__ bins,
                  int32_t *__restrict__ fill, uint4 *__restrict__ keys) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    scatter_tiles(packed, depths, n, n < N, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
+    scatter_tiles(scatter_request(packed, depths, n, n < N), n, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
         const int pos = bins[tile].x + atomicAdd(&fill[tile], 1);
         if (pos < capacity) keys[pos] = make_uint4(d, (uint32_t)g, m, 0u);
     });
@@ -388,17 +507,23 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
           const int32_t *__restrict__ wg_base, uint4 *__restrict__ keys) {
     extern __shared__ int32_t h[];
     const int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
+    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
+    // few thousand Gaussians with huge rectangles still keep every CU's waves busy; the records of the
+    // next chunk are in flight while the current one is scattered (see k_count_tiles)
+    const int stride = (blockDim.x >> 6) * gridDim.x, lane = threadIdx.x & 63;
+    int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    ScatterIn in = scatter_request(packed, depths, chunk * 64 + lane, (int64_t)chunk * 64 + lane < N);
     for (int t = threadIdx.x; t < tiles; t += blockDim.x) h[t] = bins[t].x + my_base[t];
     __syncthreads();
-    // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
-    // few thousand Gaussians with huge rectangles still keep every CU's waves busy
-    for (int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x; chunk * 64 < N;
-         chunk += (blockDim.x >> 6) * gridDim.x) {
-        const int n = chunk * 64 + (threadIdx.x & 63);
-        scatter_tiles(packed, depths, n, n < N, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
+    for (; (int64_t)chunk * 64 < N; chunk += stride) {
+        const int n = chunk * 64 + lane;
+        const int64_t nn = (int64_t)n + (int64_t)stride * 64;   // (may not fit an int beyond the last chunk)
+        const ScatterIn next = scatter_request(packed, depths, (int)(nn < N ? nn : 0), nn < N);
+        scatter_tiles(in, n, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
             const int pos = atomicAdd(&h[tile], 1);
             if (pos < capacity) keys[pos] = make_uint4(d, (uint32_t)g, m, 0u);
         });
+        in = next;
     }
 }
 
@@ -632,17 +757,6 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
 // into registers (PL per lane), bucket b is owned by lane b % 64 (conflict-free LDS access), the
 // exclusive scan is B/64 DPP wave scans.  LDS: 10*64*PL + 4*B bytes (7 KiB for PL = 8, B = 512),
 // so that many tiles are resident per CU and their global-memory round trips overlap.
-__device__ __forceinline__ int wave_inclusive_scan_i(int v) {
-    // Hillis-Steele inside each 16-lane row (row_shr with zero fill), then the two row carries
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 template <int PL, int B>
 __global__ void __launch_bounds__(64)
 k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
@@ -877,12 +991,15 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
         const size_t lds = sizeof(int32_t) * ((size_t)tiles + tiles / 32 + 1);
         const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
         if (use_lds)
-            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scan_tiles),
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scan_tiles_fast),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
-        hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
-                           counts, reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host,
-                           tile_order);
+        if (use_lds)
+            hipLaunchKernelGGL(gs::k_scan_tiles_fast, dim3(1), dim3(1024), lds, s, tiles, counts,
+                               reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
+        else
+            hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, 0, counts,
+                               reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
     }
     GS_LAUNCH_CHECK();
     return GS_OK;
