@@ -285,6 +285,10 @@ class Pipeline:
                                    self.cam_pos, s.K, s.degrees_to_use, g["radii"], g["rgb_raw"],
                                    self.bwd_ws, gout, ZEROED | ACC, viewmat_dev=self.vm_dev,
                                    projmat_dev=self.pm_dev)
+            if self.fx is not None:
+                # this camera's colour cotangents go on the wire now: the all-gather runs on RCCL's
+                # stream while the next local camera is rendered
+                self.fx.start_camera(slot)
             mark()
             break
         self.num_isects = b.num_isects

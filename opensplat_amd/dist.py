@@ -148,7 +148,11 @@ class FactoredExchange:
     — 56 instead of 236 MB at W = 2, 161 instead of 413 MB at W = 8.  With c cameras per rank the
     all-gather grows to c x 12 MB per rank: the flat exchange wins once c x W exceeds ~32.
 
-    Layout of a rank's message: [ camera centres: 4 floats x c | v_colour: c x N x 3 floats ].
+    Layout: ONE message per local camera, [ camera centre x y z 0 | v_colour N x 3 ] (4 + 3 N floats), each
+    gathered by its own collective.  With c > 1 cameras per rank the gather of camera j is issued as soon
+    as ITS backward has been enqueued (start_camera) and runs on RCCL's stream while camera j + 1 is
+    rendered: of the exchange only the last camera's gather and the ONE geometry all-reduce (the local
+    cameras' geometry gradients are summed in place first, GS_FLAG_ACCUMULATE_GRADS) stay exposed.
     """
 
     def __init__(self, N: int, K: int, cameras_per_rank: int, device):
@@ -156,21 +160,24 @@ class FactoredExchange:
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.multi else 1
         self.rank = dist.get_rank() if self.multi else 0
-        self.hdr = 4 * self.cpr
-        self.chunk = self.hdr + self.cpr * N * 3
-        self.recv = torch.zeros(self.world * self.chunk, dtype=torch.float32, device=device)
+        self.msg = 4 + 3 * N                           # floats of one camera's message
+        self.chunk = self.cpr * self.msg               # floats a rank contributes per exchange
+        # recv[j]: the world's messages for local-camera slot j, in rank order
+        self.recv = torch.zeros((self.cpr, self.world * self.msg), dtype=torch.float32, device=device)
         # (a one-rank "exchange" runs in place: the rank's message is the gathered buffer)
-        self.send = torch.zeros(self.chunk, dtype=torch.float32, device=device) if self.multi else self.recv
-        self._w_gather = self._w_geo = None
+        self.send = torch.zeros((self.cpr, self.msg), dtype=torch.float32, device=device) if self.multi \
+            else self.recv
+        self._w_gather = [None] * self.cpr
+        self._started = [False] * self.cpr
+        self._w_geo = None
 
     def v_color(self, j: int) -> torch.Tensor:
-        """[N, 3] view of the message where gs_gaussian_backward (GS_FLAG_EMIT_VCOLOR) puts local
-        camera j's colour cotangent."""
-        o = self.hdr + j * self.N * 3
-        return self.send[o:o + self.N * 3].view(self.N, 3)
+        """[N, 3] view of camera j's message where gs_gaussian_backward (GS_FLAG_EMIT_VCOLOR) puts its
+        colour cotangent."""
+        return self.send[j, 4:4 + self.N * 3].view(self.N, 3)
 
     def set_cam_pos(self, j: int, cam_pos: torch.Tensor) -> None:
-        self.send[4 * j:4 * j + 3].copy_(cam_pos.reshape(-1)[:3])
+        self.send[j, 0:3].copy_(cam_pos.reshape(-1)[:3])
 
     @property
     def bytes_moved_per_rank(self) -> int:
@@ -179,27 +186,36 @@ class FactoredExchange:
         w = self.world
         return int(2 * (w - 1) / w * 11 * self.N * 4 + (w - 1) * self.chunk * 4) if w > 1 else 0
 
+    def start_camera(self, j: int) -> None:
+        """All-gather of local camera j's message; call right behind that camera's gs_gaussian_backward.
+        Runs while the next local camera is rendered."""
+        if self.multi and not self._started[j]:
+            self._w_gather[j] = dist.all_gather_into_tensor(self.recv[j], self.send[j], async_op=True)
+        self._started[j] = True
+
     def start(self, grads: GradBuffer):
-        """Enqueue both collectives (after the last local camera's backward): the all-gather first —
-        its consumer, the SH backward over all cameras plus the Adam step of 48 of the 59 parameters
-        per Gaussian, then overlaps the geometry all-reduce."""
-        self._w_gather = self._w_geo = None
-        if not self.multi:
-            return
-        self._w_gather = dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
-        self._w_geo = dist.all_reduce(grads.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
+        """Behind the LAST local camera's backward: the gathers that are not on their way yet, then the
+        geometry all-reduce — its consumer comes last: the SH backward over all cameras plus the Adam step
+        of 48 of the 59 parameters per Gaussian overlap it."""
+        for j in range(self.cpr):
+            self.start_camera(j)
+        self._w_geo = None
+        if self.multi:
+            self._w_geo = dist.all_reduce(grads.rest_block(), op=dist.ReduceOp.SUM, async_op=True)
 
     def finish_sh(self, grads: GradBuffer, means: torch.Tensor, degrees_to_use: int) -> None:
-        """Wait for the all-gather, then form the SH gradients of ALL cameras into the flat buffer."""
+        """Per local camera: wait for its gather, then add the SH gradients of that slot's cameras (one per
+        rank) to the flat buffer."""
         from . import cabi
 
-        wait_all(self._w_gather)
-        self._w_gather = None
         for j in range(self.cpr):
+            wait_all(self._w_gather[j])
+            self._w_gather[j] = None
+            self._started[j] = False
             cabi.sh_backward_cameras(
-                self.K, degrees_to_use, means, self.recv[4 * j:], self.recv[self.hdr + j * self.N * 3:],
+                self.K, degrees_to_use, means, self.recv[j], self.recv[j, 4:],
                 grads.v_dc, grads.v_rest, cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0,
-                cam_pos_stride=self.chunk, v_colors_stride=self.chunk, n_cams=self.world)
+                cam_pos_stride=self.msg, v_colors_stride=self.msg, n_cams=self.world)
 
     def finish_geometry(self) -> None:
         wait_all(self._w_geo)

@@ -147,8 +147,9 @@ def _fx_worker(rank, world, port, N, K, cpr, q):
     for j in range(cpr):
         fx.set_cam_pos(j, torch.tensor([rank, j, 7.0]))
         fx.v_color(j).fill_(10.0 * rank + j)
+    fx.start_camera(0)                # (what the pipeline does behind the first camera's backward)
     fx.start(grads)
-    gdist.wait_all(fx._w_gather)      # (finish_sh would launch the HIP kernel: GPU test)
+    gdist.wait_all(*fx._w_gather)     # (finish_sh would launch the HIP kernel: GPU test)
     fx.finish_geometry()
     q.put((rank, grads.flat.numpy().copy(), fx.recv.numpy().copy(), fx.bytes_moved_per_rank))
     torch.distributed.destroy_process_group()
@@ -156,7 +157,8 @@ def _fx_worker(rank, world, port, N, K, cpr, q):
 
 def test_factored_exchange_messages_world2():
     """dist.FactoredExchange on two gloo ranks: the geometry block is summed, the SH block is left
-    alone, and both ranks hold both messages [camera centres | colour cotangents] in rank order."""
+    alone, and both ranks hold, per local-camera slot, both ranks' messages [camera centre | colour
+    cotangent] in rank order."""
     N, K, world, cpr = 37, 16, 2, 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -175,11 +177,11 @@ def test_factored_exchange_messages_world2():
         flat, msg, moved = got[rank]
         assert np.array_equal(flat[:sh], base[:sh] * (rank + 1))          # SH block: not exchanged
         assert np.array_equal(flat[sh:], base[sh:] * 3)                   # geometry: summed (1 + 2)
-        chunk = 4 * cpr + cpr * N * 3
-        assert msg.size == world * chunk
-        for r in range(world):
-            m = msg[r * chunk:(r + 1) * chunk]
-            for j in range(cpr):
-                assert list(m[4 * j:4 * j + 3]) == [r, j, 7.0]
-                assert np.all(m[4 * cpr + j * N * 3:4 * cpr + (j + 1) * N * 3] == 10.0 * r + j)
-        assert moved == int(2 * 0.5 * 11 * N * 4 + chunk * 4)
+        one = 4 + N * 3                                  # one camera's message
+        assert msg.shape == (cpr, world * one)            # slot j: the world's cameras j, in rank order
+        for j in range(cpr):
+            for r in range(world):
+                m = msg[j, r * one:(r + 1) * one]
+                assert list(m[0:3]) == [r, j, 7.0]
+                assert np.all(m[4:] == 10.0 * r + j)
+        assert moved == int(2 * 0.5 * 11 * N * 4 + cpr * one * 4)
