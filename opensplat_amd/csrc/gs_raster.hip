@@ -79,6 +79,19 @@ __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 struct __attribute__((aligned(16))) SRec {
     float4 p0, p1, p2;  // the packed record as gathered: {x y A B | C o smax rx | r g b ry}
 };
+// The backward's staged record: the rectangle words (read by the rare binding entries only) move to a
+// fourth vector and their places carry the entry's VISIBILITY thresholds: alpha = o * vis >= 1/255 is
+// decided as vis >= (1/255) / o, formed once per staged entry instead of once per pixel pass.
+//   {x y A B | C o smax t_hi | r g b t_lo | rx ry - -},  t_hi/lo = (1/255) / o * (1 +- kVisBand)
+// vis >= t_hi: certainly a contributor; vis < t_lo: certainly none; in between the pass redoes the
+// forward's exact arithmetic.  The band covers the fast exponential (2^-21), the backward's fused sigma
+// (<= 1.5e-6 relative in vis at sigma = 5.5) and the roundings of the threshold itself.
+struct __attribute__((aligned(16))) SRecB {
+    float4 p0, p1, p2;
+    float2 p3;
+    float2 pad;
+};
+constexpr float kVisBand = 4.0e-6f;
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -133,16 +146,56 @@ __device__ __forceinline__ uint32_t touch_from_mask(uint32_t m, int ox, int oy) 
            ((t & (blk << (4 * dr + dc))) ? 8u : 0u);
 }
 
-__device__ __forceinline__ void stage_sentinel(SRec *s) {
+template <class R>
+__device__ __forceinline__ void stage_sentinel(R *s) {
     s->p0 = make_float4(qnan(), 0.0f, 0.0f, 0.0f);
     s->p1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     s->p2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // next entry of each group's walk; an exhausted group gets the sentinel slot
+#ifndef GS_WALK_BITSET
+#define GS_WALK_BITSET 1
+#endif
+#if GS_WALK_BITSET
+// clearing the bit just found is ONE scalar instruction (s_bitset0_b64; `m &= m - 1` is three); for an
+// exhausted group e = 64 addresses bit 0 of a mask that is already zero
+#define GS_WALK_STEP(m, e)                                        \
+    const int e = (m) != 0ull ? (int)__builtin_ctzll(m) : kChunk; \
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(e));
+#else
 #define GS_WALK_STEP(m, e)                                   \
     const int e = (m) != 0ull ? (int)__builtin_ctzll(m) : kChunk; \
     (m) &= (m)-1ull;
+#endif
+// The walk of a chunk: the four groups' next slots packed into one SGPR (a lane extracts its group's
+// with one v_bfe_u32).  GS_WALK_COUNT: the number of steps — the longest of the four lists, which do
+// not change during the walk — is taken once per chunk and the loop counts (add, compare) instead of
+// OR-ing four 64-bit masks per step.  GS_WALK_AHEAD: the packed slots of step i + 1 are formed while
+// step i computes (scalar work off the critical path of the step's first LDS read).
+#ifndef GS_WALK_COUNT
+#define GS_WALK_COUNT 0
+#endif
+#ifndef GS_WALK_AHEAD
+#define GS_WALK_AHEAD 1
+#endif
+#define GS_WALK_PACK(ep)                                                                             \
+    uint32_t ep;                                                                                     \
+    {                                                                                                \
+        GS_WALK_STEP(m0, e0_)                                                                        \
+        GS_WALK_STEP(m1, e1_)                                                                        \
+        GS_WALK_STEP(m2, e2_)                                                                        \
+        GS_WALK_STEP(m3, e3_)                                                                        \
+        ep = (uint32_t)e0_ | ((uint32_t)e1_ << 8) | ((uint32_t)e2_ << 16) | ((uint32_t)e3_ << 24);   \
+    }
+#if GS_WALK_COUNT
+#define GS_WALK_LOOP_BEGIN                                                                                     \
+    const int steps_ = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),                            \
+                           max(__builtin_popcountll(m2), __builtin_popcountll(m3)));                           \
+    for (int it_ = 0; it_ < steps_; ++it_) {
+#else
+#define GS_WALK_LOOP_BEGIN while ((m0 | m1 | m2 | m3) != 0ull) {
+#endif
 
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
@@ -200,6 +253,13 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             stage[lane].p1 = n1;
             stage[lane].p2 = n2;
         }
+        // does any staged entry carry a rectangle that cuts its sigma_max ellipse (rare)?  Decided once
+        // per chunk: the walk of a chunk without one does not look at the flag at all
+#ifndef GS_FWD_CHUNK_BINDS
+#define GS_FWD_CHUNK_BINDS 0
+#endif
+        const bool chunk_binds = !GS_FWD_CHUNK_BINDS ||
+            __builtin_amdgcn_ballot_w64(touch != 0u && (__float_as_uint(n1.z) & 1u) != 0u) != 0ull;
         // a block whose 16 pixels are all finished walks nothing
         uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
         uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
@@ -216,15 +276,22 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
             }
         }
-        while ((m0 | m1 | m2 | m3) != 0ull) {
-            GS_WALK_STEP(m0, e0)
-            GS_WALK_STEP(m1, e1)
-            GS_WALK_STEP(m2, e2)
-            GS_WALK_STEP(m3, e3)
-            // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
-            const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
+        auto walk = [&](auto binds_tag) {
+          constexpr bool BINDS = decltype(binds_tag)::value;
+#if GS_WALK_AHEAD
+          uint32_t ep_next;
+          { GS_WALK_PACK(ep0_) ep_next = ep0_; }
+          while (ep_next != 0x40404040u) {
+            const uint32_t ep = ep_next;
             const int e = (int)((ep >> gsh) & 0xFFu);
             const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+            { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
+#else
+          GS_WALK_LOOP_BEGIN
+            GS_WALK_PACK(ep)
+            const int e = (int)((ep >> gsh) & 0xFFu);
+            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+#endif
             const uint32_t sbits = __float_as_uint(q1.z);
             GS_STAT(0, 1);
             const float dx = q0.x - pxf, dy = q0.y - pyf;
@@ -233,8 +300,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             sg = 0.5f * sg;
             sg = sg + (q0.w * dx) * dy;
             // (lane predicates as 64-bit scalar masks + inverse_ballot: one compare per predicate)
-            const uint64_t mbinds = __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u);
-            if (mbinds != 0ull) {
+            const uint64_t mbinds = BINDS ? __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) : 0ull;
+            if (BINDS && mbinds != 0ull) {
                 // rare: some group's Gaussian has a rectangle that cuts its sigma_max ellipse —
                 // apply the rectangle per pixel (and turn -0.0 into +0.0, see gs_pack_splats)
                 asm volatile("; rectangle binds");
@@ -272,7 +339,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a2 = a2 + w * q2.z;
             T = nT;
             le = ok ? e : le;
-        }
+          }
+        };
+        if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
         last = le >= 0 ? c0 + le : last;
         le = -1;
     }
@@ -373,7 +442,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                      float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
     using G = WaveGeom<PX>;
-    __shared__ SRec stage[kChunk + 1];
+    __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
     __shared__ float acc[kAcc * kAccStride];
     const int lane = threadIdx.x;
@@ -467,9 +536,12 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
             const float4 n0 = packed[3 * (size_t)ng + 0], n1 = packed[3 * (size_t)ng + 1],
                          n2 = packed[3 * (size_t)ng + 2];
 #endif
+            // (an opacity <= 0 never reaches 1/255: threshold +inf)
+            const float tv = n1.y > 0.0f ? (1.0f / 255.0f) / n1.y : __builtin_inff();
             stage[lane].p0 = n0;
-            stage[lane].p1 = n1;
-            stage[lane].p2 = n2;
+            stage[lane].p1 = make_float4(n1.x, n1.y, n1.z, tv * (1.0f + kVisBand));
+            stage[lane].p2 = make_float4(n2.x, n2.y, n2.z, tv * (1.0f - kVisBand));
+            stage[lane].p3 = make_float2(n1.w, n2.w);
             binds_t = (__float_as_uint(n1.z) & 1u) != 0u;
         }
         if (hi - lane >= range.x) sid[lane] = ng;
@@ -503,15 +575,20 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         bool flushed_any = false;  // wave-uniform
         auto walk = [&](auto binds_tag) {
             constexpr bool BINDS = decltype(binds_tag)::value;
-            while ((m0 | m1 | m2 | m3) != 0ull) {
-                GS_WALK_STEP(m0, e0)
-                GS_WALK_STEP(m1, e1)
-                GS_WALK_STEP(m2, e2)
-                GS_WALK_STEP(m3, e3)
-                // the four slots packed into one SGPR; each lane extracts its group's (one v_bfe_u32)
-                const uint32_t ep = (uint32_t)e0 | ((uint32_t)e1 << 8) | ((uint32_t)e2 << 16) | ((uint32_t)e3 << 24);
+#if GS_WALK_AHEAD
+            uint32_t ep_next;
+            { GS_WALK_PACK(ep0_) ep_next = ep0_; }
+            while (ep_next != 0x40404040u) {
+                const uint32_t ep = ep_next;
                 const int e = (int)((ep >> gsh) & 0xFFu);
                 const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+                { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
+#else
+            GS_WALK_LOOP_BEGIN
+                GS_WALK_PACK(ep)
+                const int e = (int)((ep >> gsh) & 0xFFu);
+                const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+#endif
                 const uint32_t sbits = __float_as_uint(q1.z);
                 const int idx = hi - e;  // index of this entry in the sorted list
                 GS_STAT(8, 1);
@@ -520,8 +597,9 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                 const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
                 // rectangle test data of the rare entries whose rectangle cuts the sigma_max ellipse
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
-                float su = 0.0f, suy = 0.0f, suyy = 0.0f, gr = 0.0f, gg = 0.0f, gb = 0.0f;
-                bool any = false;  // wave-uniform
+                // (-0 is the identity of the addition: the first live pass adds to nothing)
+                float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
+                uint64_t anym = 0ull;  // lanes that needed the entry in some pass
     #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
@@ -536,7 +614,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                             float se = Adxdx + (q1.x * dy) * dy;
                             se = 0.5f * se;
                             se = se + Bdx * dy;
-                            const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                            const float2 q3 = stage[e].p3;
+                            const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y);
                             const uint32_t pyu = (uint32_t)(py0 + p * G::LH);
                             const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
                                             pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
@@ -549,38 +628,43 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                     const uint64_t mneed = __builtin_amdgcn_ballot_w64(idx <= last[p]) &
                                            __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
                     if (mneed == 0ull) continue;
-                    any = true;
+                    anym |= mneed;
                     GS_STAT(9, 1);
                     GS_STAT(10, __builtin_popcountll(mneed));
                     // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338.  Lanes
                     // that do not need the entry keep whatever the exponential makes of their sigma
                     // (possibly inf or NaN) until `ok` discards it: they end with vis = alpha = 0
                     float vis = __expf(-sg);
-                    float alpha = q1.y * vis;
+                    uint64_t mok;
                     if (EXACT) {
-                        // same >= 1/255 decision as the forward: redo the exponential exactly (from the
-                        // forward's sigma) where the fast one cannot decide
-                        const float thr = 1.0f / 255.0f;
-                        const uint64_t mamb = mneed & __builtin_amdgcn_ballot_w64(fabsf(alpha - thr) < 1.0e-8f);
-                        if (mamb != 0ull) {
+                        // the forward's >= 1/255 decision, taken on vis against the entry's thresholds
+                        // (SRecB); inside the band the forward's own arithmetic is redone — its sigma,
+                        // the exact exponential, alpha = o * vis — and decides
+                        const uint64_t bhi = __builtin_amdgcn_ballot_w64(vis >= q1.w);
+                        const uint64_t blo = __builtin_amdgcn_ballot_w64(vis >= q2.w);
+                        mok = mneed & bhi;
+                        if (bhi != blo) {   // some lane sits in the band (one scalar compare when none does)
                             asm volatile("; threshold ambiguous");
-                            if (__builtin_amdgcn_inverse_ballot_w64(mamb)) {
+                            bool in = false;
+                            if (__builtin_amdgcn_inverse_ballot_w64(mneed & blo & ~bhi)) {
                                 float se = Adxdx + (q1.x * dy) * dy;
                                 se = 0.5f * se;
                                 se = se + Bdx * dy;
                                 vis = expf_glibc_cmem(-se);
-                                alpha = q1.y * vis;
+                                in = q1.y * vis >= (1.0f / 255.0f);
                             }
+                            mok |= __builtin_amdgcn_ballot_w64(in);
                         }
+                    } else {
+                        mok = mneed & __builtin_amdgcn_ballot_w64(q1.y * vis >= (1.0f / 255.0f));
                     }
-                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(
-                        mneed & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)));
-                    alpha = ok ? __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.99f) : 0.0f;
-                    vis = ok ? vis : 0.0f;
-                    // ra = 1 / (1 - alpha): hardware reciprocal + one Newton step
+                    vis = __builtin_amdgcn_inverse_ballot_w64(mok) ? vis : 0.0f;
+                    const float alpha = fminf(q1.y * vis, 0.99f);   // 0 where the entry does not contribute
+                    // ra = 1 / (1 - alpha) by the hardware reciprocal (1 ulp; exactly 1 for alpha = 0): T
+                    // is a running product either way — a correctly rounded quotient would make its
+                    // error 1 instead of 1.5 ulp per entry
                     const float om = 1.0f - alpha;
-                    float ra = __builtin_amdgcn_rcpf(om);
-                    ra = fmaf(ra, fmaf(-om, ra, 1.0f), ra);
+                    const float ra = __builtin_amdgcn_rcpf(om);
                     T[p] = T[p] * ra;  // transmittance in front of this Gaussian
                     const float fac = alpha * T[p];
                     gr = fmaf(fac, vo0[p], gr);
@@ -597,7 +681,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                     suy += uy;
                     suyy = fmaf(uy, dy, suyy);
                 }
-                if (!any) continue;
+                if (anym == 0ull) continue;
                 // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
                 const float ux = su * dx;
                 const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
@@ -657,6 +741,8 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
     }
 }
 #undef GS_WALK_STEP
+#undef GS_WALK_PACK
+#undef GS_WALK_LOOP_BEGIN
 
 
 // Splits the 64-byte gradient records into the four tensors the operator surface returns

@@ -83,24 +83,33 @@ inline std::vector<torch::optim::Adam *> optimizers(M &m) {   // in the order of
 template <class M>
 inline void optimizers_step(M &m) {
     torch::NoGradGuard noGrad;
-    std::vector<torch::Tensor> params, grads, expAvg, expAvgSq;
-    std::vector<double> lrs;
-    int64_t step = -1;
+    // one launch takes one step count.  The six optimisers of a Model step together, so there is one
+    // launch — except after the reference's own alpha reset (GS_FUSED_REFERENCE_ALPHA_RESET), which
+    // leaves opacitiesOpt some steps behind the others for good (its parameter is unknown to it until
+    // the next refinement): groups are launched by step count
+    struct Batch {
+        int64_t step;
+        std::vector<torch::Tensor> params, grads, expAvg, expAvgSq;
+        std::vector<double> lrs;
+    };
+    std::vector<Batch> batches;
     for (torch::optim::Adam *opt : detail::optimizers(m)) {
         torch::Tensor p = opt->param_groups()[0].params()[0];
         if (!p.grad().defined() || p.numel() == 0) continue;   // (what Adam::step skips)
         auto &s = detail::adam_state(opt, p);
         s.step(s.step() + 1);
-        // one kernel takes one step count: the six optimisers of a Model always step together
-        TORCH_CHECK(step < 0 || step == s.step(), "gs_fused::optimizers_step: step counts differ");
-        step = s.step();
-        params.push_back(p);
-        grads.push_back(p.grad().contiguous());
-        expAvg.push_back(s.exp_avg());
-        expAvgSq.push_back(s.exp_avg_sq());
-        lrs.push_back(static_cast<torch::optim::AdamOptions &>(opt->param_groups()[0].options()).lr());
+        auto b = std::find_if(batches.begin(), batches.end(), [&](const Batch &x) { return x.step == s.step(); });
+        if (b == batches.end()) {
+            batches.push_back(Batch{s.step(), {}, {}, {}, {}, {}});
+            b = batches.end() - 1;
+        }
+        b->params.push_back(p);
+        b->grads.push_back(p.grad().contiguous());
+        b->expAvg.push_back(s.exp_avg());
+        b->expAvgSq.push_back(s.exp_avg_sq());
+        b->lrs.push_back(static_cast<torch::optim::AdamOptions &>(opt->param_groups()[0].options()).lr());
     }
-    if (!params.empty()) fusedAdamStep(params, grads, expAvg, expAvgSq, lrs, step);
+    for (const Batch &b : batches) fusedAdamStep(b.params, b.grads, b.expAvg, b.expAvgSq, b.lrs, b.step);
 }
 
 // ---- Model::afterTrain (model.cpp:311-494) ----------------------------------------------------------------

@@ -116,6 +116,7 @@ class Trainer:
         self.bucket_single_rank = False   # tests: take the bucketed path without a process group
         self._pending = None
         self._opacity_frozen = False
+        self._opacity_lag = 0        # optimiser steps the opacities' Adam state is behind (reference_alpha_reset)
         self._visible = True
         self._stats = None          # (xysGradNorm, visCounts, max2DSize); None = cleared
         self.step_count = 0
@@ -249,21 +250,32 @@ class Trainer:
             cnt = P.views[v].numel()
             a, b = max(lo, o), min(hi, o + cnt)
             if a < b and not (n == "opacities" and self._opacity_frozen):
-                out.append((P.flat[a:b], G.flat[a:b], M.flat[a:b], V.flat[a:b], lr[n]))
+                out.append((P.flat[a:b], G.flat[a:b], M.flat[a:b], V.flat[a:b], lr[n],
+                            self._opacity_lag if n == "opacities" else 0))
             o += cnt
         return out
+
+    def _adam(self, groups):
+        """gs_adam_step takes ONE step count per launch: groups are launched by step count (one launch,
+        unless the reference's alpha reset left the opacities' optimiser behind: reference_alpha_reset)."""
+        for lag in sorted({g[5] for g in groups}):
+            cabi.adam_step([g[:5] for g in groups if g[5] == lag], self.step_count - lag)
 
     def optimizer_step(self):
         """Model::optimizersStep + schedulersStep (model.cpp:236-247)."""
         self.step_count += 1
+        if self._opacity_frozen:
+            # torch::optim::Adam skips a parameter without gradient: its step count stays behind for
+            # good (the re-registration at the next refinement copies it, model.cpp:253-309)
+            self._opacity_lag += 1
         if self._pending is None:
-            cabi.adam_step(self.adam_groups(), self.step_count)
+            self._adam(self.adam_groups())
         else:
             for lo, hi, ready in self._pending:     # Adam of bucket k overlaps the transfer of k + 1
                 ready()
                 groups = self.adam_groups(lo, hi)
                 if groups:
-                    cabi.adam_step(groups, self.step_count)
+                    self._adam(groups)
             self._pending = None
         # OptimScheduler::step(step) sets the lr the NEXT optimiser step uses (opensplat.cpp:168-169)
         self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps,

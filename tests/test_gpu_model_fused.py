@@ -76,10 +76,10 @@ def cam_to_world(yaw_deg):
     return c2w
 
 
-def run_shim(tmp_path, case, device, tag):
+def run_shim(tmp_path, case, device, tag, shim=SHIM):
     cpath, opath = str(tmp_path / ("case_%s.bin" % tag)), str(tmp_path / ("out_%s_%s.bin" % (tag, device)))
     write_arrays(cpath, case)
-    r = subprocess.run([SHIM, cpath, opath, "--device", device], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([shim, cpath, opath, "--device", device], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     return read_arrays(opath), r.stdout
 
@@ -102,7 +102,7 @@ def make_case(params, fx, fy, W, H, yaws, iters, shDegree, **cfg):
     return case, c, gts
 
 
-def run_trainer(params, fx, fy, W, H, yaws, iters, gts, c):
+def run_trainer(params, fx, fy, W, H, yaws, iters, gts, c, **kw):
     import torch
 
     from opensplat_amd import train
@@ -114,7 +114,7 @@ def run_trainer(params, fx, fy, W, H, yaws, iters, gts, c):
                        densify_size_thresh=c["densifySizeThresh"], stop_screen_size_at=c["stopScreenSizeAt"],
                        split_screen_size=c["splitScreenSize"], num_cameras=c["numCameras"],
                        num_downscales=c["numDownscales"], resolution_schedule=c["resolutionSchedule"],
-                       sh_degree_interval=c["shDegreeInterval"])
+                       sh_degree_interval=c["shDegreeInterval"], **kw)
     cams = [colmap.render_camera(colmap.Camera(width=W, height=H, fx=fx, fy=fy, cx=W / 2.0, cy=H / 2.0,
                                                cam_to_world=cam_to_world(y))) for y in yaws]
     bg = np.array(scenes.BACKGROUND, np.float32)
@@ -129,6 +129,7 @@ def run_trainer(params, fx, fy, W, H, yaws, iters, gts, c):
     return dict(losses=np.array(losses, np.float32), p0=np_(P.v_means), p1=np_(P.v_scales), p2=np_(P.v_quats),
                 p3=np_(P.v_opacity).reshape(-1, 1), p4=np_(P.v_dc), p5=np_(P.v_rest),
                 m0=np_(tr.exp_avg.v_means), v0=np_(tr.exp_avg_sq.v_means), means_lr=tr.means_lr,
+                m3=np_(tr.exp_avg.v_opacity).reshape(-1, 1), v3=np_(tr.exp_avg_sq.v_opacity).reshape(-1, 1),
                 stats=None if tr._stats is None else [np_(t) for t in tr._stats], N=tr.N)
 
 
@@ -193,3 +194,62 @@ def test_patched_reference_model_refines_on_the_device(tmp_path):
     # the same counts after every refinement (decisions do not depend on the split samples)
     assert py["N"] == N
     assert np.abs(gpu["losses"][:6] - py["losses"][:6]).max() < 2e-6   # identical until the first split samples
+
+
+SHIM_REFALPHA = SHIM + "_refalpha"
+
+
+@needs_shim
+@pytest.mark.skipif(not os.path.exists(SHIM_REFALPHA), reason="oracle/_ref/model_fused_shim_refalpha not built")
+def test_patched_reference_model_alpha_reset_in_both_modes(tmp_path):
+    """The alpha reset (model.cpp:464-479) inside the loop, in both builds of model_fused.inl: refine every
+    3, reset interval 9 -> reset at step 3, nothing else until step 6.  Default build: the registered
+    parameter is clamped in place and its moments zeroed (the evident intent), the opacities keep training.
+    -DGS_FUSED_REFERENCE_ALPHA_RESET: what the reference's statements do — `opacities` re-bound to a clamped
+    copy the optimiser does not know, moments left alone, nothing updates them until a refinement
+    re-registers the tensor.  Each against the Python Trainer in the same mode; the reference mode also
+    against the reference's OWN statements (the CPU device of the same patched model.cpp)."""
+    W, H, yaws = 160, 112, [0.0]
+    params, fx, fy = separated_scene(W, H, K=4, seed=5)
+    kw = dict(shDegree=1, refineEvery=3, warmupLength=2, resetAlphaEvery=3, numCameras=0)
+    logit = np.float32(np.log(np.float32(0.2) / (np.float32(1.0) - np.float32(0.2))))
+    assert (params[3] > logit + 0.5).all()       # every opacity is above the reset value: all get clamped
+
+    case, c, gts = make_case(params, fx, fy, W, H, yaws, 5, **kw)
+    # ---- the reference's actual behaviour -----------------------------------------------------------
+    ref_gpu, out = run_shim(tmp_path, case, "gpu", "ra", SHIM_REFALPHA)
+    assert "Alpha reset" in out
+    ref_cpu, _ = run_shim(tmp_path, case, "cpu", "ra", SHIM_REFALPHA)   # model.cpp:464-479 as written
+    ref_py = run_trainer(params, fx, fy, W, H, yaws, 5, gts, c, reference_alpha_reset=True)
+    for r in (ref_gpu, ref_cpu, ref_py):          # frozen at the reset value through steps 4 and 5
+        assert np.abs(r["p3"] - logit).max() < 1e-6
+    assert rel(ref_gpu["m3"], ref_py["m3"]) < 2e-5 and rel(ref_gpu["v3"], ref_py["v3"]) < 2e-5
+    assert np.abs(ref_gpu["m3"]).max() > 0        # ... and not zeroed
+    assert rel(ref_gpu["m3"], ref_cpu["m3"]) < 2e-3 and rel(ref_gpu["v3"], ref_cpu["v3"]) < 4e-3
+    assert np.abs(ref_gpu["losses"] - ref_py["losses"]).max() < 2e-6
+    assert np.abs(ref_gpu["losses"] - ref_cpu["losses"]).max() < 2e-5
+    for k in ("p0", "p1", "p2", "p4", "p5"):
+        assert rel(ref_gpu[k], ref_py[k].reshape(ref_gpu[k].shape)) < 2e-5, k
+    # ---- the evident intent (default build) -----------------------------------------------------------
+    gpu, out = run_shim(tmp_path, case, "gpu", "da")
+    assert "Alpha reset" in out
+    py = run_trainer(params, fx, fy, W, H, yaws, 5, gts, c)
+    assert np.abs(gpu["p3"] - logit).max() > 1e-3                       # two Adam steps away from the clamp
+    assert rel(gpu["p3"], py["p3"]) < 2e-5
+    assert rel(gpu["m3"], py["m3"]) < 2e-5 and rel(gpu["v3"], py["v3"]) < 2e-5
+    assert np.abs(gpu["losses"] - py["losses"]).max() < 2e-6
+    # the moments restarted from zero at step 3: two steps of history only
+    assert np.abs(gpu["v3"]).max() < np.abs(ref_gpu["v3"]).max()
+    # both modes render the same first four iterations (the reset shows from step 4's loss on ... equal too:
+    # the rendered opacities are the clamped ones in both; they part at step 5, after one more update)
+    assert np.abs(gpu["losses"][:4] - ref_gpu["losses"][:4]).max() < 2e-6
+    assert abs(gpu["losses"][4] - ref_gpu["losses"][4]) > 0
+
+    # ---- the refinement at step 6 re-registers the opacities in the reference mode too ----------------
+    case8, c8, gts8 = make_case(params, fx, fy, W, H, yaws, 8, densifyGradThresh=1e-7, **kw)
+    ref8, out = run_shim(tmp_path, case8, "gpu", "rb", SHIM_REFALPHA)
+    assert "Added" in out and ref8["counts"][4] == params[0].shape[0] and ref8["counts"][5] != params[0].shape[0]
+    py8 = run_trainer(params, fx, fy, W, H, yaws, 8, gts8, c8, reference_alpha_reset=True)
+    assert py8["N"] == int(ref8["counts"][-1])
+    assert ref8["m3"].shape[0] == py8["N"]
+    assert np.abs(ref8["p3"] - logit).max() > 1e-3                      # training again after step 6
