@@ -111,10 +111,17 @@ FUSED_HUNKS = [
      '// MI355X-native fused operators behind Model\'s own call sites (opensplat_amd/csrc)\n'
      '#include "model_fused.inl"\n'
      '#endif\n\n'),
-    ('    torch::Tensor colors =  torch::cat({featuresDc.index({Slice(), None, Slice()}), featuresRest}, 1);',
+    # in front of the camera matrices: on a GPU device the reference builds them ON the device
+    # (torch::eye(4, device) + two index_put_ of host tensors, projectionMatrix(..., device)): three
+    # synchronising host-to-device copies per iteration; the fused path keeps them on the host and hands
+    # them to the kernels by value
+    ('    torch::Tensor viewMat = torch::eye(4, device);',
      '#ifdef USE_HIP_NATIVE_FUSED\n'
-     '    if (device != torch::kCPU)\n'
-     '        return gs_fused::render(*this, viewMat, projMat, T, fx, fy, cx, cy, height, width, step);\n'
+     '    if (device != torch::kCPU){\n'
+     '        const float fovX_ = 2.0f * std::atan(width / (2.0f * fx)), fovY_ = 2.0f * std::atan(height / (2.0f * fy));\n'
+     '        return gs_fused::render(*this, Rinv, Tinv, T, projectionMatrix(0.001f, 1000.0f, fovX_, fovY_, torch::kCPU),\n'
+     '                                fx, fy, cx, cy, height, width, step);\n'
+     '    }\n'
      '#endif\n'),
     ('  meansOpt->step();',
      '#ifdef USE_HIP_NATIVE_FUSED\n'

@@ -3,7 +3,8 @@
 // Included by a model.cpp patched with `integration/apply_hip_native.py --fused` (macro
 // USE_HIP_NATIVE_FUSED); the patch adds four call sites, nothing else:
 //
-//   Model::forward      model.cpp:114-222  -> gs_fused::render          one SplatRender node: cat, exp,
+//   Model::forward      model.cpp:105-222  -> gs_fused::render          camera matrices kept on the host;
+//                                                                      one SplatRender node: cat, exp,
 //                                                                      normalise, view directions, SH,
 //                                                                      +0.5 / clamp, sigmoid, binning,
 //                                                                      compositing, clamp_max
@@ -36,26 +37,33 @@ namespace gs_fused {
 
 using torch::indexing::Slice;
 
-// ---- Model::forward: the render chain behind the camera set-up (model.cpp:114-222) ------------------
-// viewMat [4,4], projMat [4,4] (projectionMatrix(), NOT yet multiplied), T [3,1] = camera centre in
-// world space — the tensors Model::forward has in hand at that point.
+// ---- Model::forward from the camera matrices on (model.cpp:105-222) --------------------------------
+// Rinv [3,3], Tinv [3,1]: world -> camera (model.cpp:100-101); T [3,1]: the camera centre in world space;
+// projMat [4,4] = projectionMatrix() (NOT yet multiplied) — all HOST tensors, as Model::forward has
+// them at that point.  They stay on the host: the operators take 4x4 matrices and float[3] arguments by
+// value, so an iteration issues no host-to-device copy and never waits for the device (the reference
+// builds viewMat / projMat on the device — three synchronising copies — and reads radii.sum() back,
+// model.cpp:105-113,173).
 template <class M>
-inline torch::Tensor render(M &m, const torch::Tensor &viewMat, const torch::Tensor &projMat,
-                            const torch::Tensor &T, float fx, float fy, float cx, float cy, int height,
+inline torch::Tensor render(M &m, const torch::Tensor &Rinv, const torch::Tensor &Tinv, const torch::Tensor &T,
+                            const torch::Tensor &projMat, float fx, float fy, float cx, float cy, int height,
                             int width, int step) {
     const int degreesToUse = (std::min<int>)(step / m.shDegreeInterval, m.shDegree);
     const int64_t N = m.means.size(0);
+    torch::Tensor viewMat = torch::eye(4);                                   // model.cpp:105-107, on the host
+    viewMat.index_put_({Slice(torch::indexing::None, 3), Slice(torch::indexing::None, 3)}, Rinv);
+    viewMat.index_put_({Slice(torch::indexing::None, 3), Slice(3, 4)}, Tinv);
     // d loss / d xys, filled by the node's backward: Model::afterTrain reads it as xys.grad() (:318)
     torch::Tensor xysGrad = torch::zeros({N, 2}, m.means.options().requires_grad(false));
     auto out = SplatRender::apply(m.means, m.scales, m.quats, m.opacities, m.featuresDc, m.featuresRest,
-                                  viewMat, torch::matmul(projMat, viewMat),
-                                  T.transpose(0, 1).contiguous().to(m.device), fx, fy, cx, cy, height, width,
-                                  degreesToUse, m.backgroundColor.detach(), xysGrad);
+                                  viewMat, torch::matmul(projMat, viewMat), T.transpose(0, 1).contiguous(), fx, fy,
+                                  cx, cy, height, width, degreesToUse, m.backgroundColor.detach(), xysGrad);
     m.radii = out[2];
     m.xys = out[1].detach().requires_grad_();
-    // model.cpp:173-174 (the reference's own host synchronisation): nothing visible -> background, and
-    // xys.grad() stays undefined, which makes afterTrain return at once (:315)
-    if (m.radii.sum().template item<float>() == 0.0f) return m.backgroundColor.repeat({height, width, 1});
+    // model.cpp:173-174 reads radii.sum() back to return the bare background when nothing is visible — a
+    // tensor without graph, on which the training loop's backward() throws.  Not mirrored: such a frame
+    // renders the background here too (no Gaussian composited), with zero gradients, and costs no
+    // device synchronisation on every other frame
     m.xys.mutable_grad() = xysGrad;
     return out[0];
 }

