@@ -1061,20 +1061,35 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                            keys);
     }
     GS_LAUNCH_CHECK();
-    // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
-    // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
-    // longer: in place in global memory
     int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
     // Every class also moves the coverage masks (third word of the records) along with the keys.
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
-    // longer: in place in global memory.  The launches for the longer classes are skipped when the
-    // previous frame's longest list (list_stats[1]) was comfortably inside the first class.
-    const bool only_short = list_stats && list_stats[0] > 0 && list_stats[1] <= 400;
+    // longer: in place in global memory.
+    // Which classes are launched follows the PREVIOUS frame's statistics (list_stats = {M, longest
+    // list}); a launch over all tiles that finds nothing to do still costs its dispatch (39 us for the
+    // 256-thread class at 4K).  Whatever is launched last-in-class takes any longer segment itself (in
+    // place in global memory: slow, correct, and only on the frame where a list first outgrows the guess).
+    //   longest <= 400:              the 512 class alone
+    //   longest <= 900:              no 8192 class; lists mostly beyond 512 (mean > 300): the 1024 class
+    //                                alone, for every segment
+    //   otherwise / no statistics:   all three
+    const bool have_stats = list_stats && list_stats[0] > 0;
+    const bool only_short = have_stats && list_stats[1] <= 400;
+    const bool no_long = have_stats && list_stats[1] <= 900;
+    const bool only_mid = no_long && !only_short && (int64_t)list_stats[0] > 300 * (int64_t)tiles;
+    if (only_mid) {
+        hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
+                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        GS_LAUNCH_CHECK();
+        return GS_OK;
+    }
     if (!only_short) {
         hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
+                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
+    }
+    if (!no_long) {
         constexpr int CAP = 8192, B = 4096, NT = 256;
         const size_t lds = 8 * CAP + 4 * B + 64 + 2 * CAP;
         GS_HIP_CHECK(hipFuncSetAttribute(

@@ -516,6 +516,52 @@ def test_stale_list_statistics_only_cost_time():
     assert np.array_equal(np_(f["img"]), np_(ref["img"]))
 
 
+def test_sort_class_launch_policy_every_branch_and_every_stale_transition():
+    """gs_bin_sort launches its classes after the PREVIOUS frame's {M, longest list}: the 512 class alone
+    (longest <= 400), the 1024 class alone (longest <= 900, mean list > 300), the 512 + 1024 classes
+    (longest <= 900), all three otherwise.  Frames of each kind follow each other on ONE workspace, so that
+    every policy meets every kind of frame — also the ones it did not expect; ids and image must equal a
+    fresh run's (which launches everything) each time."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    W, H = 160, 96
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def find(cond, candidates):
+        for kw in candidates:
+            sc = scenes.camera_scene(W=W, H=H, K=0, znear=1.0, zfar=100.0, **kw)
+            out = hip_pipeline(sc, backward=False)
+            if cond(out["binned"].list_stats):
+                return sc, out
+        pytest.fail("no candidate scene had the wanted list statistics")
+
+    short = find(lambda st: st[1] <= 400, [dict(N=1500, seed=73)])
+    mid_dense = find(lambda st: 400 < st[1] <= 900 and st[0] > 300 * tiles,
+                     [dict(N=n, seed=75, sigma_px=(2.0, 5.0)) for n in range(8000, 30000, 1000)])
+    mid_sparse = find(lambda st: 400 < st[1] <= 900 and st[0] <= 300 * tiles,
+                      [dict(N=n, seed=76, sigma_px=(0.5, 2.0), hot=(0.3, 24)) for n in range(3000, 20000, 500)])
+    long_ = find(lambda st: st[1] > 1024, [dict(N=40000, seed=74, sigma_px=(2.0, 5.0))])
+    ws = cabi.BinWorkspace()
+    order = [mid_dense, mid_dense, long_, long_, mid_sparse, mid_sparse, long_, short, short, mid_dense,
+             mid_sparse, short, long_, mid_dense, short, mid_sparse, mid_dense]
+    for sc, ref in order:
+        opac = to_dev(sc.opacities.reshape(-1))
+        while True:
+            b = cabi.bin_and_sort(sc.W, sc.H, ref["xys"], ref["depths"], ref["radii"], ref["conics"], ref["colors"],
+                                  opac, ref["cov2d"], ws, speculative=True)
+            f = cabi.rasterize_forward(sc.W, sc.H, b, sc.background)
+            if cabi.validate_binning(b):
+                break
+        torch.cuda.synchronize()
+        assert list(ws.list_stats) == list(ref["binned"].list_stats)
+        assert np.array_equal(np_(b.gaussian_ids_sorted)[:b.num_isects],
+                              np_(ref["binned"].gaussian_ids_sorted)[:b.num_isects])
+        assert np.array_equal(np_(b.block_masks)[:b.num_isects], np_(ref["binned"].block_masks)[:b.num_isects])
+        assert np.array_equal(np_(f["img"]), np_(ref["img"]))
+
+
 def test_roctx_ranges_can_be_switched_on():
     """GSPLAT_ROCTX=1: the entry points of the path push / pop ROCTX ranges (SURVEY.md §5 tracing);
     libroctx64 is resolved in the process at first use.  The smoke step must run unchanged."""
