@@ -69,7 +69,18 @@ struct BinnedLists {
 // false if the capacity was too small — repeat both steps then (the capacity has grown).
 // (The reference's binAndSortGaussians, rasterize_gaussians.hpp:11-20, blocks on cumsum().item()
 // before it can allocate, and takes radius-square tile counts; its five-tuple contract — caller-side
-// cumulative counts, one global sort — is served at the launcher level, bindings_hip_native.h.)
+// cumulative counts, one global sort — is binAndSortGaussians below, on the launchers of
+// bindings_hip_native.h.)
+// The reference's own function, signature and five-tuple contract unchanged
+// (rasterize_gaussians.hpp:11-20, rasterize_gaussians.cpp:6-37): (isectIds int64 [M], gaussianIds int32
+// [M], isectIdsSorted, gaussianIdsSorted, tileBins int32 [rows, 2]) from caller-side cumulative
+// radius-square tile counts — map_gaussian_to_intersects, one global torch::sort, gather, bin edges.
+// For callers written against that contract; RasterizeGaussians::forward itself takes the route above.
+typedef std::tuple<int, int, int> TileBounds;   // (tile_bounds.hpp's own typedef, repeated)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+binAndSortGaussians(int numPoints, int numIntersects, torch::Tensor xys, torch::Tensor depths,
+                    torch::Tensor radii, torch::Tensor cumTilesHit, TileBounds tileBounds);
+
 BinnedLists binAndSortPacked(
     const torch::Tensor &xys, const torch::Tensor &depths, const torch::Tensor &radii,
     const torch::Tensor &conics, const torch::Tensor &colors, const torch::Tensor &opacity,

@@ -9,6 +9,7 @@
 // There is deliberately NO CPU fallback: every operator TORCH_CHECKs that its inputs live on the
 // GPU, and the package fails to import if libgsplat_hip.so is missing.
 #include "gsplat_ops.hpp"
+#include "bindings_hip_native.h"
 
 #include <ATen/hip/HIPEvent.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -247,6 +248,20 @@ BinnedLists binPackedRecords(const Tensor &packed, const Tensor &depths, int H, 
                  "gs_bin_sort");
     g_binCalls++;
     return b;
+}
+
+// rasterize_gaussians.cpp:6-37, statement for statement on this library's launchers
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor>
+binAndSortGaussians(int numPoints, int numIntersects, Tensor xys, Tensor depths, Tensor radii,
+                    Tensor cumTilesHit, TileBounds tileBounds) {
+    auto t = map_gaussian_to_intersects_tensor(numPoints, numIntersects, xys, depths, radii, cumTilesHit,
+                                               tileBounds);
+    Tensor isectIds = std::get<0>(t), gaussianIds = std::get<1>(t);
+    auto sorted = torch::sort(isectIds);
+    Tensor isectIdsSorted = std::get<0>(sorted), sortedIndices = std::get<1>(sorted);
+    Tensor gaussianIdsSorted = torch::gather(gaussianIds, 0, sortedIndices);
+    Tensor tileBins = get_tile_bin_edges_tensor(numIntersects, isectIdsSorted);
+    return std::make_tuple(isectIds, gaussianIds, isectIdsSorted, gaussianIdsSorted, tileBins);
 }
 
 BinnedLists binAndSortPacked(const Tensor &xys, const Tensor &depths, const Tensor &radii,
@@ -972,7 +987,17 @@ static int64_t op_binning_capacity(int64_t device, int64_t w, int64_t h) {
     return gsplatBinningCapacity((int)device, (int)w, (int)h);
 }
 
+static std::vector<Tensor> op_bin_and_sort_gaussians(int64_t numPoints, int64_t numIntersects, Tensor xys,
+                                                     Tensor depths, Tensor radii, Tensor cumTilesHit,
+                                                     int64_t tilesX, int64_t tilesY) {
+    auto t = binAndSortGaussians((int)numPoints, (int)numIntersects, xys, depths, radii, cumTilesHit,
+                                 std::make_tuple((int)tilesX, (int)tilesY, 1));
+    return {std::get<0>(t), std::get<1>(t), std::get<2>(t), std::get<3>(t), std::get<4>(t)};
+}
+
 TORCH_LIBRARY(opensplat_amd, m) {
+    m.def("bin_and_sort_gaussians(int num_points, int num_intersects, Tensor xys, Tensor depths, Tensor radii, "
+          "Tensor cum_tiles_hit, int tiles_x, int tiles_y) -> Tensor[]", &op_bin_and_sort_gaussians);
     m.def("binning_reset() -> ()", &op_binning_reset);
     m.def("binning_counters() -> int[]", &op_binning_counters);
     m.def("binning_capacity(int device, int img_width, int img_height) -> int", &op_binning_capacity);

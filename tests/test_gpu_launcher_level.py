@@ -30,6 +30,54 @@ def _glue_bin_and_sort(T, xys, depths, radii, num_tiles_hit, tiles_x, tiles_y):
     return M, ids_sorted, gids_sorted.contiguous(), bins
 
 
+def test_operator_level_bin_and_sort_gaussians_keeps_the_references_five_tuple():
+    """binAndSortGaussians with the reference's signature and contract (rasterize_gaussians.hpp:11-20):
+    (isectIds, gaussianIds, isectIdsSorted, gaussianIdsSorted, tileBins) from caller-side cumulative tile
+    counts — checked against numpy's evaluation of the same definition (tile << 32 | depth bits, stable
+    order of equal keys not required by the contract)."""
+    import torch
+
+    from opensplat_amd import ops  # noqa: F401  (loads libgsplat_torch.so)
+    from tests.util import hip_pipeline
+
+    T = torch.ops.opensplat_amd
+    s = scenes.camera_scene(5000, 320, 200, K=0, seed=81, znear=1.0, zfar=100.0)
+    p = hip_pipeline(s, backward=False)
+    W, H = s.W, s.H
+    tx, ty = (W + 15) // 16, (H + 15) // 16
+    xys, depths, radii = p["xys"], p["depths"], p["radii"]
+    # radius-square tile counts, as the reference's projection kernel reports them (helpers.cuh get_tile_bbox)
+    x, y, r = np_(xys)[:, 0], np_(xys)[:, 1], np_(radii).astype(np.float32)
+    x0 = np.clip(np.floor((x - r) / 16), 0, tx).astype(np.int64); x1 = np.clip(np.floor((x + r + 16) / 16), 0, tx).astype(np.int64)
+    y0 = np.clip(np.floor((y - r) / 16), 0, ty).astype(np.int64); y1 = np.clip(np.floor((y + r + 16) / 16), 0, ty).astype(np.int64)
+    hit = np.where(r > 0, (x1 - x0) * (y1 - y0), 0)
+    cum = torch.from_numpy(np.cumsum(hit).astype(np.int32)).cuda()
+    M = int(hit.sum())
+    ids, gids, ids_sorted, gids_sorted, bins = T.bin_and_sort_gaussians(len(x), M, xys, depths, radii, cum, tx, ty)
+    torch.cuda.synchronize()
+    assert ids.dtype == torch.int64 and gids.dtype == torch.int32 and bins.dtype == torch.int32
+    assert ids.shape == (M,) and gids.shape == (M,) and ids_sorted.shape == (M,) and gids_sorted.shape == (M,)
+    ids_n, gids_n, ids_s, gids_s, bins_n = (np_(t) for t in (ids, gids, ids_sorted, gids_sorted, bins))
+    # the unsorted pairs: every (tile, Gaussian) of the radius square once, key = tile << 32 | depth bits
+    dbits = np_(depths).view(np.int32).astype(np.int64)
+    want = []
+    for g in np.nonzero(hit)[0]:
+        for yy in range(y0[g], y1[g]):
+            for xx in range(x0[g], x1[g]):
+                want.append((((yy * tx + xx) << 32) | dbits[g], g))
+    want = np.array(sorted(want), dtype=np.int64)
+    got = np.stack([ids_n, gids_n.astype(np.int64)], -1)
+    assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want)
+    # sorted by key; the ids follow their keys; the bins delimit the tiles
+    assert np.all(np.diff(ids_s) >= 0) and np.array_equal(np.sort(ids_n), ids_s)
+    pair = {(int(k), int(g)) for k, g in zip(ids_n, gids_n)}
+    assert all((int(k), int(g)) in pair for k, g in zip(ids_s[::97], gids_s[::97]))
+    tiles = ids_s >> 32
+    for t in np.unique(tiles)[::7]:
+        lo, hi = bins_n[t]
+        assert np.all(tiles[lo:hi] == t) and (lo == 0 or tiles[lo - 1] < t) and (hi == M or tiles[hi] > t)
+
+
 @pytest.mark.parametrize("W,H,N", [(320, 200, 6000), (203, 117, 3000)])
 def test_reference_operator_glue_on_the_launcher_functions(W, H, N):
     import torch
