@@ -2,13 +2,15 @@
  *
  * Replaces, for a COLMAP capture, what Camera::loadImage (input_data.cpp:40-96) gets from OpenCV:
  *   imreadRGB (cv_utils.cpp:3-14: cv::imread + BGR->RGB)      -> gs_jpeg_info / gs_jpeg_decode_rgb
- * for baseline (sequential, Huffman, 8-bit) JPEG files — what cameras and COLMAP pipelines write.
+ * for 8-bit Huffman-coded JPEG files — baseline / extended sequential (one scan or one per component) and
+ * progressive (SOF2: spectral selection + successive approximation) — what cameras, phones and COLMAP
+ * pipelines write.
  * The decoder follows the algorithms of the IJG library that cv::imread delegates to (libjpeg /
  * libjpeg-turbo defaults: "islow" integer IDCT jidctint.c, "fancy" triangle chroma upsampling
  * jdsample.c, fixed-point YCbCr->RGB jdcolor.c), so that the pixels are the ones OpenSplat trains on:
  * bit-exact against libjpeg's own output on every fixture (tests/test_image.py, pinned through
  * Pillow, which wraps the same library).
- * Not supported (GS_ERR_UNSUPPORTED): progressive / arithmetic-coded / 12-bit / CMYK files.
+ * Not supported (GS_ERR_UNSUPPORTED): arithmetic-coded / lossless / 12-bit / CMYK files.
  * EXIF orientation is NOT applied (cv::imread applies it; COLMAP's own reader does not).
  *
  * Plain host C (libgsplat_image.so, gcc): no HIP, no torch.  Status codes as in gsplat_hip.h.

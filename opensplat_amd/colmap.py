@@ -421,8 +421,8 @@ def apply_exif_orientation(img: np.ndarray, orientation: int) -> np.ndarray:
 
 
 def _decode_jpeg_any(blob: bytes) -> np.ndarray:
-    """Baseline JPEGs go through the in-tree decoder (bit-exact against libjpeg).  Progressive,
-    arithmetic-coded, 12-bit or CMYK files — which it refuses — are handed to Pillow when that is
+    """Sequential and progressive Huffman JPEGs go through the in-tree decoder (bit-exact against libjpeg).
+    Arithmetic-coded, lossless, 12-bit or CMYK files — which it refuses — are handed to Pillow when that is
     installed (it wraps the same libjpeg cv::imread uses); without it the error says what to do."""
     try:
         return decode_jpeg(blob)

@@ -1,4 +1,5 @@
-/* gs_image.c — baseline JPEG decoder of libgsplat_image.so (include/gsplat_image.h).
+/* gs_image.c — JPEG decoder (baseline, extended sequential and progressive Huffman) of
+ * libgsplat_image.so (include/gsplat_image.h).
  *
  * Written from the JPEG standard (ITU T.81) and the documented behaviour of the IJG library's
  * default decoding path, which is what cv::imread runs for OpenSplat's training images
@@ -8,6 +9,11 @@
  * steps determine the pixel values bit for bit; tests/test_image.py pins the result against libjpeg
  * itself (through Pillow) on 4:4:4 / 4:2:2 / 4:2:0 / greyscale files of ragged sizes, several
  * qualities, optimised Huffman tables and restart markers.
+ *
+ * A single-scan sequential file (what cameras write) is decoded MCU by MCU straight into the sample
+ * planes.  Progressive files (SOF2: spectral selection and successive approximation, T.81 annex G) and
+ * sequential files with several scans collect their coefficients for the whole image first, scan by
+ * scan, and are transformed at the end — libjpeg's final output for a complete file.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +57,10 @@ typedef struct {
     int restart_interval;
     int adobe_transform;       /* -1 = no Adobe marker */
     int progressive;
+    int have_sof;
+    /* the scan header last parsed (SOS) */
+    int ns, scomp[MAX_COMPS];  /* components of the scan: indices into c[] */
+    int ss, se, ah, al;
 } Jpeg;
 
 static const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
@@ -62,7 +72,7 @@ const char *gs_image_strerror(int status) {
     switch (status) {
     case GS_IMG_OK: return "ok";
     case GS_IMG_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case GS_IMG_ERR_UNSUPPORTED: return "unsupported JPEG variant (progressive, arithmetic, 12-bit, CMYK)";
+    case GS_IMG_ERR_UNSUPPORTED: return "unsupported JPEG variant (arithmetic-coded, lossless, 12-bit, CMYK)";
     case GS_IMG_ERR_CORRUPT: return "corrupt or truncated JPEG stream";
     default: return "unknown status";
     }
@@ -250,28 +260,36 @@ static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int
 /* ---- header parsing ------------------------------------------------------------------------------- */
 static int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
-/* Parses markers up to and including SOS; *scan points at the entropy-coded data. */
-static int parse_headers(Jpeg *j, const uint8_t *data, size_t size, const uint8_t **scan) {
+/* Parses markers from *pp up to and including the next SOS: tables are updated, the scan header is
+ * stored in j, *pp is left at the entropy-coded data.  Returns GS_IMG_OK (a scan follows), 1 (EOI or the
+ * end of the data: no further scan) or an error.  Call with a zeroed-and-initialised j the first time
+ * (jpeg_begin). */
+static int jpeg_begin(Jpeg *j, const uint8_t *data, size_t size, const uint8_t **pp) {
     memset(j, 0, sizeof(*j));
     j->adobe_transform = -1;
     if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) return GS_IMG_ERR_CORRUPT;
-    const uint8_t *p = data + 2, *end = data + size;
-    int have_sof = 0;
+    *pp = data + 2;
+    return GS_IMG_OK;
+}
+static int next_scan(Jpeg *j, const uint8_t **pp, const uint8_t *end) {
+    const uint8_t *p = *pp;
     for (;;) {
         while (p < end && *p != 0xFF) p++;                 /* resynchronise */
         while (p < end && *p == 0xFF) p++;                 /* fill bytes */
-        if (p >= end) return GS_IMG_ERR_CORRUPT;
+        if (p >= end) return j->have_sof ? 1 : GS_IMG_ERR_CORRUPT;
         const int m = *p++;
-        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
-        if (m == 0xD9) return GS_IMG_ERR_CORRUPT;          /* EOI before a scan */
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01 || m == 0x00) continue;
+        if (m == 0xD9) return 1;                           /* EOI */
         if (p + 2 > end) return GS_IMG_ERR_CORRUPT;
         const int len = rd16(p);
         if (len < 2 || p + len > end) return GS_IMG_ERR_CORRUPT;
         const uint8_t *s = p + 2, *se = p + len;
         switch (m) {
-        case 0xC0: case 0xC1: {                            /* baseline / extended sequential, Huffman */
+        case 0xC0: case 0xC1: case 0xC2: {                 /* baseline / extended sequential / progressive, Huffman */
+            if (j->have_sof) return GS_IMG_ERR_CORRUPT;
             if (se - s < 6) return GS_IMG_ERR_CORRUPT;
             if (s[0] != 8) return GS_IMG_ERR_UNSUPPORTED;
+            j->progressive = m == 0xC2;
             j->H = rd16(s + 1);
             j->W = rd16(s + 3);
             j->ncomp = s[5];
@@ -288,12 +306,12 @@ static int parse_headers(Jpeg *j, const uint8_t *data, size_t size, const uint8_
                 if (c->h > j->hmax) j->hmax = c->h;
                 if (c->v > j->vmax) j->vmax = c->v;
             }
-            have_sof = 1;
+            j->have_sof = 1;
             break;
         }
-        case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB:
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB:
         case 0xCD: case 0xCE: case 0xCF:
-            return GS_IMG_ERR_UNSUPPORTED;                 /* progressive, lossless, arithmetic, ... */
+            return GS_IMG_ERR_UNSUPPORTED;                 /* lossless, hierarchical, arithmetic */
         case 0xC4:                                         /* DHT */
             while (s < se) {
                 if (se - s < 17) return GS_IMG_ERR_CORRUPT;
@@ -329,22 +347,28 @@ static int parse_headers(Jpeg *j, const uint8_t *data, size_t size, const uint8_
             if (se - s >= 12 && memcmp(s, "Adobe", 5) == 0) j->adobe_transform = s[11];
             break;
         case 0xDA: {                                       /* SOS */
-            if (!have_sof) return GS_IMG_ERR_CORRUPT;
-            if (se - s < 1 || s[0] != j->ncomp || se - s < 1 + 2 * j->ncomp + 3)
-                return GS_IMG_ERR_UNSUPPORTED;             /* (multi-scan sequential files) */
-            for (int i = 0; i < j->ncomp; i++) {
+            if (!j->have_sof) return GS_IMG_ERR_CORRUPT;
+            if (se - s < 1) return GS_IMG_ERR_CORRUPT;
+            j->ns = s[0];
+            if (j->ns < 1 || j->ns > j->ncomp || se - s < 1 + 2 * j->ns + 3) return GS_IMG_ERR_CORRUPT;
+            for (int i = 0; i < j->ns; i++) {
                 const int cid = s[1 + 2 * i], t = s[2 + 2 * i];
-                Comp *c = NULL;
+                int idx = -1;
                 for (int k = 0; k < j->ncomp; k++)
-                    if (j->c[k].id == cid) c = &j->c[k];
-                if (!c || c != &j->c[i]) return GS_IMG_ERR_UNSUPPORTED;
-                c->td = t >> 4;
-                c->ta = t & 15;
-                if (c->td > 3 || c->ta > 3 || !j->dc[c->td].present || !j->ac[c->ta].present ||
-                    !j->qt_present[c->tq])
-                    return GS_IMG_ERR_CORRUPT;
+                    if (j->c[k].id == cid) idx = k;
+                /* (components of a scan follow the frame's order, T.81 B.2.3) */
+                if (idx < 0 || (i > 0 && idx <= j->scomp[i - 1])) return GS_IMG_ERR_CORRUPT;
+                j->scomp[i] = idx;
+                j->c[idx].td = t >> 4;
+                j->c[idx].ta = t & 15;
+                if (j->c[idx].td > 3 || j->c[idx].ta > 3) return GS_IMG_ERR_CORRUPT;
             }
-            *scan = se;
+            const uint8_t *q = s + 1 + 2 * j->ns;
+            j->ss = q[0];
+            j->se = q[1];
+            j->ah = q[2] >> 4;
+            j->al = q[2] & 15;
+            *pp = se;
             return GS_IMG_OK;
         }
         default: break;                                    /* APPn, COM, ...: skipped */
@@ -357,8 +381,10 @@ int gs_jpeg_info(const uint8_t *data, size_t size, int *width, int *height, int 
     if (!data) return GS_IMG_ERR_INVALID_ARGUMENT;
     Jpeg j;
     const uint8_t *scan;
-    const int rc = parse_headers(&j, data, size, &scan);
-    if (rc) return rc;
+    int rc = jpeg_begin(&j, data, size, &scan);
+    if (rc == GS_IMG_OK) rc = next_scan(&j, &scan, data + size);
+    if (rc < 0) return rc;
+    if (rc == 1) return GS_IMG_ERR_CORRUPT;                /* no scan at all */
     if (width) *width = j.W;
     if (height) *height = j.H;
     if (components) *components = j.ncomp;
@@ -472,15 +498,228 @@ static int decode_block(Bits *b, const Huff *dc, const Huff *ac, int *pred, int1
     return GS_IMG_OK;
 }
 
+/* restart interval boundary: byte-align, expect RSTn */
+static int take_restart(Bits *b, int *next_rst) {
+    b->bitbuf = 0;
+    b->bitcnt = 0;
+    if (b->hit_marker) {
+        if (b->hit_marker != 0xD0 + *next_rst) return GS_IMG_ERR_CORRUPT;
+        b->p += 2;
+        b->hit_marker = 0;
+    } else {
+        while (b->p + 1 < b->end && !(b->p[0] == 0xFF && b->p[1] >= 0xD0 && b->p[1] <= 0xD7)) b->p++;
+        if (b->p + 1 >= b->end || b->p[1] != 0xD0 + *next_rst) return GS_IMG_ERR_CORRUPT;
+        b->p += 2;
+    }
+    *next_rst = (*next_rst + 1) & 7;
+    return GS_IMG_OK;
+}
+
+/* ---- progressive scans (T.81 annex G; the four procedures of the IJG library's jdphuff.c) ---------- */
+typedef struct {
+    int eobrun;                /* blocks still covered by the current end-of-band run */
+} ProgState;
+
+static int prog_dc_first(Bits *b, const Huff *dc, int *pred, int16_t *coef, int al) {
+    const int t = decode_symbol(b, dc);
+    if (t < 0 || t > 11) return GS_IMG_ERR_CORRUPT;
+    *pred += t ? extend(get_bits(b, t), t) : 0;
+    coef[0] = (int16_t)(*pred * (1 << al));
+    return GS_IMG_OK;
+}
+static int prog_dc_refine(Bits *b, int16_t *coef, int al) {
+    if (get_bits(b, 1)) coef[0] = (int16_t)(coef[0] | (1 << al));
+    return GS_IMG_OK;
+}
+static int prog_ac_first(Bits *b, const Huff *ac, ProgState *st, int16_t *coef, int ss, int se, int al) {
+    if (st->eobrun > 0) {
+        st->eobrun--;
+        return GS_IMG_OK;
+    }
+    for (int k = ss; k <= se; k++) {
+        const int rs = decode_symbol(b, ac);
+        if (rs < 0) return GS_IMG_ERR_CORRUPT;
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > 63) return GS_IMG_ERR_CORRUPT;
+            coef[kZigzag[k]] = (int16_t)(extend(get_bits(b, s), s) * (1 << al));
+        } else if (r == 15) {
+            k += 15;                                       /* ZRL */
+        } else {
+            st->eobrun = 1 << r;                           /* EOBr: this block and eobrun - 1 more */
+            if (r) st->eobrun += get_bits(b, r);
+            st->eobrun--;
+            break;
+        }
+    }
+    return GS_IMG_OK;
+}
+static int prog_ac_refine(Bits *b, const Huff *ac, ProgState *st, int16_t *coef, int ss, int se, int al) {
+    const int p1 = 1 << al, m1 = -(1 << al);
+    int k = ss;
+    if (st->eobrun == 0) {
+        for (; k <= se; k++) {
+            const int rs = decode_symbol(b, ac);
+            if (rs < 0) return GS_IMG_ERR_CORRUPT;
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                if (s != 1) return GS_IMG_ERR_CORRUPT;     /* a newly non-zero coefficient is +-1 */
+                s = get_bits(b, 1) ? p1 : m1;
+            } else if (r != 15) {
+                st->eobrun = 1 << r;                       /* EOBr: the band ends here */
+                if (r) st->eobrun += get_bits(b, r);
+                break;
+            }
+            /* pass over r still-zero coefficients, correcting every already non-zero one on the way */
+            do {
+                int16_t *c = &coef[kZigzag[k]];
+                if (*c != 0) {
+                    if (get_bits(b, 1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                } else if (--r < 0) {
+                    break;
+                }
+                k++;
+            } while (k <= se);
+            if (s) {
+                if (k > 63) return GS_IMG_ERR_CORRUPT;
+                coef[kZigzag[k]] = (int16_t)s;
+            }
+        }
+    }
+    if (st->eobrun > 0) {
+        /* inside an end-of-band run: only correction bits for the non-zero coefficients that remain */
+        for (; k <= se; k++) {
+            int16_t *c = &coef[kZigzag[k]];
+            if (*c != 0 && get_bits(b, 1) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+        }
+        st->eobrun--;
+    }
+    return GS_IMG_OK;
+}
+
+/* One scan of a multi-scan file into the coefficient arrays (coefs[i]: blocks_w * blocks_h * 64, natural
+ * order).  Leaves *pp at the marker that ends the entropy-coded segment. */
+static int decode_scan_to_coefs(Jpeg *j, int16_t **coefs, const uint8_t **pp, const uint8_t *end) {
+    const int prog = j->progressive;
+    const int ss = prog ? j->ss : 0, se = prog ? j->se : 63, ah = prog ? j->ah : 0, al = prog ? j->al : 0;
+    if (prog) {
+        /* G.1.1.1.1: DC scans carry no AC band; an AC scan has one component */
+        if (ss > se || se > 63 || al > 13 || ah > 13) return GS_IMG_ERR_CORRUPT;
+        if (ss == 0 && se != 0) return GS_IMG_ERR_CORRUPT;
+        if (ss > 0 && j->ns != 1) return GS_IMG_ERR_CORRUPT;
+    }
+    for (int i = 0; i < j->ns; i++) {
+        const Comp *c = &j->c[j->scomp[i]];
+        const int need_dc = ss == 0 && ah == 0, need_ac = se > 0;
+        if ((need_dc && !j->dc[c->td].present) || (need_ac && !j->ac[c->ta].present)) return GS_IMG_ERR_CORRUPT;
+    }
+    Bits b;
+    memset(&b, 0, sizeof(b));
+    b.p = *pp;
+    b.end = end;
+    ProgState st = {0};
+    int restart_left = j->restart_interval, next_rst = 0, rc = GS_IMG_OK;
+    for (int i = 0; i < j->ncomp; i++) j->c[i].pred = 0;
+    const int mcu_w = 8 * j->hmax, mcu_h = 8 * j->vmax;
+    const int interleaved = j->ns > 1;
+    const Comp *c0 = &j->c[j->scomp[0]];
+    /* a one-component scan walks that component's own blocks (T.81 A.2.2), an interleaved one the MCUs */
+    const int total_x = interleaved ? (j->W + mcu_w - 1) / mcu_w : (c0->ds_w + 7) / 8;
+    const int total_y = interleaved ? (j->H + mcu_h - 1) / mcu_h : (c0->ds_h + 7) / 8;
+    for (int my = 0; my < total_y && rc == GS_IMG_OK; my++)
+        for (int mx = 0; mx < total_x && rc == GS_IMG_OK; mx++) {
+            if (j->restart_interval && restart_left == 0) {
+                rc = take_restart(&b, &next_rst);
+                if (rc) break;
+                restart_left = j->restart_interval;
+                for (int i = 0; i < j->ncomp; i++) j->c[i].pred = 0;
+                st.eobrun = 0;
+            }
+            for (int i = 0; i < j->ns && rc == GS_IMG_OK; i++) {
+                Comp *c = &j->c[j->scomp[i]];
+                const int h = interleaved ? c->h : 1, v = interleaved ? c->v : 1;
+                for (int by = 0; by < v && rc == GS_IMG_OK; by++)
+                    for (int bx = 0; bx < h && rc == GS_IMG_OK; bx++) {
+                        const size_t blk = (size_t)(my * v + by) * c->blocks_w + (size_t)(mx * h + bx);
+                        int16_t *coef = coefs[j->scomp[i]] + blk * 64;
+                        if (!prog) rc = decode_block(&b, &j->dc[c->td], &j->ac[c->ta], &c->pred, coef);
+                        else if (ss == 0) rc = ah == 0 ? prog_dc_first(&b, &j->dc[c->td], &c->pred, coef, al)
+                                                       : prog_dc_refine(&b, coef, al);
+                        else rc = ah == 0 ? prog_ac_first(&b, &j->ac[c->ta], &st, coef, ss, se, al)
+                                          : prog_ac_refine(&b, &j->ac[c->ta], &st, coef, ss, se, al);
+                    }
+            }
+            restart_left--;
+        }
+    if (rc) return rc;
+    /* the marker behind the entropy-coded data (the bit reader never reads past one) */
+    const uint8_t *p = b.p;
+    if (!b.hit_marker)
+        while (p + 1 < end && !(p[0] == 0xFF && p[1] != 0x00 && !(p[1] >= 0xD0 && p[1] <= 0xD7))) p++;
+    *pp = p;
+    return GS_IMG_OK;
+}
+
+/* sample planes -> interleaved RGB: fancy upsampling + fixed-point YCbCr -> RGB */
+static int planes_to_rgb(const Jpeg *j, uint8_t *out) {
+    /* colour conversion tables (16-bit fixed point), per call and on the stack: 4 KiB and 256
+     * iterations are nothing next to a decode, and a decoder called from several loader threads
+     * (ctypes releases the GIL) must not share lazily initialised statics */
+    int crr[256], cbb[256];
+    long crg[256], cbg[256];
+    for (int i = 0; i < 256; i++) {
+        const long x = i - 128;
+        crr[i] = (int)((91881L * x + 32768L) >> 16);      /* FIX(1.40200) */
+        cbb[i] = (int)((116130L * x + 32768L) >> 16);     /* FIX(1.77200) */
+        crg[i] = -46802L * x;                             /* FIX(0.71414) */
+        cbg[i] = -22554L * x + 32768L;                    /* FIX(0.34414), + ONE_HALF */
+    }
+    const int mcus_x = (j->W + 8 * j->hmax - 1) / (8 * j->hmax);
+    const size_t roww = (size_t)(mcus_x * 8 * j->hmax + 16);
+    uint8_t *rows = (uint8_t *)malloc(roww * 4);
+    if (!rows) return GS_IMG_ERR_INVALID_ARGUMENT;
+    const int ycc = j->ncomp == 3 && j->adobe_transform != 0;   /* Adobe transform 0: stored as RGB */
+    for (int y = 0; y < j->H; y++) {
+        uint8_t *o = out + (size_t)y * j->W * 3;
+        if (j->ncomp == 1) {
+            const uint8_t *g = j->c[0].plane + (size_t)y * j->c[0].blocks_w * 8;
+            for (int x = 0; x < j->W; x++) o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = g[x];
+            continue;
+        }
+        uint8_t *r0 = rows, *r1 = rows + roww, *r2 = rows + 2 * roww;
+        upsample_row(j, &j->c[0], y, r0, rows + 3 * roww);
+        upsample_row(j, &j->c[1], y, r1, rows + 3 * roww);
+        upsample_row(j, &j->c[2], y, r2, rows + 3 * roww);
+        if (!ycc) {
+            for (int x = 0; x < j->W; x++) { o[3 * x] = r0[x]; o[3 * x + 1] = r1[x]; o[3 * x + 2] = r2[x]; }
+            continue;
+        }
+        for (int x = 0; x < j->W; x++) {
+            const int Y = r0[x], cb = r1[x], cr = r2[x];
+            int R = Y + crr[cr], G = Y + (int)((cbg[cb] + crg[cr]) >> 16), B = Y + cbb[cb];
+            o[3 * x] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
+            o[3 * x + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
+            o[3 * x + 2] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
+        }
+    }
+    free(rows);
+    return GS_IMG_OK;
+}
+
 int gs_jpeg_decode_rgb(const uint8_t *data, size_t size, uint8_t *out, size_t out_bytes) {
     if (!data || !out) return GS_IMG_ERR_INVALID_ARGUMENT;
     Jpeg j;
-    const uint8_t *scan;
-    int rc = parse_headers(&j, data, size, &scan);
-    if (rc) return rc;
+    const uint8_t *scan, *end = data + size;
+    int rc = jpeg_begin(&j, data, size, &scan);
+    if (rc == GS_IMG_OK) rc = next_scan(&j, &scan, end);
+    if (rc < 0) return rc;
+    if (rc == 1) return GS_IMG_ERR_CORRUPT;                /* no scan */
     if (out_bytes < (size_t)j.W * j.H * 3) return GS_IMG_ERR_INVALID_ARGUMENT;
-    for (int i = 0; i < j.ncomp; i++)
+    for (int i = 0; i < j.ncomp; i++) {
         if (j.hmax % j.c[i].h || j.vmax % j.c[i].v) return GS_IMG_ERR_UNSUPPORTED;  /* fractional ratios */
+        if (!j.qt_present[j.c[i].tq] && !j.progressive) return GS_IMG_ERR_CORRUPT;
+    }
     const int mcu_w = 8 * j.hmax, mcu_h = 8 * j.vmax;
     const int mcus_x = (j.W + mcu_w - 1) / mcu_w, mcus_y = (j.H + mcu_h - 1) / mcu_h;
     for (int i = 0; i < j.ncomp; i++) {
@@ -503,91 +742,72 @@ int gs_jpeg_decode_rgb(const uint8_t *data, size_t size, uint8_t *out, size_t ou
         }
         c->pred = 0;
     }
-    Bits b;
-    memset(&b, 0, sizeof(b));
-    b.p = scan;
-    b.end = data + size;
-    int16_t coef[64];
-    const int single = j.ncomp == 1;
-    const int total_x = single ? j.c[0].blocks_w : mcus_x, total_y = single ? j.c[0].blocks_h : mcus_y;
-    int restart_left = j.restart_interval, next_rst = 0;
     rc = GS_IMG_OK;
-    for (int my = 0; my < total_y && rc == GS_IMG_OK; my++) {
-        for (int mx = 0; mx < total_x && rc == GS_IMG_OK; mx++) {
-            if (j.restart_interval && restart_left == 0) {
-                /* byte-align, expect RSTn, reset the predictors */
-                b.bitbuf = 0;
-                b.bitcnt = 0;
-                if (b.hit_marker) {
-                    if (b.hit_marker != 0xD0 + next_rst) { rc = GS_IMG_ERR_CORRUPT; break; }
-                    b.p += 2;
-                    b.hit_marker = 0;
-                } else {
-                    while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) b.p++;
-                    if (b.p + 1 >= b.end || b.p[1] != 0xD0 + next_rst) { rc = GS_IMG_ERR_CORRUPT; break; }
-                    b.p += 2;
+    if (!j.progressive && j.ns == j.ncomp) {
+        /* ---- one sequential scan with every component: MCU by MCU straight into the planes ---- */
+        for (int i = 0; i < j.ncomp; i++) {
+            const Comp *c = &j.c[i];
+            if (!j.dc[c->td].present || !j.ac[c->ta].present) rc = GS_IMG_ERR_CORRUPT;
+        }
+        Bits b;
+        memset(&b, 0, sizeof(b));
+        b.p = scan;
+        b.end = end;
+        int16_t coef[64];
+        const int single = j.ncomp == 1;
+        const int total_x = single ? j.c[0].blocks_w : mcus_x, total_y = single ? j.c[0].blocks_h : mcus_y;
+        int restart_left = j.restart_interval, next_rst = 0;
+        for (int my = 0; my < total_y && rc == GS_IMG_OK; my++) {
+            for (int mx = 0; mx < total_x && rc == GS_IMG_OK; mx++) {
+                if (j.restart_interval && restart_left == 0) {
+                    rc = take_restart(&b, &next_rst);
+                    if (rc) break;
+                    restart_left = j.restart_interval;
+                    for (int i = 0; i < j.ncomp; i++) j.c[i].pred = 0;
                 }
-                next_rst = (next_rst + 1) & 7;
-                restart_left = j.restart_interval;
-                for (int i = 0; i < j.ncomp; i++) j.c[i].pred = 0;
+                for (int i = 0; i < j.ncomp && rc == GS_IMG_OK; i++) {
+                    Comp *c = &j.c[i];
+                    const int h = single ? 1 : c->h, v = single ? 1 : c->v;
+                    const int stride = c->blocks_w * 8;
+                    for (int by = 0; by < v && rc == GS_IMG_OK; by++)
+                        for (int bx = 0; bx < h; bx++) {
+                            rc = decode_block(&b, &j.dc[c->td], &j.ac[c->ta], &c->pred, coef);
+                            if (rc) break;
+                            uint8_t *o = c->plane + ((size_t)(my * v + by) * 8) * stride + (size_t)(mx * h + bx) * 8;
+                            idct_islow(coef, j.qt[c->tq], o, stride);
+                        }
+                }
+                restart_left--;
             }
-            for (int i = 0; i < j.ncomp && rc == GS_IMG_OK; i++) {
-                Comp *c = &j.c[i];
-                const int h = single ? 1 : c->h, v = single ? 1 : c->v;
-                const int stride = c->blocks_w * 8;
-                for (int by = 0; by < v && rc == GS_IMG_OK; by++)
-                    for (int bx = 0; bx < h; bx++) {
-                        rc = decode_block(&b, &j.dc[c->td], &j.ac[c->ta], &c->pred, coef);
-                        if (rc) break;
-                        uint8_t *o = c->plane + ((size_t)(my * v + by) * 8) * stride + (size_t)(mx * h + bx) * 8;
-                        idct_islow(coef, j.qt[c->tq], o, stride);
-                    }
-            }
-            restart_left--;
         }
+    } else {
+        /* ---- several scans (progressive, or a sequential file with one scan per component): all
+         *      coefficients first, the transform at the end ---- */
+        int16_t *coefs[MAX_COMPS] = {NULL, NULL, NULL};
+        for (int i = 0; i < j.ncomp && rc == GS_IMG_OK; i++) {
+            coefs[i] = (int16_t *)calloc((size_t)j.c[i].blocks_w * j.c[i].blocks_h * 64, sizeof(int16_t));
+            if (!coefs[i]) rc = GS_IMG_ERR_INVALID_ARGUMENT;
+        }
+        int more = 1;
+        while (rc == GS_IMG_OK && more) {
+            rc = decode_scan_to_coefs(&j, coefs, &scan, end);
+            if (rc) break;
+            const int nx = next_scan(&j, &scan, end);
+            if (nx < 0) rc = nx;
+            else more = nx == GS_IMG_OK;
+        }
+        for (int i = 0; i < j.ncomp && rc == GS_IMG_OK; i++) {
+            const Comp *c = &j.c[i];
+            if (!j.qt_present[c->tq]) { rc = GS_IMG_ERR_CORRUPT; break; }   /* (tables may follow the frame header) */
+            const int stride = c->blocks_w * 8;
+            for (int by = 0; by < c->blocks_h; by++)
+                for (int bx = 0; bx < c->blocks_w; bx++)
+                    idct_islow(coefs[i] + ((size_t)by * c->blocks_w + bx) * 64, j.qt[c->tq],
+                               c->plane + ((size_t)by * 8) * stride + (size_t)bx * 8, stride);
+        }
+        for (int i = 0; i < MAX_COMPS; i++) free(coefs[i]);
     }
-    if (rc == GS_IMG_OK) {
-        /* colour conversion tables (16-bit fixed point), per call and on the stack: 4 KiB and 256
-         * iterations are nothing next to a decode, and a decoder called from several loader threads
-         * (ctypes releases the GIL) must not share lazily initialised statics */
-        int crr[256], cbb[256];
-        long crg[256], cbg[256];
-        for (int i = 0; i < 256; i++) {
-            const long x = i - 128;
-            crr[i] = (int)((91881L * x + 32768L) >> 16);      /* FIX(1.40200) */
-            cbb[i] = (int)((116130L * x + 32768L) >> 16);     /* FIX(1.77200) */
-            crg[i] = -46802L * x;                             /* FIX(0.71414) */
-            cbg[i] = -22554L * x + 32768L;                    /* FIX(0.34414), + ONE_HALF */
-        }
-        const size_t roww = (size_t)(mcus_x * mcu_w + 16);
-        uint8_t *rows = (uint8_t *)malloc(roww * 4);
-        if (!rows) rc = GS_IMG_ERR_INVALID_ARGUMENT;
-        const int ycc = j.ncomp == 3 && j.adobe_transform != 0;   /* Adobe transform 0: stored as RGB */
-        for (int y = 0; y < j.H && rc == GS_IMG_OK; y++) {
-            uint8_t *o = out + (size_t)y * j.W * 3;
-            if (j.ncomp == 1) {
-                const uint8_t *g = j.c[0].plane + (size_t)y * j.c[0].blocks_w * 8;
-                for (int x = 0; x < j.W; x++) o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = g[x];
-                continue;
-            }
-            uint8_t *r0 = rows, *r1 = rows + roww, *r2 = rows + 2 * roww;
-            upsample_row(&j, &j.c[0], y, r0, rows + 3 * roww);
-            upsample_row(&j, &j.c[1], y, r1, rows + 3 * roww);
-            upsample_row(&j, &j.c[2], y, r2, rows + 3 * roww);
-            if (!ycc) {
-                for (int x = 0; x < j.W; x++) { o[3 * x] = r0[x]; o[3 * x + 1] = r1[x]; o[3 * x + 2] = r2[x]; }
-                continue;
-            }
-            for (int x = 0; x < j.W; x++) {
-                const int Y = r0[x], cb = r1[x], cr = r2[x];
-                int R = Y + crr[cr], G = Y + (int)((cbg[cb] + crg[cr]) >> 16), B = Y + cbb[cb];
-                o[3 * x] = (uint8_t)(R < 0 ? 0 : (R > 255 ? 255 : R));
-                o[3 * x + 1] = (uint8_t)(G < 0 ? 0 : (G > 255 ? 255 : G));
-                o[3 * x + 2] = (uint8_t)(B < 0 ? 0 : (B > 255 ? 255 : B));
-            }
-        }
-        free(rows);
-    }
+    if (rc == GS_IMG_OK) rc = planes_to_rgb(&j, out);
     for (int i = 0; i < j.ncomp; i++) free(j.c[i].plane);
     return rc;
 }

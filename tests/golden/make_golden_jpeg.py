@@ -42,6 +42,17 @@ CASES = [  # name, W, H, save options
 ]
 
 
+PROGRESSIVE = [  # SOF2: DC first / refinement, AC bands first / refinement (libjpeg's default script)
+    ("prog_q85_420", 83, 61, dict(quality=85, subsampling=2)),
+    ("prog_q92_422_opt", 83, 61, dict(quality=92, subsampling=1, optimize=True)),
+    ("prog_q97_444", 50, 33, dict(quality=97, subsampling=0)),
+    ("prog_q25_420", 64, 40, dict(quality=25, subsampling=2)),
+    ("prog_q85_420_rst", 83, 61, dict(quality=85, subsampling=2, restart_marker_blocks=3)),
+    ("prog_tiny_3x2", 3, 2, dict(quality=90, subsampling=2)),
+    ("prog_q80_grey", 45, 37, dict(quality=80)),
+]
+
+
 def main():
     out = {}
     for i, (name, W, H, opts) in enumerate(CASES):
@@ -53,11 +64,18 @@ def main():
         blob = b.getvalue()
         out[name + "_file"] = np.frombuffer(blob, np.uint8)
         out[name + "_rgb"] = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"))
-    b = io.BytesIO()
-    Image.fromarray(picture(32, 24, 99)).save(b, "JPEG", quality=85, progressive=True)
-    out["progressive_file"] = np.frombuffer(b.getvalue(), np.uint8)
+    for i, (name, W, H, opts) in enumerate(PROGRESSIVE):
+        img = picture(W, H, 50 + i)
+        if name.endswith("grey"):
+            img = img[..., 0]
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", progressive=True, **opts)
+        blob = b.getvalue()
+        assert b"\xff\xc2" in blob
+        out[name + "_file"] = np.frombuffer(blob, np.uint8)
+        out[name + "_rgb"] = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"))
     np.savez_compressed(os.path.join(HERE, "jpeg_fixtures.npz"), **out)
-    print("wrote %d fixtures" % len(CASES))
+    print("wrote %d fixtures" % (len(CASES) + len(PROGRESSIVE)))
 
 
 if __name__ == "__main__":

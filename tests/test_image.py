@@ -8,7 +8,7 @@
   undistort.dispatch.cpp, imgwarp.cpp) in plain C and opensplat_amd/colmap.py must agree with it bit for
   bit on random and on lens-distorted synthetic captures; not pinned to an OpenCV build (none offline).
   Exact arithmetic and an analytically distorted picture check the meaning of the results;
-* EXIF orientation (cv::imread applies it) and the hand-over of non-baseline JPEGs to Pillow."""
+* EXIF orientation (cv::imread applies it) and the hand-over of what the decoder refuses (CMYK, ...) to Pillow."""
 import io
 import os
 
@@ -22,17 +22,109 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_
 
 def test_jpeg_fixtures_decode_to_libjpegs_pixels():
     g = np.load(GOLD)
-    names = sorted(k[:-5] for k in g.files if k.endswith("_file") and k != "progressive_file")
+    names = sorted(k[:-5] for k in g.files if k.endswith("_file") and not k.startswith("prog"))
     assert len(names) >= 10
     for n in names:
         got = colmap.decode_jpeg(g[n + "_file"].tobytes())
         assert got.shape == g[n + "_rgb"].shape and np.array_equal(got, g[n + "_rgb"]), n
 
 
+def test_progressive_jpeg_fixtures_decode_to_libjpegs_pixels():
+    """SOF2 files (spectral selection + successive approximation, T.81 annex G): 4:2:0 / 4:2:2 / 4:4:4,
+    greyscale, optimised tables, restart markers — libjpeg's final pixels, bit for bit."""
+    g = np.load(GOLD)
+    names = sorted(k[:-5] for k in g.files if k.startswith("prog_") and k.endswith("_file"))
+    assert len(names) >= 6
+    for n in names:
+        got = colmap.decode_jpeg(g[n + "_file"].tobytes())
+        assert got.shape == g[n + "_rgb"].shape and np.array_equal(got, g[n + "_rgb"]), n
+
+
+def _split_scans_444(blob):
+    """A baseline 4:4:4 file re-written as a sequential file with ONE SCAN PER COMPONENT (T.81 allows
+    it; some encoders write it): with 1x1 sampling every component's blocks come in the same raster order
+    in both layouts, so each block's bits are copied as they are."""
+    def segs(b):
+        i, out = 2, []
+        while b[i + 1] != 0xDA:
+            n = (b[i + 2] << 8) | b[i + 3]
+            out.append(b[i:i + 2 + n]); i += 2 + n
+        n = (b[i + 2] << 8) | b[i + 3]
+        return out, b[i:i + 2 + n], b[i + 2 + n:]
+    hdrs, sos, data = segs(blob)
+    huff = {}
+    for h in hdrs:
+        if h[1] == 0xC4:
+            q = 4
+            while q < len(h):
+                tc_th, bits = h[q], list(h[q + 1:q + 17]); vals = h[q + 17:q + 17 + sum(bits)]
+                code, k, table = 0, 0, {}
+                for ln in range(1, 17):
+                    for _ in range(bits[ln - 1]):
+                        table[(ln, code)] = vals[k]; code += 1; k += 1
+                    code <<= 1
+                huff[tc_th] = table; q += 17 + sum(bits)
+        if h[1] == 0xC0:
+            H, W, nc = (h[5] << 8) | h[6], (h[7] << 8) | h[8], h[9]
+            assert nc == 3 and all(h[11 + 3 * i] == 0x11 for i in range(3))
+    comps = [(sos[5 + 2 * i], sos[6 + 2 * i]) for i in range(3)]
+    raw = bytearray(); i = 0
+    while i < len(data):                          # un-stuff, stop at EOI
+        if data[i] == 0xFF:
+            if data[i + 1] == 0: raw.append(0xFF); i += 2; continue
+            break
+        raw.append(data[i]); i += 1
+    bits = "".join(format(x, "08b") for x in raw)
+    pos, streams = 0, ["", "", ""]
+
+    def sym(tab):
+        nonlocal pos
+        code = 0
+        for ln in range(1, 17):
+            code = (code << 1) | int(bits[pos]); pos += 1
+            if (ln, code) in tab:
+                return tab[(ln, code)]
+        raise AssertionError("bad code")
+    for _ in range(((W + 7) // 8) * ((H + 7) // 8)):
+        for c, (cid, t) in enumerate(comps):
+            start = pos
+            cat = sym(huff[t >> 4])                      # DC: category, then that many bits
+            pos += cat
+            k = 1
+            while k < 64:
+                rs = sym(huff[0x10 | (t & 15)])
+                if rs == 0: break
+                if rs == 0xF0: k += 16; continue
+                k += (rs >> 4) + 1; pos += rs & 15
+            streams[c] += bits[start:pos]
+    out = bytearray(b"\xff\xd8") + b"".join(hdrs)
+    for c, (cid, t) in enumerate(comps):
+        out += bytes([0xFF, 0xDA, 0, 8, 1, cid, t, 0, 63, 0])
+        st = streams[c] + "1" * (-len(streams[c]) % 8)
+        for q in range(0, len(st), 8):
+            v = int(st[q:q + 8], 2); out.append(v)
+            if v == 0xFF: out.append(0)
+    return bytes(out + b"\xff\xd9")
+
+
+def test_sequential_file_with_one_scan_per_component():
+    g = np.load(GOLD)
+    blob = _split_scans_444(g["q95_444_opt_file"].tobytes())
+    assert blob.count(b"\xff\xda") == 3
+    assert np.array_equal(colmap.decode_jpeg(blob), g["q95_444_opt_rgb"])
+
+
 def test_jpeg_unsupported_and_corrupt_files_are_refused():
     g = np.load(GOLD)
+    # arithmetic coding (SOF9) is refused by name; so is 12-bit precision
+    blob = bytearray(g["q75_420_file"].tobytes())
+    sof = blob.index(b"\xff\xc0")
+    ari = bytes(blob[:sof + 1]) + b"\xc9" + bytes(blob[sof + 2:])
     with pytest.raises(ValueError, match="unsupported"):
-        colmap.decode_jpeg(g["progressive_file"].tobytes())
+        colmap.decode_jpeg(ari)
+    deep = bytearray(blob); deep[sof + 4] = 12
+    with pytest.raises(ValueError, match="unsupported"):
+        colmap.decode_jpeg(bytes(deep))
     blob = g["q75_420_file"].tobytes()
     with pytest.raises(ValueError):
         colmap.decode_jpeg(blob[:40])
@@ -56,12 +148,14 @@ def test_jpeg_live_sweep_against_pillow():
         img[H // 2:] = (np.linspace(0, 255, W)[None, :, None] * np.ones((H - H // 2, 1, 3))).astype(np.uint8)
         for q in (20, 75, 98):
             for sub in (0, 1, 2):
-                b = io.BytesIO()
-                Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=sub, optimize=bool(q & 1))
-                ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))
-                assert np.array_equal(colmap.decode_jpeg(b.getvalue()), ref), (W, H, q, sub)
-                n += 1
-    assert n == 45
+                for prog in (False, True):
+                    b = io.BytesIO()
+                    Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=sub, optimize=bool(q & 1),
+                                              progressive=prog)
+                    ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))
+                    assert np.array_equal(colmap.decode_jpeg(b.getvalue()), ref), (W, H, q, sub, prog)
+                    n += 1
+    assert n == 90
 
 
 def test_resize_area_integer_and_fractional_scales():
@@ -271,16 +365,24 @@ def test_exif_orientation_is_applied_like_cv_imread(tmp_path, big_endian):
     assert colmap.exif_orientation(blob[:2] + b"\xff\xe1\x00\x08Exif\x00\x00" + blob[2:]) == 1
 
 
-def test_progressive_jpeg_goes_to_pillow_or_says_what_to_do(tmp_path):
+def test_progressive_jpeg_is_read_natively(tmp_path):
+    """read_image_u8 on a progressive file: the own decoder (no Pillow needed since round 3)."""
     g = np.load(GOLD)
     path = str(tmp_path / "prog.jpg")
-    open(path, "wb").write(g["progressive_file"].tobytes())
-    try:
-        import PIL  # noqa: F401
-    except ImportError:
-        with pytest.raises(ValueError, match="Pillow"):
-            colmap.read_image_u8(path)
-        return
+    open(path, "wb").write(g["prog_q85_420_file"].tobytes())
+    assert np.array_equal(colmap.read_image_u8(path), g["prog_q85_420_rgb"])
+
+
+def test_cmyk_jpeg_goes_to_pillow_or_says_what_to_do(tmp_path):
+    """What the own decoder refuses by name (here: a four-component CMYK file) is handed to Pillow when that
+    is installed — the same libjpeg cv::imread uses — and refused with instructions otherwise."""
+    PIL = pytest.importorskip("PIL")
     from PIL import Image
+
+    rs = np.random.RandomState(3)
+    path = str(tmp_path / "cmyk.jpg")
+    Image.fromarray(rs.randint(0, 256, (24, 32, 4)).astype(np.uint8), "CMYK").save(path, "JPEG", quality=90)
+    with pytest.raises(ValueError, match="unsupported"):
+        colmap.decode_jpeg(open(path, "rb").read())
     ref = np.asarray(Image.open(path).convert("RGB"))
     assert np.array_equal(colmap.read_image_u8(path), ref)
