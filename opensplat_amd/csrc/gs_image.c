@@ -208,8 +208,8 @@ static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int
         tmp2 = z1 + z3 * (-FIX_1_847759065);
         tmp3 = z1 + z2 * FIX_0_765366865;
         z2 = in0; z3 = in4;
-        tmp0 = (z2 + z3) << CONST_BITS;
-        tmp1 = (z2 - z3) << CONST_BITS;
+        tmp0 = (z2 + z3) * (1L << CONST_BITS);   /* (a shift of a negative value is undefined in C) */
+        tmp1 = (z2 - z3) * (1L << CONST_BITS);
         tmp10 = tmp0 + tmp3; tmp13 = tmp0 - tmp3; tmp11 = tmp1 + tmp2; tmp12 = tmp1 - tmp2;
         tmp0 = in7; tmp1 = in5; tmp2 = in3; tmp3 = in1;
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; z4 = tmp1 + tmp3;
@@ -235,8 +235,8 @@ static void idct_islow(const int16_t *coef, const uint16_t *q, uint8_t *out, int
         z1 = (z2 + z3) * FIX_0_541196100;
         tmp2 = z1 + z3 * (-FIX_1_847759065);
         tmp3 = z1 + z2 * FIX_0_765366865;
-        tmp0 = (w[0] + w[4]) << CONST_BITS;
-        tmp1 = (w[0] - w[4]) << CONST_BITS;
+        tmp0 = (w[0] + w[4]) * (1L << CONST_BITS);
+        tmp1 = (w[0] - w[4]) * (1L << CONST_BITS);
         tmp10 = tmp0 + tmp3; tmp13 = tmp0 - tmp3; tmp11 = tmp1 + tmp2; tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; z4 = tmp1 + tmp3;
