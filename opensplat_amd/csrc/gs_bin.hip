@@ -442,7 +442,7 @@ __device__ __forceinline__ void scatter_tiles(const ScatterIn &in, int n, int ti
     TileRect r = {0, 0, 0, 0};
     uint32_t db = 0;
     SplatForMask g = {0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u};
-    uint4 w = make_uint4(kNoRowTable, 0u, 0u, 0u);
+    RowTable w = {kNoRowTable, 0u, 0u, 0u, 0u};
     if (valid) {
         g.x = in.p0.x; g.y = in.p0.y; g.A = in.p0.z; g.B = in.p0.w; g.C = in.p1.x;
         g.smax = __float_as_uint(in.p1.z);
@@ -453,14 +453,17 @@ __device__ __forceinline__ void scatter_tiles(const ScatterIn &in, int n, int ti
         db = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
     }
     const int cnt = valid ? r.count() : 0;
-    // small rectangles: the lane walks its own tiles, masks from the Gaussian's block-row table
+    // the Gaussian's block-row table once, for every lane with tiles (rectangles beyond 64 x 64 pixels
+    // get none: their tiles fall back to block_mask16)
+    if (__builtin_amdgcn_ballot_w64(cnt > 0) != 0ull) {
+        if (cnt > 0) w = block_rows_table(g.x, g.y, g.A, g.B, g.C, g.smax, g.rx, g.ry);
+    }
+    // small rectangles: the lane walks its own tiles
     if (__builtin_amdgcn_ballot_w64(cnt > 0 && cnt <= kLaneTiles) != 0ull) {
-        if (cnt > 0 && cnt <= kLaneTiles)
-            w = block_rows_table(g.x, g.y, g.A, g.B, g.C, g.smax, g.rx, g.ry);
         if (cnt > 0 && cnt <= kLaneTiles) {
             for (int ty = r.ty0; ty < r.ty1; ty++)
                 for (int tx = r.tx0; tx < r.tx1; tx++) {
-                    const uint32_t m = w.x != kNoRowTable
+                    const uint32_t m = w.base != kNoRowTable
                                            ? mask_from_rows(w, tx, ty)
                                            : block_mask16(g.x, g.y, g.A, g.B, g.C, g.smax, g.rx, g.ry,
                                                           tx * GS_TILE, ty * GS_TILE);
@@ -469,7 +472,8 @@ __device__ __forceinline__ void scatter_tiles(const ScatterIn &in, int n, int ti
         }
     }
     // a rectangle with more than kLaneTiles tiles is walked by the whole wave (one lane looping over
-    // thousands of tiles would stall the other 63): every lane takes tiles of the broadcast record
+    // thousands of tiles would stall the other 63): every lane takes tiles of the broadcast record and
+    // assembles its mask from the broadcast row table
     uint64_t big = __builtin_amdgcn_ballot_w64(cnt > kLaneTiles);
     const int lane = threadIdx.x & 63;
     while (big) {
@@ -481,13 +485,24 @@ __device__ __forceinline__ void scatter_tiles(const ScatterIn &in, int n, int ti
         const int ty0 = GS_BCAST_I(r.ty0), ty1 = GS_BCAST_I(r.ty1);
         const uint32_t d = (uint32_t)GS_BCAST_I(db);
         const int id = GS_BCAST_I(n);
+        RowTable bw;
+        bw.base = (uint32_t)GS_BCAST_I(w.base);
+        const int wd = tx1 - tx0, total = wd * (ty1 - ty0);
+        if (bw.base != kNoRowTable) {
+            bw.r0 = (uint32_t)GS_BCAST_I(w.r0); bw.r1 = (uint32_t)GS_BCAST_I(w.r1);
+            bw.r2 = (uint32_t)GS_BCAST_I(w.r2); bw.r3 = (uint32_t)GS_BCAST_I(w.r3);
+            for (int i = lane; i < total; i += 64) {
+                const int tx = tx0 + i % wd, ty = ty0 + i / wd;
+                emit(ty * tiles_x + tx, d, id, mask_from_rows(bw, tx, ty));
+            }
+            continue;
+        }
         const float bx = GS_BCAST_F(g.x), by = GS_BCAST_F(g.y), bA = GS_BCAST_F(g.A);
         const float bB = GS_BCAST_F(g.B), bC = GS_BCAST_F(g.C);
         const uint32_t bs = (uint32_t)GS_BCAST_I(g.smax), brx = (uint32_t)GS_BCAST_I(g.rx);
         const uint32_t bry = (uint32_t)GS_BCAST_I(g.ry);
 #undef GS_BCAST_I
 #undef GS_BCAST_F
-        const int wd = tx1 - tx0, total = wd * (ty1 - ty0);
         for (int i = lane; i < total; i += 64) {
             const int tx = tx0 + i % wd, ty = ty0 + i / wd;
             emit(ty * tiles_x + tx, d, id,

@@ -301,26 +301,31 @@ __device__ __forceinline__ uint32_t block_mask16(float gx, float gy, float A, fl
     return mask;
 }
 
-// The same coverage computed ONCE PER GAUSSIAN instead of once per (tile, Gaussian): a 16-byte table of
-// the block-column extent of each 4-pixel block row the Gaussian's rectangle spans —
-//   w.x = first block row | first block column << 16     (image / 4; 0xFFFFFFFF: no table)
-//   w.y, w.z, w.w = twelve rows x one byte: (first column - w.x's) | (last column - w.x's) << 4;
-//                   first > last (0x0F) = row not reached
+// The same coverage computed ONCE PER GAUSSIAN instead of once per (tile, Gaussian): a table of the
+// block-column extent of each 4-pixel block row the Gaussian's rectangle spans —
+//   base = first block row | first block column << 16      (image / 4; kNoRowTable: no table)
+//   r0..r3 = sixteen rows x one byte: (first column - base's) | (last column - base's) << 4;
+//                first > last (0x0F) = row not reached
 // — from which the mask of any tile is assembled with a few integer operations (mask_from_rows): the
-// per-entry work of the binning drops from ~300 to ~90 VALU instructions and its gather from 36 to 16
-// bytes.  Rectangles spanning more than 12 block rows or 16 block columns (48 x 64 pixels) get no
-// table; their entries fall back to block_mask16.
+// per-entry work of the binning drops from ~300 to ~90 VALU instructions.  Rectangles spanning more
+// than 16 block rows or 16 block columns (64 x 64 pixels) get no table; their entries fall back to
+// block_mask16.
 constexpr uint32_t kNoRowTable = 0xFFFFFFFFu;
-__device__ __forceinline__ uint4 block_rows_table(float gx, float gy, float A, float B, float C,
-                                                  uint32_t smax_bits, uint32_t rx, uint32_t ry) {
+constexpr int kRowTableRows = 16;
+struct RowTable {   // (named words, not an array: an array member sends the whole table to scratch memory)
+    uint32_t base;
+    uint32_t r0, r1, r2, r3;
+};
+__device__ __forceinline__ RowTable block_rows_table(float gx, float gy, float A, float B, float C,
+                                                     uint32_t smax_bits, uint32_t rx, uint32_t ry) {
     const int x0 = (int)(rx & 0xFFFFu), x1 = (int)(rx >> 16) - 1;   // inclusive
     const int y0 = (int)(ry & 0xFFFFu), y1 = (int)(ry >> 16) - 1;
-    uint4 w = make_uint4(kNoRowTable, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu);
+    RowTable w = {kNoRowTable, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu};
     if (x1 < x0 || y1 < y0) return w;
     const int br0 = y0 >> 2, br1 = y1 >> 2, bc0 = x0 >> 2, bc1 = x1 >> 2;
-    if (br1 - br0 >= 12 || bc1 - bc0 >= 16) return w;
+    if (br1 - br0 >= kRowTableRows || bc1 - bc0 >= 16) return w;
     const EllipseRows e = ellipse_rows(gx, gy, A, B, C, smax_bits);
-    uint32_t rows0 = 0x0F0F0F0Fu, rows1 = 0x0F0F0F0Fu, rows2 = 0x0F0F0F0Fu;
+    uint32_t rows0 = 0x0F0F0F0Fu, rows1 = 0x0F0F0F0Fu, rows2 = 0x0F0F0F0Fu, rows3 = 0x0F0F0F0Fu;
     for (int k = 0; k <= br1 - br0; k++) {   // (per-lane trip count: 2.8 on average at C2)
         const int ylo = max(4 * (br0 + k), y0), yhi = min(4 * (br0 + k) + 3, y1);
         int clo = x0, chi = x1;
@@ -337,23 +342,28 @@ __device__ __forceinline__ uint4 block_rows_table(float gx, float gy, float A, f
             const uint32_t clr = ~(0xFFu << sh), set = byte << sh;
             if ((k >> 2) == 0) rows0 = (rows0 & clr) | set;
             else if ((k >> 2) == 1) rows1 = (rows1 & clr) | set;
-            else rows2 = (rows2 & clr) | set;
+            else if ((k >> 2) == 2) rows2 = (rows2 & clr) | set;
+            else rows3 = (rows3 & clr) | set;
         }
     }
-    w.x = (uint32_t)br0 | ((uint32_t)bc0 << 16);
-    w.y = rows0; w.z = rows1; w.w = rows2;
+    w.base = (uint32_t)br0 | ((uint32_t)bc0 << 16);
+    w.r0 = rows0; w.r1 = rows1; w.r2 = rows2; w.r3 = rows3;
     return w;
 }
-// mask of the tile at tile coordinates (tx, ty) from a row table; only for w.x != kNoRowTable
-__device__ __forceinline__ uint32_t mask_from_rows(const uint4 w, int tx, int ty) {
-    const int br0 = (int)(w.x & 0xFFFFu), bc0 = (int)(w.x >> 16);
+// mask of the tile at tile coordinates (tx, ty) from a row table; only for w.base != kNoRowTable
+__device__ __forceinline__ uint32_t mask_from_rows(const RowTable w, int tx, int ty) {
+    // (by value, words copied to scalars: a select among the members of a struct behind a reference is a
+    // select among ADDRESSES, which pins the table in scratch memory)
+    const uint32_t r0 = w.r0, r1 = w.r1, r2 = w.r2, r3 = w.r3;
+    const int br0 = (int)(w.base & 0xFFFFu), bc0 = (int)(w.base >> 16);
     const int dc = bc0 - 4 * tx;   // table columns -> tile-local block columns
     uint32_t mask = 0u;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int k = 4 * ty + r - br0;
-        const uint32_t word = (k >> 2) == 0 ? w.y : ((k >> 2) == 1 ? w.z : w.w);
-        const uint32_t byte = (k >= 0 && k < 12) ? ((word >> ((k & 3) * 8)) & 0xFFu) : 0x0Fu;
+        const int q = k >> 2;
+        const uint32_t word = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : r3));
+        const uint32_t byte = (k >= 0 && k < kRowTableRows) ? ((word >> ((k & 3) * 8)) & 0xFFu) : 0x0Fu;
         const int lo = max((int)(byte & 15u) + dc, 0), hi = min((int)(byte >> 4) + dc, 3);
         // (an unreached row has first = 15 > last = 0; clipping to the tile keeps first > last)
         const uint32_t cm = ((2u << max(hi, 0)) - 1u) & ~((1u << lo) - 1u);
