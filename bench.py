@@ -490,6 +490,34 @@ def operator_binning_probe(scene, dev, passes=3):
             "policy": "running maximum of 1.125 M + 1024 per (device, width, height)"}
 
 
+def moving_camera_probe(pipe, scene, cams, passes=3):
+    """The timed scene under a camera that changes EVERY step (the eight C4 yaw cameras in turn, after
+    one untimed pass): what a training loop sees — no frame finds its lists, records or gradient
+    records warm in the caches from an identical predecessor, and the speculative id-list capacity must
+    hold across views.  Rides in the default line so that the driver captures it."""
+    import torch
+
+    misses0 = pipe.misses
+    for c in cams:                      # one pass to settle the capacity (its misses are reported)
+        pipe.set_camera(*c)
+        pipe.step()
+    torch.cuda.synchronize()
+    misses_first_pass = pipe.misses - misses0
+    n = passes * len(cams)
+    t0 = time.perf_counter()
+    for i in range(n):
+        pipe.set_camera(*cams[i % len(cams)])
+        pipe.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"cameras": len(cams), "steps": n, "value": n / dt, "unit": "rasterizations/s",
+           "ms_per_step": dt / n * 1e3, "repeated_forwards_first_pass": misses_first_pass,
+           "repeated_forwards_timed": pipe.misses - misses0 - misses_first_pass,
+           "note": "yaw -14 .. +14 deg around the timed camera, a different camera every step"}
+    pipe.set_camera(scene.viewmat, scene.projmat)
+    return out
+
+
 def cpu_baseline(scene, n_sample):
     """OpenSplat's gsplat-cpu (oracle/_ref) or, if that build is absent, the C restatement."""
     import oracle
@@ -796,6 +824,11 @@ def main():
                 out["speculative_binning"]["operator_path"] = operator_binning_probe(scene, dev)
             except Exception as e:
                 out["speculative_binning"]["operator_path"] = {"error": repr(e)}
+        if world == 1 and plain and cfg == "c2" and not args.no_cpu_baseline:
+            try:
+                out["moving_camera"] = moving_camera_probe(pipe, scene, cams)
+            except Exception as e:
+                out["moving_camera"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, args.cpu_gaussians)
