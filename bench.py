@@ -449,6 +449,8 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, profiled_name):
                     live = e.get("live_lane_frac")
                     rv.append({"kernel": k, "valu_busy_frac": busy, "live_lane_frac": live,
                                "useful_frac": None if live is None else busy * live,
+                               "salu_per_valu": e.get("salu_per_valu"),
+                               "valu_insts_per_launch": e.get("valu_insts_per_launch"),
                                "steps_per_list_entry": e.get("steps_per_list_entry"),
                                "block_entries_per_list_entry": e.get("block_entries_per_list_entry")})
         except Exception:

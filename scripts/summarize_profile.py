@@ -149,6 +149,10 @@ def main():
         if d.get("SQ_BUSY_CYCLES"):
             e["valu_busy_of_8"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_BUSY_CYCLES"]
             e["valu_insts_per_launch"] = d.get("SQ_INSTS_VALU")
+            if d.get("SQ_INSTS_VALU"):
+                # the CU's one scalar unit serves four SIMDs: a kernel near one scalar instruction per
+                # vector instruction is co-bound by it (the forward's walk)
+                e["salu_per_valu"] = d.get("SQ_INSTS_SALU", 0) / d["SQ_INSTS_VALU"]
         if d.get("SQ_WAVE_CYCLES"):
             e["wait_any_frac"] = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
         kern[key] = e
