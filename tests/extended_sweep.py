@@ -2,7 +2,7 @@
 """One-off stress of the compositing kernels beyond the 15 seeded cases of tests/test_gpu_parity.py:
 random configurations START..END, forward bit-exact against the oracle (image, final_Ts, last
 contributor), backward within 2e-5 with 1, 2 and 4 pixels per lane and in the deterministic mode.
-Test infrastructure (uses oracle/ like the tests do).   python scripts/extended_sweep.py [START END]"""
+Test infrastructure (uses oracle/ like the tests do).   python tests/extended_sweep.py [START END]"""
 import os
 import sys
 
