@@ -560,6 +560,25 @@ def test_sort_class_launch_policy_every_branch_and_every_stale_transition():
                               np_(ref["binned"].gaussian_ids_sorted)[:b.num_isects])
         assert np.array_equal(np_(b.block_masks)[:b.num_isects], np_(ref["binned"].block_masks)[:b.num_isects])
         assert np.array_equal(np_(f["img"]), np_(ref["img"]))
+    # a capacity miss under the one-launch policy (the 1024 class alone clamps the overflowing ranges itself)
+    sc, ref = mid_dense
+    assert 400 < ws.list_stats[1] <= 900 and ws.list_stats[0] > 300 * tiles
+    ws.capacity = 1024
+    opac = to_dev(sc.opacities.reshape(-1))
+    tries = 0
+    while True:
+        b = cabi.bin_and_sort(sc.W, sc.H, ref["xys"], ref["depths"], ref["radii"], ref["conics"], ref["colors"],
+                              opac, ref["cov2d"], ws, speculative=True)
+        f = cabi.rasterize_forward(sc.W, sc.H, b, sc.background)
+        tries += 1
+        if cabi.validate_binning(b):
+            break
+        assert int(np_(b.tile_bins).max()) <= 1024
+    torch.cuda.synchronize()
+    assert tries == 2
+    assert np.array_equal(np_(b.gaussian_ids_sorted)[:b.num_isects],
+                          np_(ref["binned"].gaussian_ids_sorted)[:b.num_isects])
+    assert np.array_equal(np_(f["img"]), np_(ref["img"]))
 
 
 def test_roctx_ranges_can_be_switched_on():
