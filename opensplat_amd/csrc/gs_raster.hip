@@ -387,7 +387,6 @@ __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float
 constexpr int kAcc = 9;           // accumulator floats per staged entry
 constexpr int kAccStride = kChunk + 1;  // component-major [9][65]: the nine components of an entry in nine banks
 constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_FLAG_DETERMINISTIC
-constexpr int kBackwardPixelsPerLane = 2;      // WaveGeom of the backward when the list statistics are unknown
 
 // (five waves per SIMD: the compiler keeps the rare exact-exponential / rectangle paths out of the
 // register budget)
@@ -399,25 +398,20 @@ constexpr int kBackwardPixelsPerLane = 2;      // WaveGeom of the backward when 
 #ifndef GS_BWD_PREFETCH
 #define GS_BWD_PREFETCH 0
 #endif
+// One wave of the backward: the pixels [wx0, wx0 + WW) x [wy0, wy0 + WH) of `tile` (WaveGeom<PX>).  The
+// LDS arrays belong to the calling kernel (one wave per workgroup).
 template <bool EXACT, bool DET, int PX>
-// (four pixels per lane at 96 VGPRs keep eight values in scratch, touched once per CHUNK, not per step:
-// 356 us against 363 us with four waves per SIMD and none)
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
-k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
-                     const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
-                     const int2 *__restrict__ bins,
-                     const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
-                     const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
-                     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
-                     const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                     float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+__device__ __forceinline__ void
+backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__restrict__ sid,
+              float *__restrict__ acc, int W, int H, const int32_t *__restrict__ ids,
+              const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
+              const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+              const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+              const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+              const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+              float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
     using G = WaveGeom<PX>;
-    __shared__ SRecB stage[kChunk + 1];
-    __shared__ int sid[kChunk];
-    __shared__ float acc[kAcc * kAccStride];
     const int lane = threadIdx.x;
-    int tile, wx0, wy0;
-    if (!decode_wave<PX>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
@@ -703,6 +697,76 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
         for (int i = 0; i < kAcc; i++) acc[i * kAccStride + lane] = 0.0f;
     }
 }
+
+// One geometry for every tile (flag bits 21..22: measurements, the wave-geometry tests).
+template <bool EXACT, bool DET, int PX>
+// (four pixels per lane at 96 VGPRs keep eight values in scratch, touched once per CHUNK, not per step:
+// 356 us against 363 us with four waves per SIMD and none)
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                     const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
+                     const int2 *__restrict__ bins,
+                     const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                     const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                     const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                     float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    __shared__ SRecB stage[kChunk + 1];
+    __shared__ int sid[kChunk];
+    __shared__ float acc[kAcc * kAccStride];
+    int tile, wx0, wy0;
+    if (!decode_wave<PX>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
+    backward_wave<EXACT, DET, PX>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
+                                  bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+}
+
+// The default: four pixels per lane — one wave per tile — amortise the per-step reduction best, but leave
+// a tile's whole list to ONE wave; a tile whose list is much longer than the others (clustered scenes: a
+// few thousand entries) would finish long after the rest of the frame.  Such tiles — list longer than
+// `long_len`, among the first kLongSlots of the longest-first order — are taken by FOUR waves with one
+// pixel per lane instead (8 x 8 quadrants, a fourth of the steps each), in the same launch: the first
+// 4 * kLongSlots workgroups look at those slots and leave unless the tile is long, the workgroup that owns
+// the tile with four pixels per lane leaves if it is.  Both read the same bins and the same threshold.
+constexpr int kLongSlots = 64;
+template <bool EXACT, bool DET>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_len,
+                           const int32_t *__restrict__ order, const int32_t *__restrict__ ids,
+                           const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
+                           const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                           const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                           const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                           const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                           float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    __shared__ SRecB stage[kChunk + 1];
+    __shared__ int sid[kChunk];
+    __shared__ float acc[kAcc * kAccStride];
+    const int b = blockIdx.x;
+    if (b < 4 * kLongSlots) {
+        const int slot = b >> 2, part = b & 3;
+        if (slot >= num_tiles || !order) return;   // (without the longest-first order: no long path)
+        const int tile = order[slot];
+        const int2 r = bins[tile];
+        if (r.y - r.x <= long_len) return;
+        const int wx0 = (tile % tiles_x) * GS_TILE + 8 * (part & 1), wy0 = (tile / tiles_x) * GS_TILE + 8 * (part >> 1);
+        if (wx0 >= W || wy0 >= H) return;
+        backward_wave<EXACT, DET, 1>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1,
+                                     bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+        return;
+    }
+    // (decode_wave<4> on the remaining workgroups; the slot decides whether the tile was taken above)
+    const int bb = b - 4 * kLongSlots;
+    const int slot = ((bb >> 3) << 3) + (bb & 7);
+    if (slot >= num_tiles) return;
+    const int tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
+    if (slot < kLongSlots && order) {
+        const int2 r = bins[tile];
+        if (r.y - r.x > long_len) return;
+    }
+    const int wx0 = (tile % tiles_x) * GS_TILE, wy0 = (tile / tiles_x) * GS_TILE;
+    backward_wave<EXACT, DET, 4>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
+                                 bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+}
 #undef GS_WALK_STEP
 #undef GS_WALK_PACK
 
@@ -915,19 +979,25 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         GS_HIP_CHECK(hipMemsetAsync(gfix, 0, (size_t)N * gs::kGradRec * sizeof(long long), s));
     else if (!(flags & GS_FLAG_RECORDS_ZEROED))
         GS_HIP_CHECK(hipMemsetAsync(gacc, 0, rec_bytes, s));
-    // pixels per lane of the backward (WaveGeom).  Four (one wave per tile, 8 x 8 blocks) amortise
-    // the per-step reduction best — 360 against 381 us at C2, 2.13 against 2.26 ms at C3 — but leave
-    // a tile's whole list to ONE wave: with a few very long lists (hot-spot scene: 0.81 against 0.51
-    // ms) two pixels per lane, i.e. two waves per tile, finish sooner.  list_stats (the scan's
-    // {M, longest list}) decides; without it the safe middle is taken.  Flag bits 21..22 select
-    // 1 / 2 / 4 explicitly (measurements).
-    int px_per_lane = gs::kBackwardPixelsPerLane;
+    // Wave geometry of the backward (WaveGeom): four pixels per lane — one wave per tile, 8 x 8 blocks —
+    // amortise the per-step reduction best (338 against 378 / 500 us with two / one at C2), and the
+    // default launch gives the few tiles whose list is far longer than the others four waves with one
+    // pixel per lane (k_rasterize_backward_mixed).  "Far longer": beyond 4 x the mean list and 1024
+    // entries, from the scan's {M, longest list} of the previous frame when the caller has it (a stale
+    // value costs time, not correctness: both halves of the launch read the same threshold).  Flag bits
+    // 21..22 select 1 / 2 / 4 pixels per lane for every tile (measurements, tests).
+    int px_per_lane = 0;   // 0: mixed
+    int long_len = 1024;
     if (list_stats && list_stats[0] > 0) {
         const int64_t mean_len = ((int64_t)list_stats[0] + tiles - 1) / tiles;
-        px_per_lane = (int64_t)list_stats[1] <= 8 * mean_len + 256 ? 4 : 2;
+        long_len = (int)std::min<int64_t>(std::max<int64_t>(4 * mean_len, 1024), 1 << 30);
+        // no list was that long in the frame the statistics come from: the plain launch (the mixed one
+        // costs 256 workgroups that look and leave, 1.5 us at C2)
+        if (list_stats[1] <= long_len) px_per_lane = 4;
     }
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    const int units = (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // WaveGeom<PX>::PER_TILE waves per tile
+    const int units = px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
+                                       : (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // PER_TILE waves per tile
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
@@ -936,11 +1006,16 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     hipLaunchKernelGGL((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
                        tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
                        bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
-#define GS_BWD_LAUNCH(EX, DT)                                      \
-    do {                                                           \
-        if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);           \
-        else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);      \
-        else GS_BWD_LAUNCH3(EX, DT, 4);                            \
+#define GS_BWD_LAUNCH(EX, DT)                                                                              \
+    do {                                                                                                   \
+        if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);                                                   \
+        else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);                                              \
+        else if (px_per_lane == 4) GS_BWD_LAUNCH3(EX, DT, 4);                                              \
+        else                                                                                               \
+            hipLaunchKernelGGL((gs::k_rasterize_backward_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H, \
+                               tiles_x, tiles, long_len, tile_order, gaussian_ids_sorted, block_masks, bins, \
+                               pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, \
+                               gacc, gfix);                                                                \
     } while (0)
     if (det) {
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, true); else GS_BWD_LAUNCH(true, true);

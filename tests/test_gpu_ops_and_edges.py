@@ -475,6 +475,36 @@ def test_hot_spot_scene_matches_oracle(restated):
         assert rel_err(np_(base[k]), go[k].reshape(np_(base[k]).shape)) < 2e-5, k
 
 
+def test_very_long_lists_next_to_short_ones_match_oracle(restated):
+    """40 % of the Gaussians in a 24-px window: a handful of tiles with lists of several thousand entries —
+    far beyond 4 x the mean and 1024 — which the default backward launch gives FOUR waves with one pixel
+    per lane while every other tile keeps its one wave with four (k_rasterize_backward_mixed); also with
+    stale and with absent list statistics (the threshold then differs, the result must not)."""
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(30000, 203, 117, K=0, seed=91, znear=1.0, zfar=100.0, sigma_px=(1.0, 5.0),
+                            hot=(0.4, 24))
+    base = hip_pipeline(s, backward=True)
+    lens = np_(base["binned"].tile_bins)
+    lens = lens[:, 1] - lens[:, 0]
+    tiles = lens.size
+    assert lens.max() > 2500 and lens.max() > 8 * lens.mean() and (lens > max(1024, 4 * lens.mean())).sum() >= 2
+    fo, go = oracle_raster(restated, s, np_(base["xys"]), np_(base["conics"]), np_(base["colors"]),
+                           np_(base["cov2d"]), np_(base["depths"]), s.v_out)
+    assert np.array_equal(np_(base["img"]), fo["img"])
+    import ctypes
+
+    b = base["binned"]
+    own = b.list_stats
+    for stats in ("own", "stale_small", "stale_huge", None):
+        b.list_stats = {"own": own, "stale_small": (ctypes.c_int32 * 2)(tiles * 4, 40),
+                        "stale_huge": (ctypes.c_int32 * 2)(tiles * 5000, 9000), None: None}[stats]
+        g = cabi.rasterize_backward(s.W, s.H, s.N, b, s.background, base["final_Ts"], base["final_idx"],
+                                    to_dev(s.v_out), 0)
+        for k in ["v_xy", "v_conic", "v_colors", "v_opacity"]:
+            assert rel_err(np_(g[k]), go[k].reshape(np_(g[k]).shape)) < 2e-5, (stats, k)
+
+
 def test_bin_scan_reports_the_list_statistics():
     """gs_bin_scan stores {M, longest tile list} in pinned host memory (the sort picks its
     long-segment launches from the previous frame's values)."""
