@@ -249,9 +249,10 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            tile_order (from gs_bin_scan): the launch starts with the longest lists.  list_stats
  *            (the scan's {M, longest list}; nullable): the forward ignores it (every tile is
  *            composited by four quadrant waves); the backward gives a tile to ONE wave with four
- *            pixels per lane when the longest list is within 8x the mean (+256), to two waves
- *            with two pixels per lane otherwise or when the statistics are unknown.  Scheduling
- *            only: the sums differ by atomic order as always.
+ *            pixels per lane, and — when the statistics are unknown or their longest list exceeds
+ *            max(1024, 4 x mean) — the tiles whose own list exceeds that length to four waves with
+ *            one pixel per lane, inside the same launch.  Scheduling only: the sums differ by
+ *            atomic order as always.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
