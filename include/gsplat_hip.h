@@ -250,7 +250,7 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            (the scan's {M, longest list}; nullable): the forward ignores it (every tile is
  *            composited by four quadrant waves); the backward gives a tile to ONE wave with four
  *            pixels per lane, and — when the statistics are unknown or their longest list exceeds
- *            max(1024, 4 x mean) — the tiles whose own list exceeds that length to four waves with
+ *            max(512, 2 x mean) — the tiles whose own list exceeds that length to four waves with
  *            one pixel per lane, inside the same launch.  Scheduling only: the sums differ by
  *            atomic order as always.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,

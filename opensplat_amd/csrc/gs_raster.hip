@@ -982,15 +982,16 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     // Wave geometry of the backward (WaveGeom): four pixels per lane — one wave per tile, 8 x 8 blocks —
     // amortise the per-step reduction best (338 against 378 / 500 us with two / one at C2), and the
     // default launch gives the few tiles whose list is far longer than the others four waves with one
-    // pixel per lane (k_rasterize_backward_mixed).  "Far longer": beyond 4 x the mean list and 1024
-    // entries, from the scan's {M, longest list} of the previous frame when the caller has it (a stale
+    // pixel per lane (k_rasterize_backward_mixed).  "Far longer": beyond 2 x the mean list and 512
+    // entries (a wave slot works through tiles / slots ~ 1.6 mean lists at 1080p: a list much longer
+    // than that finishes after everything else), from the scan's {M, longest list} of the previous frame when the caller has it (a stale
     // value costs time, not correctness: both halves of the launch read the same threshold).  Flag bits
     // 21..22 select 1 / 2 / 4 pixels per lane for every tile (measurements, tests).
     int px_per_lane = 0;   // 0: mixed
-    int long_len = 1024;
+    int long_len = 512;
     if (list_stats && list_stats[0] > 0) {
         const int64_t mean_len = ((int64_t)list_stats[0] + tiles - 1) / tiles;
-        long_len = (int)std::min<int64_t>(std::max<int64_t>(4 * mean_len, 1024), 1 << 30);
+        long_len = (int)std::min<int64_t>(std::max<int64_t>(2 * mean_len, 512), 1 << 30);
         // no list was that long in the frame the statistics come from: the plain launch (the mixed one
         // costs 256 workgroups that look and leave, 1.5 us at C2)
         if (list_stats[1] <= long_len) px_per_lane = 4;
