@@ -727,7 +727,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
 // pixel per lane instead (8 x 8 quadrants, a fourth of the steps each), in the same launch: the first
 // 4 * kLongSlots workgroups look at those slots and leave unless the tile is long, the workgroup that owns
 // the tile with four pixels per lane leaves if it is.  Both read the same bins and the same threshold.
-constexpr int kLongSlots = 64;
+constexpr int kLongSlots = 256;
 template <bool EXACT, bool DET>
 __global__ void __launch_bounds__(64, GS_BWD_WAVES)
 k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_len,
