@@ -251,8 +251,9 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            composited by four quadrant waves); the backward gives a tile to ONE wave with four
  *            pixels per lane, and — when the statistics are unknown or their longest list exceeds
  *            max(512, 2 x mean) — the tiles whose own list exceeds that length to four waves with
- *            one pixel per lane, inside the same launch.  Scheduling only: the sums differ by
- *            atomic order as always.
+ *            one pixel per lane, inside the same launch; a frame of fewer than 1280 / 2560 tiles
+ *            gives EVERY tile four / two waves.  Scheduling only: the sums differ by atomic order
+ *            as always.
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */

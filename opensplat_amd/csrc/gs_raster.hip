@@ -996,6 +996,12 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         // costs 256 workgroups that look and leave, 1.5 us at C2)
         if (list_stats[1] <= long_len) px_per_lane = 4;
     }
+    // a small frame does not fill the chip with one wave per tile (256 CUs x 4 SIMDs x 5 waves = 5120 slots;
+    // the quarter-resolution frames a training run starts with have a few dozen tiles): more waves per
+    // tile then cost 1.1 / 1.5 x the work and take a half / a quarter of the time
+    constexpr int kWaveSlots = 5120;
+    if (4 * tiles <= kWaveSlots) px_per_lane = 1;
+    else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
     const int units = px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
                                        : (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // PER_TILE waves per tile
