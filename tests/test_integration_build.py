@@ -23,6 +23,38 @@ def _lines(out):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
+def test_fused_patch_adds_five_guarded_early_returns_and_nothing_else(tmp_path):
+    """`--fused`: model.cpp gains the include and four `if (device != kCPU) return
+    gs_fused::...` sites, every inserted line inside `#ifdef USE_HIP_NATIVE_FUSED`; with the inserted blocks
+    removed the file is the reference's, byte for byte; applying the patch twice changes nothing."""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    import apply_hip_native as A
+
+    src = open(os.path.join(REF, "model.cpp")).read()
+    out = A.patch_model_cpp(src)
+    assert out.count("#ifdef USE_HIP_NATIVE_FUSED") == 5 and out.count("#endif") == src.count("#endif") + 5
+    assert A.patch_model_cpp(out) == out
+    stripped = re.sub(r"#ifdef USE_HIP_NATIVE_FUSED\n.*?#endif\n\n?", "", out, flags=re.S)
+    # (the include hunk carries a trailing blank line; the others none)
+    assert stripped == src
+    for call in ("gs_fused::render(*this, Rinv, Tinv, T,", "gs_fused::optimizers_step(*this)",
+                 "gs_fused::after_train(*this, step)", "::mainLoss(rgb, gt, ssimWeight)", '#include "model_fused.inl"'):
+        assert out.count(call) == 1, call
+    # the CPU device never reaches the fused code: every call sits behind a device / is_cuda test
+    for m in re.finditer(r"#ifdef USE_HIP_NATIVE_FUSED\n(.*?)#endif", out, flags=re.S):
+        body = m.group(1)
+        assert "#include" in body or "device != torch::kCPU" in body or "rgb.is_cuda()" in body, body
+    # and the command-line form writes the same file
+    r = subprocess.run(["python3", os.path.join(ROOT, "integration", "apply_hip_native.py"), REF, "--out",
+                        str(tmp_path), "--fused"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(tmp_path / "model.cpp").read() == out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree")
 def test_patch_script_guards_only_the_gpu_declarations(tmp_path):
     r = subprocess.run(["python3", os.path.join(ROOT, "integration", "apply_hip_native.py"), REF, "--out",
                         str(tmp_path)], capture_output=True, text=True)
