@@ -401,19 +401,48 @@ def algorithmic_bytes(N, K, M, P):
     return total, per_stage
 
 
-def kernel_tables(N, K, M, P, stage_ms, kernel_ms, profiled_name):
+def kernel_tables(N, K, M, P, stage_ms, kernel_ms, kernel_live, profiled_name):
     """(kernels, kernels_profiled, roofline_valu) for the JSON line.
 
-    kernels           what THIS run measured with HIP events on the launch stream: the four one-kernel
-                      stages and the binning stage (count + scan + scatter + per-tile sorts), each with
-                      its algorithmic bytes (SURVEY.md §8d split) and the HBM fraction
-    kernels_profiled  every gs:: kernel from the committed rocprofv3 passes of the same command
+    kernels           EVERY kernel of the step as THIS run measured it (instrumented pass: HIP events on the
+                      launch stream right around each launch, gs_debug_timeline): mean ms per step, launches
+                      per step, and — where SURVEY.md §8d / DESIGN.md §4 define them — the kernel's algorithmic
+                      bytes and HBM fraction; followed by the stage rows (events at the stage boundaries)
+    kernels_profiled  REPLAYED: every gs:: kernel from the committed rocprofv3 passes of the same command
                       (profiles/kernels*.json, scripts/summarize_profile.py): average duration, counter
                       traffic, VALU issue occupancy
-    roofline_valu     the two compositing kernels are bound by VALU issue, not by HBM: of the issue slots
-                      they fill (valu_busy_frac) the fraction of lanes doing needed work (live_lane_frac,
-                      instrumented build) — useful_frac is their product, the number the kernel work of
-                      this repo moves"""
+    roofline_valu     REPLAYED: the two compositing kernels are bound by VALU issue, not by HBM: of the issue
+                      slots they fill (valu_busy_frac) the fraction of lanes doing needed work
+                      (live_lane_frac, instrumented build) — useful_frac is their product"""
+    # algorithmic bytes per kernel (prefix of the kernel's short name -> bytes per launch)
+    kalg = [
+        ("k_sh_project_pack16", N * (232 + 12) + N * (44 + 68)),
+        ("k_gaussian_forward", N * (44 + 12 * K + 112)),
+        ("k_gaussian_backward", N * (124 + 44 + 12 * K)),
+        ("k_count_tiles", N * 32),
+        ("k_scan_tiles", 16 * (P // 256)),
+        ("k_scatter", N * 36 + 16 * M),
+        ("k_bucket_sort", 22 * M),
+        ("k_rasterize_forward", 40 * M + 20 * P),
+        ("k_rasterize_backward", 40 * M + 20 * P + 36 * N),
+        ("memset(gradientrecords)", 64 * N),
+        ("k_project_forward", N * (40 + 44)),
+        ("k_project_backward", N * (40 + 36 + 40)),
+        ("k_sh_forward", N * (12 + 12 * K + 12)),
+        ("k_sh_backward", N * (24 + 12 * K)),
+        ("k_pack_splats", N * 52 + N * 52),
+        ("k_unpack_grads", N * 100),
+    ]
+    kernels = []
+    for name, e in kernel_live.items():
+        nbytes = next((b for pre, b in kalg if name.startswith(pre)), None)
+        ms = e["ms"]
+        per_launch = ms / max(e["launches_per_step"], 1e-9)
+        gbs = nbytes / (per_launch * 1e-3) / 1e9 if (nbytes and per_launch > 0) else None
+        kernels.append({"kernel": name, "ms": ms, "launches_per_step": e["launches_per_step"],
+                        "algorithmic_bytes": nbytes, "hbm_GBs": gbs,
+                        "hbm_frac": None if gbs is None else gbs / HBM_PEAK_GBS,
+                        "timed_by": "HIP events around the launch, this run (instrumented pass)"})
     alg = {
         "gaussian_fwd": ("k_sh_project_pack16 / k_gaussian_forward", N * (232 + 12) + N * (44 + 68)
                          if K == 16 else N * (44 + 12 * K + 112)),
@@ -422,32 +451,28 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, profiled_name):
         "rasterize_bwd": ("k_rasterize_backward (+ record memset)", 40 * M + 20 * P + 36 * N),
         "gaussian_bwd": ("k_gaussian_backward", N * (124 + 44 + 12 * K)),
     }
-    kernels = []
     for st, (kname, nbytes) in alg.items():
         if st not in stage_ms:
             continue
         ms = stage_ms[st]
-        if st == "rasterize_fwd" and kernel_ms.get("k_rasterize_forward"):
-            ms = kernel_ms["k_rasterize_forward"]
-        if st == "rasterize_bwd" and kernel_ms.get("k_rasterize_backward"):
-            ms = kernel_ms["k_rasterize_backward"]
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
         kernels.append({"stage": st, "kernel": kname, "ms": ms, "algorithmic_bytes": nbytes,
                         "hbm_GBs": gbs, "hbm_frac": None if gbs is None else gbs / HBM_PEAK_GBS,
-                        "timed_by": "HIP events, this run"})
+                        "timed_by": "HIP events at the stage boundaries, this run (instrumented pass)"})
     prof, rv = None, None
     path = os.path.join(ROOT, "profiles", profiled_name) if profiled_name else None
     if path and os.path.exists(path):
         try:
             d = json.load(open(path))
-            prof = {"source": "profiles/%s (rocprofv3, tag %s)" % (profiled_name, d.get("tag")),
-                    "kernels": d["kernels"]}
+            src = "replayed from profiles/%s (rocprofv3, tag %s) — not measured in this run" % (
+                profiled_name, d.get("tag"))
+            prof = {"source": src, "kernels": d["kernels"]}
             rv = []
             for k, e in sorted(d["kernels"].items()):
                 if k.startswith("k_rasterize_") and "valu_busy_of_8" in e:
                     busy = min(e["valu_busy_of_8"] / 8.0, 1.0)
                     live = e.get("live_lane_frac")
-                    rv.append({"kernel": k, "valu_busy_frac": busy, "live_lane_frac": live,
+                    rv.append({"kernel": k, "source": src, "valu_busy_frac": busy, "live_lane_frac": live,
                                "useful_frac": None if live is None else busy * live,
                                "salu_per_valu": e.get("salu_per_valu"),
                                "valu_insts_per_launch": e.get("valu_insts_per_launch"),
@@ -456,6 +481,47 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, profiled_name):
         except Exception:
             prof, rv = None, None
     return kernels, prof, rv
+
+
+def exchange_probe(pipe, world, dev, iters=5):
+    """N > 1: BOTH gradient exchanges timed on their own, back to back in the same run, on the step's real
+    buffers — `flat` = north_star's single sum all-reduce of the whole gradient buffer (236 B per Gaussian at
+    K = 16), `factored` = all-gather of the colour cotangents + all-reduce of the geometry block + the local SH
+    backward over the gathered cameras.  ms = max over ranks of the mean over `iters`
+    exchanges, each between barriers.  The first multi-GPU run answers the design question by itself."""
+    import torch
+
+    from opensplat_amd import dist
+
+    s = pipe.s
+    fx = pipe.fx if (pipe.fx is not None and pipe.fx.cpr == 1) else dist.FactoredExchange(s.N, s.K, 1, dev)
+    fx.set_cam_pos(0, pipe.cam_pos)
+
+    def flat():
+        dist.wait_all(dist.allreduce_all_async(pipe.grads))
+
+    def factored():
+        fx.start(pipe.grads)
+        fx.finish(pipe.grads, pipe.means, s.degrees_to_use)
+
+    out = {}
+    for name, fn in (("flat", flat), ("factored", factored)):
+        fn()   # warm-up (communicator channels, buffers)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters * 1e3
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        out[name + "_ms"] = float(t.item())
+    out["flat_bytes_moved_per_rank"] = int(2 * (world - 1) / world * pipe.grads.nbytes)
+    out["factored_bytes_moved_per_rank"] = fx.bytes_moved_per_rank
+    out["note"] = ("exchange alone (no render), %d iterations each, host-timed between synchronisations, max "
+                   "over ranks; the gradient values are whatever the last step left (sums of sums)" % iters)
+    return out
 
 
 def operator_binning_probe(scene, dev, passes=3):
@@ -677,56 +743,103 @@ def main():
                 print("bench.py:   rank %(rank)d -> %(device)s (%(name)s), local_rank %(local_rank)d, pid %(pid)d" % i,
                       file=sys.stderr)
             sys.stderr.flush()
+    # ---- warm-up (untimed): the W steps asked for, then more until the clocks and caches have settled —
+    # a 1080p step is 0.8 ms, five of them are over before the GPU has left its idle clock (the driver's
+    # `--steps 20 --warmup W` line of round 3 read 6 % below a 50-step run for that reason alone)
+    def timed_block(n):
+        """n plain steps (no events, no hooks) between barrier + synchronize on both sides; seconds (max
+        over ranks)."""
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    warm_t0 = time.perf_counter()
     for _ in range(args.warmup):
         one_step()
-    misses_warmup = pipe.misses
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    all_events, all_kernel_events = [], []
-
-    def new_pair():
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        b.record()  # creates the HIP handles gs_debug_time_next_kernel needs
-        return a, b
-
-    # HIP events are recorded inside the timed region on every `stride`-th step only: each record is
-    # a marker packet that costs ~5 us of stream time, a dozen per step would be 4 % of the step
-    stride = max(1, args.steps // 8)
-    sampled = [i for i in range(args.steps) if i % stride == 0]
-    kev_pool = {i: {k: new_pair() for k in ("k_rasterize_forward", "k_rasterize_backward")}
-                for i in sampled}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i in kev_pool:
-            ev = []
-            one_step(ev, kev_pool[i])
-            all_events.append(ev)
-            all_kernel_events.append(kev_pool[i])
-        else:
+    warmup_run = args.warmup
+    settle = float(os.environ.get("GSPLAT_BENCH_SETTLE_S", "0.3"))
+    while True:
+        # (every rank takes the same decision: the exchange inside one_step is collective)
+        go = torch.tensor([1.0 if (time.perf_counter() - warm_t0 < settle and warmup_run < 4000) else 0.0],
+                          device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(go, op=torch.distributed.ReduceOp.MAX)
+        if float(go.item()) == 0.0:
+            break
+        for _ in range(16):
             one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        torch.cuda.synchronize()
+        warmup_run += 16
+    misses_warmup = pipe.misses
 
-    # per-stage durations from HIP events recorded on the launch stream inside the timed region
+    # ---- the timed region: EXACTLY --steps plain steps.  Nothing is recorded inside it: no HIP events, no
+    # hooks (round 3 sampled every (steps // 8)-th step with ~11 event records of ~5 us each — with the
+    # driver's --steps 20 that was every other step) ----
+    elapsed = timed_block(args.steps)
+    misses_timed = pipe.misses - misses_warmup
+
+    # ---- a second, longer plain block (>= 200 steps and >= 0.25 s), reported beside the headline: what the
+    # path sustains once a run is long enough for the clocks to stop moving ----
+    sustained = None
+    if world == 1 or os.environ.get("GSPLAT_BENCH_SUSTAINED"):
+        n_sus = max(200, int(0.25 / max(elapsed / args.steps, 1e-6)) + 1)
+        n_sus = min(n_sus, 20000)
+        dt_sus = timed_block(n_sus)
+        sustained = {"steps": n_sus, "ms_per_step": dt_sus / n_sus * 1e3,
+                     "value": world * cpr * n_sus / dt_sus,
+                     "note": "plain steps like the timed region, more of them; not the headline"}
+
+    # ---- the instrumented pass, OUTSIDE the timed region: HIP events at the stage boundaries and — through
+    # the library's kernel timeline (gs_debug_timeline) — around EVERY kernel launch of the step ----
+    n_inst = 8
+    all_events, timelines = [], []
+    for _ in range(n_inst):
+        ev = []
+        cabi.timeline(True)
+        one_step(ev)
+        timelines.append(cabi.timeline_read())
+        cabi.timeline(False)
+        all_events.append(ev)
+    torch.cuda.synchronize()
+
+    # per-stage durations from HIP events recorded on the launch stream
     stage_ms = {n: 0.0 for n in pipe.stage_names}
     for ev in all_events:
         for k, name in enumerate(pipe.stage_names):
             stage_ms[name] += ev[k].elapsed_time(ev[k + 1])
     stage_ms = {k: v / max(len(all_events), 1) for k, v in stage_ms.items()}
-    # the two compositing kernels alone (events recorded inside the C ABI around the launch)
+    # every kernel of the step, by name: mean ms per step and launches per step
+    kernel_live = {}
+    for tl in timelines:
+        for name, ms in tl:
+            e = kernel_live.setdefault(cabi.kernel_short_name(name), [0.0, 0])
+            e[0] += ms
+            e[1] += 1
+    kernel_live = {k: {"ms": v[0] / n_inst, "launches_per_step": v[1] / n_inst} for k, v in kernel_live.items()}
+    # the two compositing kernels alone (whatever template instance ran)
     kernel_ms = {}
-    for name in ("k_rasterize_forward", "k_rasterize_backward"):
-        kernel_ms[name] = sum(ke[name][0].elapsed_time(ke[name][1]) for ke in all_kernel_events) \
-            / max(len(all_kernel_events), 1)
+    for short in ("k_rasterize_forward", "k_rasterize_backward"):
+        kernel_ms[short] = sum(v["ms"] for k, v in kernel_live.items() if k.startswith(short))
+
+    exchange_ab = None
+    if world > 1 and not args.stage_kernels:
+        try:
+            exchange_ab = exchange_probe(pipe, world, dev)     # collective: every rank takes part
+        except Exception as e:
+            exchange_ab = {"error": repr(e)}
 
     if rank == 0:
         N, K, M, P = scene.N, scene.K, pipe.num_isects, scene.W * scene.H
@@ -754,7 +867,7 @@ def main():
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3
         kernels, kernels_profiled, roofline_valu = kernel_tables(
-            N, K, M, P, stage_ms, kernel_ms,
+            N, K, M, P, stage_ms, kernel_ms, kernel_live,
             None if not tname else ("kernels.json" if tname == "traffic.json" else "kernels_c3.json"))
         out = {
             "metric": "forward+backward rasterizations/sec at 1M Gaussians 1080p",
@@ -782,8 +895,10 @@ def main():
                        "cameras_per_rank_per_step": cpr},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "replayed from profiles/%s (rocprofv3 PMC pass of the same command)" % tname,
                          "kernel_ms": dom_ms, "algorithmic_bytes": dom_bytes,
-                         "note": "HIP events around the kernel launch itself; the compositing kernels "
+                         "note": "achieved: HIP events around the kernel launch itself, THIS run; the compositing kernels "
                                  "are VALU-issue-bound, not HBM-bound (no dense contraction, no MFMA; "
                                  "SURVEY.md §8d, DESIGN.md §4) — the HBM fraction is reported as "
                                  "required; traffic = rocprofv3 FETCH_SIZE x 1.18 (factor calibrated on "
@@ -796,7 +911,19 @@ def main():
             # pixel x Gaussian evaluations per second of the compositing kernels, counted
             # as 256 pixels per (tile, Gaussian) list entry (the upper bound both kernels are sized by)
             "pixel_gaussian_evals_per_s": {k: 256.0 * M / (v * 1e-3) for k, v in kernel_ms.items() if v > 0},
-            "event_sampled_steps": len(all_events),
+            "warmup_steps_run": warmup_run,
+            "sustained": sustained,
+            "instrumented_steps": n_inst,
+            # which fields were MEASURED IN THIS RUN and which are read back from committed files
+            "provenance": {
+                "live": ["value", "ms_per_step", "sustained", "stage_ms", "kernel_ms", "kernels",
+                         "roofline.achieved", "roofline.kernel_ms", "path_roofline", "speculative_binning",
+                         "moving_camera", "cpu_baseline", "exchange_ms"],
+                "replayed": ["roofline.traffic", "roofline_valu", "kernels_profiled"],
+                "note": "live: timed region = exactly --steps plain steps; stage / kernel durations from an "
+                        "instrumented pass of %d steps outside it (HIP events on the launch stream, around "
+                        "every kernel launch).  replayed: rocprofv3 PMC / kernel-trace results of the same "
+                        "command, committed under profiles/ — NOT measured in this run" % n_inst},
             "path_roofline": {"algorithmic_bytes": total_bytes,
                               "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -811,6 +938,8 @@ def main():
                           "bytes_moved_per_rank": int(2 * (world - 1) / world * pipe.grads.nbytes)}),
             "grad_bytes_allreduced": (0 if world == 1 else 11 * N * 4 if pipe.fx is not None
                                       else pipe.grads.nbytes),
+            # both exchanges timed alone in this run (N > 1): flat = north_star's single all-reduce
+            "exchange_ab": exchange_ab,
             "allreduce_ms_rank0": stage_ms.get("allreduce", 0.0),
             # the whole exchange (all-reduce [+ all-gather + SH backward over the gathered cameras]) as
             # timed by HIP events on rank 0, apart from ms_per_step
@@ -818,7 +947,7 @@ def main():
             # speculative binning: forwards repeated because the id list (sized from the previous
             # call, +12.5 %) was too small — during warm-up / inside the timed region
             "speculative_binning": {"misses_warmup": misses_warmup,
-                                    "misses_timed": pipe.misses - misses_warmup,
+                                    "misses_timed": misses_timed,
                                     "id_list_capacity": pipe.ws.capacity},
         }
         if world == 1 and plain and not sequence and not args.no_cpu_baseline:   # (profiling passes skip both)

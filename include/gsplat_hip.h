@@ -91,7 +91,12 @@ typedef struct GsCamera {
 
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
-int gs_version(void);                /* 10000*major + 100*minor + patch */
+/* ABI version of THIS header: 10000*major + 100*minor + patch.  Bumped whenever an entry point changes its
+ * argument list (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0: round 4).  A consumer
+ * compiled against another header must refuse the library instead of calling through shifted arguments:
+ * opensplat_amd/cabi.py and libgsplat_torch.so compare gs_version() with this constant when they load. */
+#define GS_ABI_VERSION 400
+int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 
 /* ---------------------------------------------------------------------------------------------
  * Projection.  Replaces project_gaussians_forward_tensor (rasterizer/gsplat/bindings.h:42-64,
@@ -173,8 +178,8 @@ int gs_pack_splats(int W, int H, int N, const float *xys, const int32_t *radii,
 
 /* Workspace (bytes, 256-byte aligned base) sufficient for gs_bin_scan (any num_isects) and for
  * gs_bin_sort with capacity num_isects, for N Gaussians and a W x H image.  gs_bin_scan leaves
- * per-workgroup segment offsets and a 16-byte block-row table per Gaussian in it that the FOLLOWING
- * gs_bin_sort continues from: give both calls the same workspace (same base pointer; it may be
+ * per-workgroup segment offsets in it (where each persistent workgroup's entries start inside a tile's
+ * segment) that the FOLLOWING gs_bin_sort continues from: give both calls the same workspace (same base pointer; it may be
  * larger for the second call), the same N, W and H, and do not touch it in between.  gs_bin_sort
  * returns GS_ERR_WORKSPACE for a workspace address no gs_bin_scan of the same (N, W, H) has been
  * given (the library remembers the last scan of each workspace address on the host). */
@@ -300,9 +305,27 @@ int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags, gs_stream
  * calling thread (the compositing kernel alone), then disarms itself. */
 int gs_debug_time_next_kernel(void *event_start, void *event_stop);
 
+/* Measurement hook: the kernel timeline of the calling thread.  gs_debug_timeline(1) arms it and forgets
+ * earlier records: every kernel (and record memset) the library launches from this thread from then on is
+ * bracketed by two HIP events on its launch stream; gs_debug_timeline(0) disarms.  gs_debug_timeline_read
+ * waits for the recorded events and returns, in launch order, the kernel names (name_bytes per entry,
+ * NUL-terminated, the kernel expression as written at the launch site) and durations in milliseconds;
+ * *count = the number of records held (may exceed capacity).  A record costs ~5 us of stream time: use it
+ * on an instrumented pass, never inside a timed region (bench.py: `kernels`). */
+int gs_debug_timeline(int enable);
+int gs_debug_timeline_read(int capacity, char *names, int name_bytes, float *ms, int *count);
+
 /* Test hook: the per-row (16-lane) nine-value reduction of the compositing backward (a transposing
  * DPP butterfly, no LDS).  in [blocks, 9, 64]  ->  out[blocks, 4, 9] = sums over each 16-lane row. */
 int gs_debug_row_reduce9(int blocks, const float *in, float *out, gs_stream_t stream);
+
+/* Test hook: the nine-value group reduction as the compositing backward runs it.  mfma = 0: the DPP
+ * butterfly above, a group is a 16-lane row; mfma = 1: nine v_mfma_f32_16x16x4_f32 with one-hot B columns
+ * + three additions, a group is the sixteen lanes {4 g + q + 16 k : q, k < 4} (one quad of each row).
+ * in [blocks, 9, 64]  ->  out[blocks, 4, 9] = the nine sums of each group.
+ * gs_debug_backward_uses_mfma: which of the two the library's k_rasterize_backward was built with. */
+int gs_debug_group_reduce9(int blocks, const float *in, float *out, int mfma, gs_stream_t stream);
+int gs_debug_backward_uses_mfma(void);
 
 
 /* ---------------------------------------------------------------------------------------------

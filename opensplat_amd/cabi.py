@@ -17,6 +17,7 @@ from . import _build
 
 GS_TILE = 16
 GS_SPLAT_DWORDS = 12
+GS_ABI_VERSION = 400   # include/gsplat_hip.h
 GS_FLAG_FAST_EXP = 1
 GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
@@ -32,7 +33,7 @@ SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
     "gs_bin_sort", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
-    "gs_debug_row_reduce9", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
+    "gs_debug_timeline", "gs_debug_timeline_read", "gs_debug_row_reduce9", "gs_debug_group_reduce9", "gs_debug_backward_uses_mfma", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
 ]
 # every symbol include/gsplat_train.h declares
@@ -62,6 +63,11 @@ def lib() -> C.CDLL:
             raise ImportError("libgsplat_hip.so is not built: run `python -m opensplat_amd._build` "
                               "(no CPU fallback exists)")
         l = C.CDLL(path)
+        # the binding below is written against include/gsplat_hip.h at GS_ABI_VERSION: a library built from
+        # another header would be called through shifted arguments
+        if l.gs_version() != GS_ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding needs %d: rebuild with "
+                              "`python -m opensplat_amd._build`" % (path, l.gs_version(), GS_ABI_VERSION))
         l.gs_strerror.restype = C.c_char_p
         l.gs_last_hip_error.restype = C.c_char_p
         l.gs_bin_workspace_bytes.restype = C.c_size_t
@@ -365,6 +371,44 @@ def debug_row_reduce9(x):
     y = torch.empty((blocks, 4, 9), device=x.device, dtype=torch.float32)
     _check(lib().gs_debug_row_reduce9(C.c_int(blocks), _p(x), _p(y), _stream()), "gs_debug_row_reduce9")
     return y
+
+
+def debug_group_reduce9(x, mfma=True):
+    """x [blocks, 9, 64] -> [blocks, 4, 9]: the backward kernel's nine-value group reduction; mfma: on the
+    matrix pipe (group g = lanes {4 g + q + 16 k}), else the DPP butterfly (group = 16-lane row)."""
+    blocks = x.shape[0]
+    y = torch.empty((blocks, 4, 9), device=x.device, dtype=torch.float32)
+    _check(lib().gs_debug_group_reduce9(C.c_int(blocks), _p(x), _p(y), C.c_int(1 if mfma else 0), _stream()),
+           "gs_debug_group_reduce9")
+    return y
+
+
+def timeline(enable: bool) -> None:
+    """Arm / disarm the calling thread's kernel timeline (gs_debug_timeline)."""
+    _check(lib().gs_debug_timeline(C.c_int(1 if enable else 0)), "gs_debug_timeline")
+
+
+def timeline_read(capacity: int = 4096):
+    """-> [(kernel name, ms)] in launch order since the timeline was armed (waits for the events)."""
+    nb = 96
+    names = C.create_string_buffer(capacity * nb)
+    ms = (C.c_float * capacity)()
+    count = C.c_int(0)
+    _check(lib().gs_debug_timeline_read(C.c_int(capacity), names, C.c_int(nb), ms, C.byref(count)),
+           "gs_debug_timeline_read")
+    out = []
+    for i in range(min(count.value, capacity)):
+        raw = names.raw[i * nb:(i + 1) * nb].split(b"\0", 1)[0].decode()
+        out.append((raw, float(ms[i])))
+    return out
+
+
+def kernel_short_name(expr: str) -> str:
+    """'(gs::k_bucket_sort_wave<8, 512>)' -> 'k_bucket_sort_wave<8,512>'."""
+    e = expr.strip()
+    while e.startswith("(") and e.endswith(")"):
+        e = e[1:-1].strip()
+    return e.replace("gs::", "").replace(" ", "")
 
 
 def time_next_kernel(ev_start, ev_stop):

@@ -123,7 +123,7 @@ extern "C" int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t s
     if (chunks == 0) return GS_OK;
     const int64_t blocks = (chunks + 255) / 256;
     if (blocks > 0x7fffffffLL) return GS_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "gs_device.h"
 
 namespace gs {
@@ -41,6 +43,70 @@ TraceRange::TraceRange(const char *name) : on_(roctx_ready()) { if (on_) g_push(
 TraceRange::~TraceRange() { if (on_) g_pop(); }
 }  // namespace gs
 
+// ---- kernel timeline (GS_LAUNCH, gs_device.h) -------------------------------------------------------
+namespace gs {
+namespace {
+struct TimelineEntry {
+    const char *name;
+    hipEvent_t a, b;
+};
+struct Timeline {
+    bool armed = false;
+    std::vector<TimelineEntry> entries;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t pending = nullptr;
+    hipEvent_t take() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return e;
+    }
+    void clear() {
+        for (auto &e : entries) { if (e.a) pool.push_back(e.a); if (e.b) pool.push_back(e.b); }
+        entries.clear();
+        if (pending) { pool.push_back(pending); pending = nullptr; }
+    }
+};
+thread_local Timeline g_timeline;
+}  // namespace
+void timeline_before(hipStream_t s) {
+    Timeline &t = g_timeline;
+    if (!t.armed) return;
+    if (!t.pending) t.pending = t.take();
+    if (t.pending) (void)hipEventRecord(t.pending, s);
+}
+void timeline_after(const char *name, hipStream_t s) {
+    Timeline &t = g_timeline;
+    if (!t.armed || !t.pending) return;
+    hipEvent_t b = t.take();
+    if (!b) return;
+    (void)hipEventRecord(b, s);
+    t.entries.push_back({name, t.pending, b});
+    t.pending = nullptr;
+}
+}  // namespace gs
+
+extern "C" int gs_debug_timeline(int enable) {
+    gs::g_timeline.clear();
+    gs::g_timeline.armed = enable != 0;
+    return GS_OK;
+}
+
+extern "C" int gs_debug_timeline_read(int capacity, char *names, int name_bytes, float *ms, int *count) {
+    if (capacity < 0 || name_bytes < 8 || !count || (capacity > 0 && (!names || !ms))) return GS_ERR_INVALID_ARGUMENT;
+    gs::Timeline &t = gs::g_timeline;
+    const int n = (int)t.entries.size();
+    *count = n;
+    for (int i = 0; i < n && i < capacity; i++) {
+        GS_HIP_CHECK(hipEventSynchronize(t.entries[i].b));
+        float v = 0.0f;
+        GS_HIP_CHECK(hipEventElapsedTime(&v, t.entries[i].a, t.entries[i].b));
+        ms[i] = v;
+        snprintf(names + (size_t)i * name_bytes, (size_t)name_bytes, "%s", t.entries[i].name);
+    }
+    return GS_OK;
+}
+
 extern "C" const char *gs_strerror(int status) {
     switch (status) {
     case GS_OK: return "ok";
@@ -55,4 +121,4 @@ extern "C" const char *gs_strerror(int status) {
 
 extern "C" const char *gs_last_hip_error(void) { return gs::g_hip_err; }
 
-extern "C" int gs_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int gs_version(void) { return GS_ABI_VERSION; }

@@ -936,17 +936,28 @@ struct BinLayout {
     size_t counters, total_dev, wg_base, keys, total;
 };
 // What gs_bin_scan remembers (on the host, per workspace address) so that gs_bin_sort can tell that the
-// workspace it is handed holds the scan's leftovers — per-workgroup offsets, row tables — for the same
+// workspace it is handed holds the scan's leftovers — the per-workgroup offsets — for the same
 // problem; a mismatch is GS_ERR_WORKSPACE instead of silently corrupt lists.
 struct BinStamp {
     int N, W, H, blocks;
+    uint64_t seq = 0;   // order of stamping (eviction)
 };
 static std::mutex g_stamp_mutex;
 static std::unordered_map<const void *, BinStamp> g_stamps;
-static void stamp_workspace(const void *ws, const BinStamp &st) {
+static uint64_t g_stamp_clock = 0;
+static void stamp_workspace(const void *ws, BinStamp st) {
     std::lock_guard<std::mutex> lock(g_stamp_mutex);
-    if (g_stamps.size() > 256) g_stamps.clear();   // (workspaces come and go with the allocator)
+    st.seq = ++g_stamp_clock;
     g_stamps[ws] = st;
+    // workspaces come and go with the allocator: the OLDEST stamps leave, one at a time — a wholesale
+    // clear could drop the stamp another thread (or GPU) set between its scan and its sort;
+    // 4096 live (scan, sort) pairs in flight at once is far beyond any caller
+    while (g_stamps.size() > 4096) {
+        auto oldest = g_stamps.begin();
+        for (auto it = g_stamps.begin(); it != g_stamps.end(); ++it)
+            if (it->second.seq < oldest->second.seq) oldest = it;
+        g_stamps.erase(oldest);
+    }
 }
 static bool workspace_matches(const void *ws, const BinStamp &st) {
     std::lock_guard<std::mutex> lock(g_stamp_mutex);
@@ -979,7 +990,7 @@ extern "C" int gs_pack_splats(int W, int H, int N, const float *xys, const int32
     if (!xys || !radii || !conics || !colors || !opacities || !packed || !tiles_hit)
         return GS_ERR_INVALID_ARGUMENT;
     if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_pack_splats, dim3((N + 255) / 256), dim3(256), 0,
+    GS_LAUNCH(gs::k_pack_splats, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, W, H, N, xys, radii, conics, colors, opacities,
                        cov2d, reinterpret_cast<float4 *>(packed), tiles_hit, flags);
     GS_LAUNCH_CHECK();
@@ -1008,7 +1019,9 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
     char *base = static_cast<char *>(workspace);
     int32_t *counts = reinterpret_cast<int32_t *>(base + L.counters);
     int32_t *total_dev = reinterpret_cast<int32_t *>(base + L.total_dev);
+    gs::timeline_before(s);
     GS_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)tiles, s));
+    gs::timeline_after("memset(tile counters)", s);
     if (N > 0) {
         const size_t lds = sizeof(int32_t) * (size_t)tiles;
         if (lds <= gs::kMaxTileLds) {
@@ -1016,16 +1029,16 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
             const int blocks = gs::persistent_blocks(N);
-            hipLaunchKernelGGL(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
+            GS_LAUNCH(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
                                reinterpret_cast<const float4 *>(packed), counts,
                                reinterpret_cast<int32_t *>(base + L.wg_base));
         } else {
-            hipLaunchKernelGGL(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
+            GS_LAUNCH(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
                                tiles_x, reinterpret_cast<const float4 *>(packed), counts);
         }
         GS_LAUNCH_CHECK();
     }
-    gs::stamp_workspace(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N)});
+    gs::stamp_workspace(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N), 0});
     {
         const size_t lds = sizeof(int32_t) * ((size_t)tiles + tiles / 32 + 1);
         const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
@@ -1034,10 +1047,10 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
         if (use_lds)
-            hipLaunchKernelGGL(gs::k_scan_tiles_fast, dim3(1), dim3(1024), lds, s, tiles, counts,
+            GS_LAUNCH(gs::k_scan_tiles_fast, dim3(1), dim3(1024), lds, s, tiles, counts,
                                reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
         else
-            hipLaunchKernelGGL(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, 0, counts,
+            GS_LAUNCH(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, 0, counts,
                                reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
     }
     GS_LAUNCH_CHECK();
@@ -1053,7 +1066,7 @@ extern "C" int gs_block_masks(int W, int H, const int32_t *gaussian_ids_sorted,
     if (!tile_bins || !gaussian_ids_sorted || !packed || !block_masks) return GS_ERR_INVALID_ARGUMENT;
     if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
-    hipLaunchKernelGGL(gs::k_block_masks, dim3(tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream,
+    GS_LAUNCH(gs::k_block_masks, dim3(tiles_x * tiles_y), dim3(64), 0, (hipStream_t)stream,
                        tiles_x, reinterpret_cast<const int2 *>(tile_bins), gaussian_ids_sorted,
                        reinterpret_cast<const float4 *>(packed), block_masks);
     GS_LAUNCH_CHECK();
@@ -1077,8 +1090,8 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     const int tiles = tiles_x * tiles_y;
     const gs::BinLayout L = gs::bin_layout(N, capacity, W, H);
     if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
-    // the scan's per-workgroup offsets and row tables must be the ones of THIS problem
-    if (!gs::workspace_matches(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N)}))
+    // the scan's per-workgroup offsets must be the ones of THIS problem
+    if (!gs::workspace_matches(workspace, gs::BinStamp{N, W, H, gs::persistent_blocks(N), 0}))
         return GS_ERR_WORKSPACE;
     char *base = static_cast<char *>(workspace);
     int32_t *fill = reinterpret_cast<int32_t *>(base + L.counters);
@@ -1090,12 +1103,12 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)gs::kMaxTileLds));
         const int blocks = gs::persistent_blocks(N);
-        hipLaunchKernelGGL(gs::k_scatter, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x, capacity,
+        GS_LAUNCH(gs::k_scatter, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x, capacity,
                            reinterpret_cast<const float4 *>(packed), depths, bins,
                            reinterpret_cast<const int32_t *>(base + L.wg_base), keys);
     } else {
         GS_HIP_CHECK(hipMemsetAsync(fill, 0, sizeof(int32_t) * (size_t)tiles, s));
-        hipLaunchKernelGGL(gs::k_scatter_global, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
+        GS_LAUNCH(gs::k_scatter_global, dim3((N + 255) / 256), dim3(256), 0, s, N, tiles_x,
                            capacity, reinterpret_cast<const float4 *>(packed), depths, bins, fill,
                            keys);
     }
@@ -1118,13 +1131,13 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     const bool no_long = have_stats && list_stats[1] <= 900;
     const bool only_mid = no_long && !only_short && (int64_t)list_stats[0] > 300 * (int64_t)tiles;
     if (only_mid) {
-        hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
+        GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
                            capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
         return GS_OK;
     }
     if (!only_short) {
-        hipLaunchKernelGGL((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+        GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
                            capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
@@ -1134,12 +1147,12 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
         GS_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
+        GS_LAUNCH((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
                            CAP, capacity, bins, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
-    hipLaunchKernelGGL((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+    GS_LAUNCH((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
                        1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     GS_LAUNCH_CHECK();
     return GS_OK;

@@ -86,7 +86,7 @@ extern "C" int gs_compat_tiles_hit(int N, const float *xys, const int32_t *radii
     if (N < 0 || tiles_x <= 0 || tiles_y <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (N == 0) return GS_OK;
     if (!xys || !radii || !num_tiles_hit) return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_compat_tiles_hit, dim3((N + 255) / 256), dim3(256), 0,
+    GS_LAUNCH(gs::k_compat_tiles_hit, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, N, reinterpret_cast<const float2 *>(xys), radii, tiles_x,
                        tiles_y, num_tiles_hit);
     GS_LAUNCH_CHECK();
@@ -101,7 +101,7 @@ extern "C" int gs_compat_map_intersects(int N, const float *xys, const float *de
     if (N == 0) return GS_OK;
     if (!xys || !depths || !radii || !cum_tiles_hit || !isect_ids || !gaussian_ids)
         return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_compat_map_intersects, dim3((N + 255) / 256), dim3(256), 0,
+    GS_LAUNCH(gs::k_compat_map_intersects, dim3((N + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, N, reinterpret_cast<const float2 *>(xys), depths, radii,
                        cum_tiles_hit, tiles_x, tiles_y, isect_ids, gaussian_ids);
     GS_LAUNCH_CHECK();
@@ -114,7 +114,7 @@ extern "C" int gs_compat_tile_bin_edges(int64_t num_intersects, const int64_t *i
     if (num_intersects < 0 || tile_bins_rows < 0) return GS_ERR_INVALID_ARGUMENT;
     if (num_intersects == 0) return GS_OK;
     if (!isect_ids_sorted || !tile_bins) return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_compat_tile_bin_edges, dim3((unsigned)((num_intersects + 255) / 256)),
+    GS_LAUNCH(gs::k_compat_tile_bin_edges, dim3((unsigned)((num_intersects + 255) / 256)),
                        dim3(256), 0, (hipStream_t)stream, num_intersects, tile_bins_rows,
                        isect_ids_sorted, reinterpret_cast<int2 *>(tile_bins));
     GS_LAUNCH_CHECK();

@@ -274,7 +274,7 @@ extern "C" int gs_densify_stats(int N, const float *xys_grad, const int32_t *rad
     if (N == 0) return GS_OK;
     if (!xys_grad || !radii || !xys_grad_norm || !vis_counts || !max_2d_size)
         return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_densify_stats, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    GS_LAUNCH(gs::k_densify_stats, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        N, reinterpret_cast<const float2 *>(xys_grad), radii, max_side, first,
                        xys_grad_norm, vis_counts, max_2d_size);
     GS_LAUNCH_CHECK();
@@ -300,15 +300,15 @@ extern "C" int gs_densify_plan(int N, const GsDensifyConfig *cfg, const float *x
     if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
     char *ws = (char *)workspace;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_densify_flags, dim3(L.nb), dim3(kDBlock), 0, s, N, *cfg, xys_grad_norm,
+    GS_LAUNCH(k_densify_flags, dim3(L.nb), dim3(kDBlock), 0, s, N, *cfg, xys_grad_norm,
                        vis_counts, max_2d_size, log_scales, opacity_logits,
                        (uint8_t *)(ws + L.flags_off), (int32_t *)(ws + L.sums_off));
     GS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_densify_scan, dim3(1), dim3(256), 0, s, N, L.nb,
+    GS_LAUNCH(k_densify_scan, dim3(1), dim3(256), 0, s, N, L.nb,
                        (const int32_t *)(ws + L.sums_off), (int32_t *)(ws + L.offs_off),
                        (int32_t *)(ws + L.totals_off), counts_host);
     GS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_densify_map, dim3(L.nb), dim3(kDBlock), 0, s, N,
+    GS_LAUNCH(k_densify_map, dim3(L.nb), dim3(kDBlock), 0, s, N,
                        (const uint8_t *)(ws + L.flags_off), (const int32_t *)(ws + L.offs_off),
                        (const int32_t *)(ws + L.totals_off), (int32_t *)(ws + L.map_p_off),
                        (int32_t *)(ws + L.map_m_off), (int32_t *)(ws + L.sample_off));
@@ -348,13 +348,13 @@ extern "C" int gs_densify_apply(int N, int K, int new_N, const float *samples,
             const int64_t total = (int64_t)new_N * lens[t];
             const int64_t want = (total + 255) / 256;
             const int blocks = (int)(want < 16384 ? want : 16384);
-            hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, s, total, lens[t], srcs[t],
+            GS_LAUNCH(k_gather_rows, dim3(blocks), dim3(256), 0, s, total, lens[t], srcs[t],
                                set == 0 ? map_p : map_m, dsts[t]);
             GS_LAUNCH_CHECK();
         }
     }
     if (samples) {
-        hipLaunchKernelGGL(k_split_fixup, dim3((new_N + 255) / 256), dim3(256), 0, s, new_N, map_p,
+        GS_LAUNCH(k_split_fixup, dim3((new_N + 255) / 256), dim3(256), 0, s, new_N, map_p,
                            sample_row, samples, src[0].means, src[0].log_scales, src[0].quats,
                            dst[0].means, dst[0].log_scales);
         GS_LAUNCH_CHECK();
@@ -368,7 +368,7 @@ extern "C" int gs_reset_opacity(int N, float reset_value, float *opacity_logits,
     if (N == 0) return GS_OK;
     if (!opacity_logits) return GS_ERR_INVALID_ARGUMENT;
     const float max_logit = logf(reset_value / (1.0f - reset_value));  // torch::logit
-    hipLaunchKernelGGL(gs::k_reset_opacity, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    GS_LAUNCH(gs::k_reset_opacity, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        N, max_logit, opacity_logits, exp_avg, exp_avg_sq);
     GS_LAUNCH_CHECK();
     return GS_OK;

@@ -46,6 +46,20 @@ private:
 
 #define GS_LAUNCH_CHECK() GS_HIP_CHECK(hipGetLastError())
 
+// Every kernel launch of the library goes through GS_LAUNCH: when the calling thread has armed the
+// kernel timeline (gs_debug_timeline, include/gsplat_hip.h) a HIP event is recorded on the launch stream
+// right before and right after the launch, under the kernel's name — bench.py's per-kernel durations come
+// from its OWN run that way (an instrumented pass outside the timed region; a record costs ~5 us of stream
+// time).  Unarmed (always, outside that pass) the cost is one thread-local load and a branch.
+void timeline_before(hipStream_t s);
+void timeline_after(const char *name, hipStream_t s);
+#define GS_LAUNCH(kernel, grid, block, lds, stream, ...)                               \
+    do {                                                                               \
+        ::gs::timeline_before(stream);                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);             \
+        ::gs::timeline_after(#kernel, stream);                                         \
+    } while (0)
+
 // Small read-only arguments (background colour, camera position) may be handed over as host OR
 // device memory: a device tensor is then read by the kernel itself instead of being copied to the
 // host first (which would synchronise the stream).

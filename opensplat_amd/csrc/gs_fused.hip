@@ -471,7 +471,7 @@ static int launch_sh_backward_cameras(int N, int nb, int n_cams, const float *me
                                       hipStream_t s) {
     constexpr int BLK = ShSplit<K>::kBlock;
     const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
-    hipLaunchKernelGGL(k_sh_backward_cameras<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+    GS_LAUNCH(k_sh_backward_cameras<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
                        n_cams, means, cam_pos, cam_stride, v_colors, v_stride, v_dc, v_rest, flags);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -487,7 +487,7 @@ static int launch_gaussian_forward(const CamArgs &cam, const float *vm_dev, cons
     constexpr int BLK = ShSplit<K>::kBlock;
     const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
     const bool dev = on_device(cp);
-    hipLaunchKernelGGL(k_gaussian_forward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
+    GS_LAUNCH(k_gaussian_forward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
                        pm_dev, N, nb, means, scales, quats, opacities, dc, rest, dev ? 0.f : cp[0],
                        dev ? 0.f : cp[1], dev ? 0.f : cp[2], dev ? cp : nullptr,
                        reinterpret_cast<float4 *>(packed), depths, radii, rgb_raw, xys, flags);
@@ -506,7 +506,7 @@ static int launch_gaussian_backward(const CamArgs &cam, const float *vm_dev, con
     constexpr int BLK = ShSplit<K>::kBlock;
     const size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
     const bool dev = on_device(cp);
-    hipLaunchKernelGGL(k_gaussian_backward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
+    GS_LAUNCH(k_gaussian_backward<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, cam, vm_dev,
                        pm_dev, N, nb, means, scales, quats, opacities, dev ? 0.f : cp[0],
                        dev ? 0.f : cp[1], dev ? 0.f : cp[2], dev ? cp : nullptr, radii, rgb_raw,
                        reinterpret_cast<float4 *>(records), v_means, v_scales, v_quats, v_opacity, v_dc,
@@ -549,7 +549,7 @@ extern "C" int gs_gaussian_forward(const GsCamera *cam, const float *viewmat_dev
     case 9: GS_FWD(9);
     case 16: {  // SH forward and projection + record as one launch of two kinds of workgroups
         const bool dev = gs::on_device(cam_pos);
-        hipLaunchKernelGGL(gs::k_sh_project_pack16, dim3(5 * ((N + 255) / 256)), dim3(256), 0, s, a,
+        GS_LAUNCH(gs::k_sh_project_pack16, dim3(5 * ((N + 255) / 256)), dim3(256), 0, s, a,
                            viewmat_dev, projmat_dev, N, nb, means, scales, quats, opacities, features_dc,
                            features_rest, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
                            dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr,

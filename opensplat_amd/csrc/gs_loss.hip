@@ -423,21 +423,21 @@ extern "C" int gs_main_loss(int W, int H, const float *rendered, const float *gt
         if (!make_window(win)) return GS_ERR_UNSUPPORTED;
         nparts = L.tiles_x * L.tiles_y;
         const dim3 grid(nparts);
-        hipLaunchKernelGGL(k_ssim_maps, grid, dim3(kLossThreads), 0, s, W, H, L.tiles_x, win,
+        GS_LAUNCH(k_ssim_maps, grid, dim3(kLossThreads), 0, s, W, H, L.tiles_x, win,
                            rendered, gt, maps, partial);
         GS_LAUNCH_CHECK();
         if (v_rendered) {
-            hipLaunchKernelGGL(k_ssim_grad, grid, dim3(kLossThreads), 0, s, W, H, L.tiles_x, win,
+            GS_LAUNCH(k_ssim_grad, grid, dim3(kLossThreads), 0, s, W, H, L.tiles_x, win,
                                rendered, gt, maps, c_l1, c_ssim, v_rendered);
             GS_LAUNCH_CHECK();
         }
     } else {
         nparts = 1024;
-        hipLaunchKernelGGL(k_l1_loss, dim3(nparts), dim3(kLossThreads), 0, s,
+        GS_LAUNCH(k_l1_loss, dim3(nparts), dim3(kLossThreads), 0, s,
                            (int64_t)3 * W * H, rendered, gt, c_l1, v_rendered, partial);
         GS_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(kLossThreads), 0, s, nparts, partial, inv,
+    GS_LAUNCH(k_loss_finalize, dim3(1), dim3(kLossThreads), 0, s, nparts, partial, inv,
                        ssim_weight, ssim_weight != 0.0f ? 1 : 0, loss);
     GS_LAUNCH_CHECK();
     return GS_OK;

@@ -118,7 +118,7 @@ extern "C" int gs_project_forward(const GsCamera *cam, const float *viewmat_dev,
     if (cam->img_width > 65535 || cam->img_height > 65535) return GS_ERR_UNSUPPORTED;
     gs::CamArgs a = gs::make_cam(cam);
     int blocks = (N + 255) / 256;
-    hipLaunchKernelGGL(gs::k_project_forward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
+    GS_LAUNCH(gs::k_project_forward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
                        viewmat_dev, projmat_dev, N, means, scales, quats, xys, depths, radii, conics, num_tiles_hit, cov3d,
                        cov2d);
     GS_LAUNCH_CHECK();
@@ -138,7 +138,7 @@ extern "C" int gs_project_backward(const GsCamera *cam, const float *viewmat_dev
         return GS_ERR_INVALID_ARGUMENT;
     gs::CamArgs a = gs::make_cam(cam);
     int blocks = (N + 255) / 256;
-    hipLaunchKernelGGL(gs::k_project_backward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
+    GS_LAUNCH(gs::k_project_backward, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a,
                        viewmat_dev, projmat_dev, N, means, scales, quats, radii, v_xy, v_depth, v_conic, v_means, v_scales,
                        v_quats);
     GS_LAUNCH_CHECK();

@@ -14,8 +14,10 @@
 // The round-1 kernels gave one wave a whole 16x16 tile and let all 64 lanes evaluate every entry of
 // the tile's list; at BASELINE config 2 (footprints of ~30 pixels) only ~16 of 64 lanes were live
 // in an exponential pass.  Here a wave owns 2 x 2 BLOCKS of pixels (WaveGeom: 4x4
-// blocks with one pixel per lane in the forward, 4x8 blocks with two pixels per lane in the
-// backward), each block belongs to one 16-lane group (= one DPP row), and each group walks ITS OWN
+// blocks with one pixel per lane in the forward; 8x8 blocks with FOUR pixels per lane in the backward,
+// one wave per tile — 4x8 / 4x4 blocks with two / one pixel per lane on frames that do not fill the chip
+// and for tiles with outlying lists), each block belongs to one 16-lane group (forward: a DPP row;
+// backward: one quad out of each DPP row, the lanes a v_mfma_f32_16x16x4_f32 sums), and each group walks ITS OWN
 // list: the entries of the staged chunk whose (tightened) rectangle touches that block.  The four
 // groups execute one instruction stream on four different Gaussians:
 //   * per chunk of 64 list entries (staged by the wave itself: lane t gathers entry t, the next
@@ -39,11 +41,13 @@
 //     branches; saturation (once per pixel and frame) is a wave-uniform rare path;
 //   * backward: the exponential is v_exp_f32, with the exact fp64 evaluation re-run only for
 //     lanes whose alpha lies within 2.5e-6 (relative) of the 1/255 threshold, so the decision
-//     equals the forward's; 1/(1-alpha) is v_rcp_f32 + one Newton step; the running colour
+//     equals the forward's (decided on vis against per-entry thresholds staged once per chunk, SRecB);
+//     1/(1-alpha) is v_rcp_f32 alone (T is a running product either way); the running colour
 //     buffer is tracked as its dot product with the pixel's cotangent; the moments sum(u),
 //     sum(u dy), sum(u dy^2) are accumulated over a lane's pixels (they share xCam);
-//   * the nine partial sums are reduced over the group's 16 lanes IN REGISTERS (row_reduce9: a
-//     transposing DPP butterfly), added to per-entry accumulators in LDS (ds_add_f32, nine banks),
+//   * the nine partial sums are reduced over the group's 16 lanes on the MATRIX pipe (mfma_reduce9: nine
+//     v_mfma_f32_16x16x4_f32 with one-hot B columns + three additions; the DPP butterfly row_reduce9 of
+//     rounds 2-3 stays selectable, GS_BWD_MFMA=0), added to per-entry accumulators in LDS (ds_add_f32),
 //     converted from moments to (v_x, v_y, v_A, v_B, v_C) once per entry and flushed once per
 //     chunk with one atomic lane per (entry, component): a Gaussian costs one global atomic
 //     line-request per wave it contributes to (its nine lanes hit ONE 64-byte record).
@@ -381,6 +385,56 @@ __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float
     return (bit1 ? u : t) + dpp_f<0x4E>(bit1 ? t : u);            // quad_perm [2,3,0,1]
 }
 
+// The same nine sums on the MATRIX pipe (GS_BWD_MFMA): v_mfma_f32_16x16x4_f32 computes
+// D[i][j] += sum_k A[i][k] B[k][j] with A taken from lane (i = l & 15, k = l >> 4) and B from lane
+// (k = l >> 4, j = l & 15); D[4 (l >> 4) + r][l & 15] lands in register r of lane l.  With A = one of
+// the nine per-lane values and B = the one-hot column of its component, nine accumulating
+// instructions leave in D[i][c] the sum of component c over the four lanes {i, i + 16, i + 32, i + 48},
+// and adding a lane's four result registers sums the rows 4 g .. 4 g + 3: lane (g = l >> 4, c = l & 15)
+// ends with the total of component c over the SIXTEEN lanes {4 g + q + 16 k : q, k < 4}.  So a "group" of
+// this variant is not a DPP row but one quad out of each row (mfma_group / mfma_lane_in_group), and the
+// reduction costs three VALU additions instead of twenty-one DPP operations; the matrix pipe is
+// otherwise idle in this kernel and runs beside the other waves' VALU work (exact fp32: each product
+// is a value times one or zero, the four-term sums are fmaf chains).  A non-finite partial sum would
+// spread to the other components of its (group, entry) through 0 * inf — the DPP butterfly keeps it in
+// its own component; both are garbage-in cases (finite inputs give finite sums).
+#ifndef GS_BWD_MFMA_CHAINS
+#define GS_BWD_MFMA_CHAINS 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int mfma_group(int lane) { return (lane >> 2) & 3; }
+__device__ __forceinline__ int mfma_lane_in_group(int lane) { return (lane & 3) | ((lane >> 4) << 2); }
+__device__ __forceinline__ float mfma_reduce9(float v0, float v1, float v2, float v3, float v4,
+                                              float v5, float v6, float v7, float v8,
+                                              const float (&oh)[9]) {
+#if GS_BWD_MFMA_CHAINS == 2
+    // two accumulators (even / odd components: disjoint columns): half the dependent-latency chain
+    // (nine x 40 cycles), four more additions
+    f32x4_t da = {0.0f, 0.0f, 0.0f, 0.0f}, db = {0.0f, 0.0f, 0.0f, 0.0f};
+    da = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, oh[0], da, 0, 0, 0);
+    db = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, oh[1], db, 0, 0, 0);
+    da = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, oh[2], da, 0, 0, 0);
+    db = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, oh[3], db, 0, 0, 0);
+    da = __builtin_amdgcn_mfma_f32_16x16x4f32(v4, oh[4], da, 0, 0, 0);
+    db = __builtin_amdgcn_mfma_f32_16x16x4f32(v5, oh[5], db, 0, 0, 0);
+    da = __builtin_amdgcn_mfma_f32_16x16x4f32(v6, oh[6], da, 0, 0, 0);
+    db = __builtin_amdgcn_mfma_f32_16x16x4f32(v7, oh[7], db, 0, 0, 0);
+    da = __builtin_amdgcn_mfma_f32_16x16x4f32(v8, oh[8], da, 0, 0, 0);
+    return ((da[0] + db[0]) + (da[1] + db[1])) + ((da[2] + db[2]) + (da[3] + db[3]));
+#endif
+    f32x4_t d = {0.0f, 0.0f, 0.0f, 0.0f};
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, oh[0], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, oh[1], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, oh[2], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, oh[3], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v4, oh[4], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v5, oh[5], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v6, oh[6], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v7, oh[7], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v8, oh[8], d, 0, 0, 0);
+    return (d[0] + d[1]) + (d[2] + d[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward.  LDS per wave: staged records 3.1 KB, ids 256 B, per-entry accumulators 9 x 65 floats:
 // 5.7 KB.
@@ -397,6 +451,11 @@ constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_
 // more live registers; 0 measured faster with the mask-driven staging: 345 -> 336 us at C2)
 #ifndef GS_BWD_PREFETCH
 #define GS_BWD_PREFETCH 0
+#endif
+// 1: the per-step nine-value reduction runs on the matrix pipe (mfma_reduce9) and a group is one quad of
+// each DPP row; 0: the DPP butterfly (row_reduce9), a group is a DPP row.
+#ifndef GS_BWD_MFMA
+#define GS_BWD_MFMA 1
 #endif
 // One wave of the backward: the pixels [wx0, wx0 + WW) x [wy0, wy0 + WH) of `tile` (WaveGeom<PX>).  The
 // LDS arrays belong to the calling kernel (one wave per workgroup).
@@ -415,9 +474,23 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
+#if GS_BWD_MFMA
+    const int grp = mfma_group(lane), li = mfma_lane_in_group(lane);
+    // which of the nine sums mfma_reduce9 leaves in this lane, and for which group (rgsh: that group's
+    // byte of the packed slot word) — the lane's own pixels belong to group `grp`
+    const int rcomp = (lane & 15) < kAcc ? (lane & 15) : -1;
+    const uint32_t rgsh = 8u * (uint32_t)(lane >> 4);
+    float onehot[kAcc];
+#pragma unroll
+    for (int c = 0; c < kAcc; c++) {
+        onehot[c] = (lane & 15) == c ? 1.0f : 0.0f;
+        asm volatile("" : "+v"(onehot[c]));   // nine live registers, not nine compares per step
+    }
+#else
     const int grp = lane >> 4, li = lane & 15;
     const bool odd = (lane & 1) != 0, bit1 = (lane & 2) != 0;
     const int rcomp = reduce9_component(li);   // which of the nine sums row_reduce9 leaves in this lane
+#endif
     const int fj = (lane * 7282) >> 16;        // flush: lane = 9 * fj + fcomp (lane 63: fj = 7, no work)
     const int fcomp = lane == 63 ? kAcc : lane - 9 * fj;
     const uint32_t gsh = 8u * (uint32_t)grp;
@@ -455,20 +528,27 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
         D[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
         gl = max(gl, last[p]);
     }
-    // last contributor of each block (one DPP row) and of the wave
+    // last contributor of each block (one group of lanes) and of the wave
     gl = max(gl, dpp_i<0xB1>(gl));
     gl = max(gl, dpp_i<0x4E>(gl));
+#if GS_BWD_MFMA
+    // a group = quad g of each of the four DPP rows
+#define GS_GL(g)                                                                                        \
+    max(max(__builtin_amdgcn_readlane(gl, 4 * (g)), __builtin_amdgcn_readlane(gl, 4 * (g) + 16)),      \
+        max(__builtin_amdgcn_readlane(gl, 4 * (g) + 32), __builtin_amdgcn_readlane(gl, 4 * (g) + 48)))
+    const int gl0 = GS_GL(0), gl1 = GS_GL(1), gl2 = GS_GL(2), gl3 = GS_GL(3);
+#undef GS_GL
+#else
     gl = max(gl, dpp_i<0x141>(gl));
     gl = max(gl, dpp_i<0x140>(gl));
     const int gl0 = __builtin_amdgcn_readlane(gl, 0), gl1 = __builtin_amdgcn_readlane(gl, 16);
     const int gl2 = __builtin_amdgcn_readlane(gl, 32), gl3 = __builtin_amdgcn_readlane(gl, 48);
+#endif
     const int wave_last = max(max(gl0, gl1), max(gl2, gl3));
     const int2 range = bins[tile];
     if (wave_last < range.x) return;  // (also covers empty tiles / no contributors)
 
     if (lane == 0) stage_sentinel(&stage[kChunk]);
-    stage[lane].p0 = make_float4(0.f, 0.f, 0.f, 0.f);   // finite until staged (see the flush)
-    stage[lane].p1 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < kAcc; i++) acc[i * kAccStride + lane] = 0.0f;
 
@@ -641,10 +721,18 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 if (anym == 0ull) continue;
                 // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
                 const float ux = su * dx;
+#if GS_BWD_MFMA
+                const float r = mfma_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, onehot);
+                const int er = (int)((ep >> rgsh) & 0xFFu);   // the entry of the group this lane reports
+                if (rcomp >= 0 && r != 0.0f && er < kChunk)  // (a group without work has nothing to add)
+                    __hip_atomic_fetch_add(&acc[rcomp * kAccStride + er], r, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                 const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
                 if (rcomp >= 0 && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
                     __hip_atomic_fetch_add(&acc[rcomp * kAccStride + e], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                 flushed_any = true;
             }
         };
@@ -653,9 +741,10 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
         // ---- flush: moments -> gradient components (once per entry), then one atomic lane per
         //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
         wave_sync();
-        // (a slot whose entry was not staged this chunk has zero sums and holds a finite record — an
-        // older one, or the zeros written at the start: 0 * finite = 0, nothing is flushed for it)
-        if (hi - lane >= range.x) {
+        // (only slots staged THIS chunk: an unstaged slot has zero sums, and the stale record it may still
+        // hold — possibly one with a non-finite conic — must not be multiplied into them: 0 * inf = NaN
+        // would be flushed into whichever Gaussian the slot's id names now)
+        if (touch != 0u) {
             const float Ux = acc[0 * kAccStride + lane], Uy = acc[1 * kAccStride + lane];
             const float Uxx = acc[2 * kAccStride + lane], Uxy = acc[3 * kAccStride + lane];
             const float Uyy = acc[4 * kAccStride + lane];
@@ -823,6 +912,22 @@ __global__ void __launch_bounds__(64) k_debug_row_reduce9(const float *__restric
     if (c >= 0) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * 9 + c] = r;
 }
 
+// Test hook: mfma_reduce9 on given values.  in [blocks, 9, 64] -> out [blocks, 4, 9] (group, value),
+// group g = the lanes {4 g + q + 16 k}.
+__global__ void __launch_bounds__(64) k_debug_mfma_reduce9(const float *__restrict__ in,
+                                                           float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const float *p = in + (size_t)blockIdx.x * 9 * 64;
+    float v[9], oh[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        v[i] = p[i * 64 + lane];
+        oh[i] = (lane & 15) == i ? 1.0f : 0.0f;
+    }
+    const float r = mfma_reduce9(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], oh);
+    if ((lane & 15) < 9) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * 9 + (lane & 15)] = r;
+}
+
 // GS_FLAG_DETERMINISTIC: 64-bit fixed-point sums -> the float records
 __global__ void __launch_bounds__(256)
 k_fixed_to_records(int64_t n, const long long *__restrict__ fix, float *__restrict__ rec) {
@@ -840,10 +945,10 @@ extern "C" int gs_debug_expf(int64_t n, const float *x, float *y, uint32_t flags
     if (!x || !y) return GS_ERR_INVALID_ARGUMENT;
     int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL(gs::k_debug_expf<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+        GS_LAUNCH(gs::k_debug_expf<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            n, x, y);
     else
-        hipLaunchKernelGGL(gs::k_debug_expf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+        GS_LAUNCH(gs::k_debug_expf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            n, x, y);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -892,10 +997,25 @@ extern "C" int gs_debug_row_reduce9(int blocks, const float *in, float *out, gs_
     if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
     if (blocks == 0) return GS_OK;
     if (!in || !out) return GS_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(gs::k_debug_row_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
+    GS_LAUNCH(gs::k_debug_row_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
+
+extern "C" int gs_debug_group_reduce9(int blocks, const float *in, float *out, int mfma,
+                                      gs_stream_t stream) {
+    if (blocks < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (blocks == 0) return GS_OK;
+    if (!in || !out) return GS_ERR_INVALID_ARGUMENT;
+    if (mfma)
+        GS_LAUNCH(gs::k_debug_mfma_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
+    else
+        GS_LAUNCH(gs::k_debug_row_reduce9, dim3(blocks), dim3(64), 0, (hipStream_t)stream, in, out);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" int gs_debug_backward_uses_mfma(void) { return GS_BWD_MFMA; }
 
 extern "C" size_t gs_rasterize_backward_workspace_bytes_det(int N) {
     // float records + the 64-bit fixed-point accumulators of GS_FLAG_DETERMINISTIC
@@ -929,11 +1049,11 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
     if (flags & GS_FLAG_FAST_EXP)
-        hipLaunchKernelGGL((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
+        GS_LAUNCH((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
                            tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,
                            bg_dev, out_img, final_Ts, final_idx, clamped);
     else
-        hipLaunchKernelGGL((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
+        GS_LAUNCH((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
                            tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,
                            bg_dev, out_img, final_Ts, final_idx, clamped);
     gs::ev_after(s);
@@ -978,7 +1098,11 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     if (det)
         GS_HIP_CHECK(hipMemsetAsync(gfix, 0, (size_t)N * gs::kGradRec * sizeof(long long), s));
     else if (!(flags & GS_FLAG_RECORDS_ZEROED))
+    {
+        gs::timeline_before(s);
         GS_HIP_CHECK(hipMemsetAsync(gacc, 0, rec_bytes, s));
+        gs::timeline_after("memset(gradient records)", s);
+    }
     // Wave geometry of the backward (WaveGeom): four pixels per lane — one wave per tile, 8 x 8 blocks —
     // amortise the per-step reduction best (338 against 378 / 500 us with two / one at C2), and the
     // default launch gives the few tiles whose list is far longer than the others four waves with one
@@ -1010,7 +1134,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                 bg2 = bg_dev ? 0.f : background[2];
     gs::ev_before(s);
 #define GS_BWD_LAUNCH3(EX, DT, PXN)                                                                       \
-    hipLaunchKernelGGL((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
+    GS_LAUNCH((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
                        tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
                        bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
@@ -1019,7 +1143,7 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
         else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);                                              \
         else if (px_per_lane == 4) GS_BWD_LAUNCH3(EX, DT, 4);                                              \
         else                                                                                               \
-            hipLaunchKernelGGL((gs::k_rasterize_backward_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H, \
+            GS_LAUNCH((gs::k_rasterize_backward_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H, \
                                tiles_x, tiles, long_len, tile_order, gaussian_ids_sorted, block_masks, bins, \
                                pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, \
                                gacc, gfix);                                                                \
@@ -1035,12 +1159,12 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     GS_LAUNCH_CHECK();
     if (det) {
         const int64_t n = (int64_t)N * gs::kGradRec;
-        hipLaunchKernelGGL(gs::k_fixed_to_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n,
+        GS_LAUNCH(gs::k_fixed_to_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n,
                            reinterpret_cast<const long long *>(gfix), gacc);
         GS_LAUNCH_CHECK();
     }
     if (keep_records) return GS_OK;  // the 64-byte records go straight to gs_gaussian_backward
-    hipLaunchKernelGGL(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
+    GS_LAUNCH(gs::k_unpack_grads, dim3((N + 255) / 256), dim3(256), 0, s, N,
                        reinterpret_cast<const float4 *>(gacc),
                        (flags & GS_FLAG_LOGIT_OPACITY) ? pk : nullptr, v_xy, v_conic, v_colors,
                        v_opacity);

@@ -145,7 +145,7 @@ static int launch_fwd(int N, int nb, const float *dirs, const float *coeffs, flo
     constexpr int BLK = ShCfg<K>::kBlock;  // == Gaussians per block
     size_t lds = (size_t)BLK * ROWP * sizeof(float);
     int blocks = (N + BLK - 1) / BLK;
-    hipLaunchKernelGGL(k_sh_forward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs, coeffs,
+    GS_LAUNCH(k_sh_forward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs, coeffs,
                        colors);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -158,7 +158,7 @@ static int launch_bwd(int N, int nb, const float *dirs, const float *v_colors, f
     constexpr int BLK = ShCfg<K>::kBlock;
     size_t lds = (size_t)BLK * ROWP * sizeof(float);
     int blocks = (N + BLK - 1) / BLK;
-    hipLaunchKernelGGL(k_sh_backward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs,
+    GS_LAUNCH(k_sh_backward<K>, dim3(blocks), dim3(BLK), lds, s, N, nb, dirs,
                        v_colors, v_coeffs);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -301,7 +301,7 @@ int launch_sh_forward_fused16_quad(int N, int nb, const float *means, const floa
                                    float *colors, float *rgb_raw, hipStream_t s) {
     const bool dev = on_device(cam_pos);
     const int64_t threads = (int64_t)N * 4;
-    hipLaunchKernelGGL(k_sh_forward_fused16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+    GS_LAUNCH(k_sh_forward_fused16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        s, N, nb, means, dev ? 0.f : cam_pos[0], dev ? 0.f : cam_pos[1],
                        dev ? 0.f : cam_pos[2], dev ? cam_pos : nullptr, features_dc, features_rest,
                        colors, rgb_raw);
@@ -315,7 +315,7 @@ static int launch_fwd_fused(int N, int nb, const float *means, const float *cp, 
     constexpr int BLK = ShSplit<K>::kBlock;
     size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
     const bool dev = on_device(cp);
-    hipLaunchKernelGGL(k_sh_forward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+    GS_LAUNCH(k_sh_forward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
                        means, dev ? 0.f : cp[0], dev ? 0.f : cp[1], dev ? 0.f : cp[2],
                        dev ? cp : nullptr, dc, rest, colors, rgb_raw);
     GS_LAUNCH_CHECK();
@@ -328,7 +328,7 @@ static int launch_bwd_fused(int N, int nb, const float *means, const float *cp, 
     constexpr int BLK = ShSplit<K>::kBlock;
     size_t lds = (size_t)BLK * ShSplit<K>::ROWP * sizeof(float);
     const bool dev = on_device(cp);
-    hipLaunchKernelGGL(k_sh_backward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
+    GS_LAUNCH(k_sh_backward_fused<K>, dim3((N + BLK - 1) / BLK), dim3(BLK), lds, s, N, nb,
                        means, dev ? 0.f : cp[0], dev ? 0.f : cp[1], dev ? 0.f : cp[2],
                        dev ? cp : nullptr, rgb_raw, v_colors, v_dc, v_rest);
     GS_LAUNCH_CHECK();
@@ -353,7 +353,7 @@ extern "C" int gs_sh_forward(int N, int K, int degrees_to_use, const float *dirs
     case 9: return gs::launch_fwd<9>(N, nb, dirs, coeffs, colors, s);
     case 16: {
         const int64_t threads = (int64_t)N * 4;
-        hipLaunchKernelGGL(gs::k_sh_forward16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256),
+        GS_LAUNCH(gs::k_sh_forward16_quad, dim3((unsigned)((threads + 255) / 256)), dim3(256),
                            0, s, N, nb, dirs, coeffs, colors);
         GS_LAUNCH_CHECK();
         return GS_OK;

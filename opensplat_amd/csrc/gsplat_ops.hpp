@@ -95,10 +95,16 @@ void gsplatResetBinningState();
 std::tuple<int64_t, int64_t> gsplatBinningCounters();
 int64_t gsplatBinningCapacity(int device, int imgWidth, int imgHeight);
 
+// Reference-signature rasterize calls (ten arguments, no cov2d): {calls that found the frame's cov2d
+// behind ProjectGaussians' own conics tensor, calls that had to invert the conic} since the last reset.
+std::tuple<int64_t, int64_t> gsplatCov2dChannelCounters(bool reset = false);
+
 class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
 public:
-    // cov2d: the 7th output of ProjectGaussians; when absent the pixel rectangle is derived
-    // from the conics (call sites written against the reference's 10-argument signature).
+    // cov2d: the 7th output of ProjectGaussians.  When absent — the reference's own ten-argument call,
+    // model.cpp:208-218 — it is recovered from the storage ProjectGaussians::forward shares between
+    // conics and cov2d (same lists, same image as the eleven-argument call); only a `conics` tensor that
+    // is not that operator's untouched output gets its rectangle from conic^-1 (counted above).
     static torch::Tensor forward(torch::autograd::AutogradContext *ctx, torch::Tensor xys,
                                  torch::Tensor depths, torch::Tensor radii, torch::Tensor conics,
                                  torch::Tensor numTilesHit, torch::Tensor colors,

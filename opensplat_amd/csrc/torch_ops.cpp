@@ -16,11 +16,13 @@
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "../../include/gsplat_hip.h"
 #include "../../include/gsplat_train.h"
@@ -80,6 +82,62 @@ const float *vec3_arg(const Tensor &t, Tensor &holder) {
     return holder.data_ptr<float>();
 }
 
+
+// ---- the cov2d side channel of the reference-signature call ---------------------------------------
+// An unmodified Model::forward (model.cpp:208-218) hands RasterizeGaussians::apply the reference's TEN
+// arguments: no cov2d.  The exact gsplat-cpu pixel rectangle (gsplat_cpu.cpp:167-168) needs the
+// projection's own cov2d — re-deriving it as conic^-1 moves a floor / ceil edge whenever the det clamp
+// bound or the fp32 inversion rounds the other way ("what's weak" 1).  So
+// ProjectGaussians::forward puts conics and cov2d into ONE storage ([2, N, 3] floats: conics first) and
+// remembers that storage here; RasterizeGaussians::forward, given a `conics` tensor whose storage is one
+// of the remembered ones (same StorageImpl object — the registry holds weak references, so a live entry
+// proves identity, not just an equal address), unmodified since (version counter), finds the frame's
+// cov2d right behind it.  Anything else (a clone, an edited or hand-made conics tensor) misses and takes
+// the inversion; misses are counted (gsplatCov2dChannelCounters).
+struct Cov2dChannelEntry {
+    c10::weak_intrusive_ptr<c10::StorageImpl> storage;
+    int64_t n;
+    uint32_t version;
+};
+std::mutex g_cov2dMutex;
+std::vector<Cov2dChannelEntry> g_cov2dChannel;
+std::atomic<int64_t> g_cov2dHits{0}, g_cov2dMisses{0};
+
+void cov2d_channel_register(const Tensor &conics, int64_t N) {
+    std::lock_guard<std::mutex> lock(g_cov2dMutex);
+    // entries whose storage is gone (the frame's tensors were released) leave
+    g_cov2dChannel.erase(std::remove_if(g_cov2dChannel.begin(), g_cov2dChannel.end(),
+                                        [](const Cov2dChannelEntry &e) { return e.storage.expired(); }),
+                         g_cov2dChannel.end());
+    g_cov2dChannel.push_back({c10::weak_intrusive_ptr<c10::StorageImpl>(conics.storage().getWeakStorageImpl()),
+                              N, (uint32_t)conics._version()});
+}
+
+// the cov2d that ProjectGaussians::forward left behind `conics`, or an undefined tensor
+Tensor cov2d_channel_lookup(const Tensor &conics, int64_t N) {
+    if (!conics.defined() || !conics.is_contiguous() || conics.storage_offset() != 0 ||
+        conics.numel() != 3 * N || N == 0)
+        return Tensor();
+    const c10::Storage &st = conics.storage();
+    if (st.nbytes() < (size_t)(6 * N) * sizeof(float)) return Tensor();
+    const c10::StorageImpl *impl = st.unsafeGetStorageImpl();
+    bool found = false;
+    {
+        std::lock_guard<std::mutex> lock(g_cov2dMutex);
+        for (const Cov2dChannelEntry &e : g_cov2dChannel)
+            if (!e.storage.expired() && e.storage._unsafe_get_target() == impl && e.n == N &&
+                e.version == (uint32_t)conics._version()) {
+                found = true;
+                break;
+            }
+    }
+    if (!found) return Tensor();
+    // a plain tensor over the second half of the storage (not an autograd view of `conics`)
+    Tensor cov2d = torch::empty({0}, conics.options().requires_grad(false));
+    cov2d.set_(st, 3 * N, {N, 3}, {3, 1});
+    return cov2d;
+}
+
 }  // namespace
 
 void gsplatSetFastExp(bool enabled) { g_fast_exp.store(enabled); }
@@ -124,9 +182,15 @@ variable_list ProjectGaussians::forward(AutogradContext *ctx, Tensor means, Tens
     auto f32 = means.options();
     auto i32 = means.options().dtype(torch::kInt32);
     Tensor xys = torch::empty({N, 2}, f32), depths = torch::empty({N}, f32);
-    Tensor radii = torch::empty({N}, i32), conics = torch::empty({N, 3}, f32);
+    Tensor radii = torch::empty({N}, i32);
     Tensor numTilesHit = torch::empty({N}, i32), cov3d = torch::empty({N, 6}, f32);
-    Tensor cov2d = torch::empty({N, 3}, f32);
+    // conics and cov2d share ONE storage (conics first): the reference-signature rasterize call, which
+    // receives only `conics`, finds the frame's cov2d behind it (cov2d_channel_*, above).  Both are plain
+    // tensors over that storage, not autograd views of each other.
+    Tensor cc = torch::empty({2, N, 3}, f32);
+    Tensor conics = torch::empty({0}, f32), cov2d = torch::empty({0}, f32);
+    conics.set_(cc.storage(), 0, {N, 3}, {3, 1});
+    cov2d.set_(cc.storage(), 3 * N, {N, 3}, {3, 1});
     check_status(gs_project_forward(&cam, vmDev, pmDev, (int)N, fptr(means), fptr(scales),
                                     fptr(quats), fptr_mut(xys), fptr_mut(depths),
                                     radii.data_ptr<int32_t>(), fptr_mut(conics),
@@ -142,6 +206,7 @@ variable_list ProjectGaussians::forward(AutogradContext *ctx, Tensor means, Tens
     ctx->saved_data["clipThresh"] = clipThresh;
     ctx->save_for_backward({means, scales, quats, vmHold, pmHold, radii});
     ctx->mark_non_differentiable({radii, numTilesHit, cov3d, cov2d});
+    cov2d_channel_register(conics, N);
     return {xys, depths, radii, conics, numTilesHit, cov3d, cov2d};
 }
 
@@ -307,6 +372,12 @@ bool validateBinning(BinnedLists &b) {
     return ok;
 }
 
+std::tuple<int64_t, int64_t> gsplatCov2dChannelCounters(bool reset) {
+    auto r = std::make_tuple(g_cov2dHits.load(), g_cov2dMisses.load());
+    if (reset) { g_cov2dHits = 0; g_cov2dMisses = 0; }
+    return r;
+}
+
 void gsplatResetBinningState() {
     std::lock_guard<std::mutex> lock(g_binMutex);
     g_binStates.clear();
@@ -332,7 +403,11 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
                                    Tensor opacity, int64_t imgHeight, int64_t imgWidth,
                                    Tensor background, c10::optional<Tensor> cov2dOpt) {
     Tensor cov2d = (cov2dOpt.has_value() && cov2dOpt->defined()) ? *cov2dOpt : Tensor();
-    (void)numTilesHit;  // recounted from the pixel rectangle inside binAndSortGaussians
+    // numTilesHit carries the reference's radius-square counts (forward.cu:86-94), which size ITS global
+    // key list (rasterize_gaussians.cpp:62-63).  The lists here are per tile of the gsplat-cpu rectangle
+    //  and are counted on the device: the argument is validated and not read.
+    TORCH_CHECK(!numTilesHit.defined() || numTilesHit.numel() == xys.size(0),
+                "numTilesHit must have N elements");
     GS_CHECK_DEV(xys); GS_CHECK_DEV(depths); GS_CHECK_DEV(radii); GS_CHECK_DEV(conics);
     GS_CHECK_DEV(colors); GS_CHECK_DEV(opacity);
     GS_CHECK_F32(xys); GS_CHECK_F32(depths); GS_CHECK_I32(radii); GS_CHECK_F32(conics);
@@ -351,6 +426,13 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     }
     c10::DeviceGuard guard(xys.device());
     xys = xys.contiguous(); depths = depths.contiguous(); radii = radii.contiguous();
+    if (!cov2d.defined()) {
+        // the reference's ten-argument form (rasterize_gaussians.hpp:23-37): cov2d from the side channel
+        // of ProjectGaussians::forward; only a `conics` that is not that operator's untouched output
+        // falls back to conic^-1
+        cov2d = cov2d_channel_lookup(conics, N);
+        if (cov2d.defined()) g_cov2dHits++; else g_cov2dMisses++;
+    }
     conics = conics.contiguous(); colors = colors.contiguous(); opacity = opacity.contiguous();
     const int W = (int)imgWidth, H = (int)imgHeight;
 
@@ -983,6 +1065,10 @@ static std::vector<int64_t> op_binning_counters() {
     auto c = gsplatBinningCounters();
     return {std::get<0>(c), std::get<1>(c)};
 }
+static std::vector<int64_t> op_cov2d_channel_counters(bool reset) {
+    auto c = gsplatCov2dChannelCounters(reset);
+    return {std::get<0>(c), std::get<1>(c)};
+}
 static int64_t op_binning_capacity(int64_t device, int64_t w, int64_t h) {
     return gsplatBinningCapacity((int)device, (int)w, (int)h);
 }
@@ -996,11 +1082,15 @@ static std::vector<Tensor> op_bin_and_sort_gaussians(int64_t numPoints, int64_t 
 }
 
 TORCH_LIBRARY(opensplat_amd, m) {
+    // libgsplat_hip.so must be the one this file's header describes (shifted arguments otherwise)
+    TORCH_CHECK(gs_version() == GS_ABI_VERSION, "libgsplat_hip.so has ABI version ", gs_version(),
+                ", libgsplat_torch.so was built against ", GS_ABI_VERSION, ": rebuild both");
     m.def("bin_and_sort_gaussians(int num_points, int num_intersects, Tensor xys, Tensor depths, Tensor radii, "
           "Tensor cum_tiles_hit, int tiles_x, int tiles_y) -> Tensor[]", &op_bin_and_sort_gaussians);
     m.def("binning_reset() -> ()", &op_binning_reset);
     m.def("binning_counters() -> int[]", &op_binning_counters);
     m.def("binning_capacity(int device, int img_width, int img_height) -> int", &op_binning_capacity);
+    m.def("cov2d_channel_counters(bool reset=False) -> int[]", &op_cov2d_channel_counters);
     m.def("grad_exchange_selftest(Tensor(a!) flat, int buckets) -> Tensor(a!)", &op_grad_exchange_selftest);
     m.def("grad_exchange_factored_selftest(Tensor(a!) geometry, Tensor message, Tensor means, int K, "
           "int degrees_to_use) -> Tensor[]", &op_grad_exchange_factored_selftest);

@@ -36,8 +36,10 @@ def project_gaussians(means, scales, glob_scale, quats, viewmat, projmat, fx, fy
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
                         img_width, background, cov2d=None):
-    """-> image [H, W, 3].  Pass `cov2d` (7th output of project_gaussians) for exact gsplat-cpu
-    pixel-rectangle semantics; without it the rectangle is re-derived from the conics."""
+    """-> image [H, W, 3].  `cov2d` (7th output of project_gaussians) gives exact gsplat-cpu pixel-rectangle
+    semantics; when it is omitted (the reference's ten-argument form) it is recovered from the storage
+    project_gaussians shares between conics and cov2d — only a conics tensor that is not that operator's
+    untouched output has its rectangle re-derived from the conic (cov2d_channel_counters)."""
     return _ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity,
                                     int(img_height), int(img_width), background, cov2d)
 
@@ -61,6 +63,13 @@ def binning_counters():
     """-> (binning calls, forwards repeated because the id-list capacity was too small) since the
     last binning_reset()."""
     c = _ops.binning_counters()
+    return int(c[0]), int(c[1])
+
+
+def cov2d_channel_counters(reset: bool = False):
+    """-> (hits, misses) of the reference-signature (ten-argument) rasterize calls: a hit found the
+    frame's cov2d behind project_gaussians' own conics tensor, a miss inverted the conic."""
+    c = _ops.cov2d_channel_counters(bool(reset))
     return int(c[0]), int(c[1])
 
 

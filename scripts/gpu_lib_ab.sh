@@ -2,7 +2,7 @@
 # same-box A/B of library variants, interleaved:  gpu_lib_ab.sh suffix ...  (default = in-tree library)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 B="python bench.py --no-cpu-baseline --steps 40 --warmup 5"
-for rep in 1 2 3; do
+for rep in ${REPS:-1 2 3}; do
 for v in default "$@"; do
   if [ "$v" = default ]; then unset GSPLAT_HIP_LIB; else export GSPLAT_HIP_LIB=$PWD/opensplat_amd/csrc/libgsplat_hip_$v.so; fi
   $B ${BENCH_EXTRA:-} 2>/dev/null | python -c "

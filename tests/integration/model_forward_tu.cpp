@@ -11,6 +11,8 @@
 //
 //   model_forward_shim --cpu          CPU branch only (runs anywhere)
 //   model_forward_shim --gpu          both branches on the same parameters, images compared
+//   model_forward_shim --gpu-ordered  the same on a scene whose as-read keys are monotone in
+//                                     the true depth: both branches composite in depth order (tight bounds)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -31,7 +33,34 @@ struct Scene {
     int height, width, shDegree;
 };
 
-static Scene make_scene(int n, int width, int height, torch::Device device) {
+// ordered: a scene on which the reference's CPU chain composites in TRUE depth order, so that its image
+// can be compared tightly with the GPU path's.  gsplat-cpu sorts Gaussian a by element a + 2 of the
+// flattened [N,3] NDC array (`camDepths` is a strided view read with unit stride,
+// gsplat_cpu.cpp:128,152,157), i.e. by NDC x / y / z of Gaussian (a + 2) / 3.  Here the Gaussians are
+// indexed by increasing depth AND the flattened NDC coordinates of the first third — z0 < x1 < y1 < z1 <
+// x2 < ... — increase too (those Gaussians sit in the image corner, NDC x, y just below their own NDC z):
+// both the as-read keys and the true depths are then monotone in the index.
+static Scene make_scene(int n, int width, int height, torch::Device device, bool ordered = false);
+static void order_scene(Scene &s, int n) {
+    const double zn = 0.001, zf = 1000.0, c = (zf + zn) / (zf - zn), d = zf * zn / (zf - zn);
+    const int k1 = (n + 2) / 3 + 1;                       // Gaussians whose NDC coordinates serve as keys
+    const double zeta0 = c - d / 0.5, zeta1 = c - d / 3.0, dz = (zeta1 - zeta0) / k1;   // ~55 fp32 ulps apart
+    auto m = s.means.accessor<float, 2>();
+    torch::Tensor rest = 3.2f + 6.8f * std::get<0>(torch::sort(torch::rand({n})));
+    auto rz = rest.accessor<float, 1>();
+    for (int k = 0; k < n; k++) {
+        if (k < k1) {
+            const double zeta = zeta0 + k * dz, z = d / (c - zeta);
+            const double xn = zeta - dz + dz / 3.0, yn = zeta - dz + 2.0 * dz / 3.0;   // in (zeta_{k-1}, zeta_k)
+            m[k][0] = (float)(xn * z); m[k][1] = (float)(yn * z); m[k][2] = (float)z;
+        } else {
+            const float z = rz[k] + 1e-4f * (float)k;      // strictly increasing
+            m[k][0] *= z / m[k][2]; m[k][1] *= z / m[k][2]; m[k][2] = z;
+        }
+    }
+}
+
+static Scene make_scene(int n, int width, int height, torch::Device device, bool ordered) {
     torch::manual_seed(7);
     Scene s;
     s.width = width; s.height = height; s.shDegree = 3;
@@ -50,6 +79,7 @@ static Scene make_scene(int n, int width, int height, torch::Device device) {
     s.projMat = torch::tensor({{zn / r, 0.0f, 0.0f, 0.0f}, {0.0f, zn / t, 0.0f, 0.0f},
                                {0.0f, 0.0f, (zf + zn) / (zf - zn), -zf * zn / (zf - zn)}, {0.0f, 0.0f, 1.0f, 0.0f}});
     s.camPos = torch::zeros({1, 3});
+    if (ordered) order_scene(s, n);
     for (torch::Tensor *p : {&s.means, &s.scales, &s.quats, &s.featuresDc, &s.featuresRest, &s.opacities,
                              &s.backgroundColor, &s.viewMat, &s.projMat, &s.camPos})
         *p = p->to(device);
@@ -111,8 +141,8 @@ static torch::Tensor forward(Scene &m, torch::Device device, int degreesToUse, t
     return torch::clamp_max(rgb, 1.0f);
 }
 
-static int run(torch::Device device, torch::Tensor *img_out) {
-    Scene s = make_scene(1500, 96, 64, device);
+static int run(torch::Device device, torch::Tensor *img_out, bool ordered = false) {
+    Scene s = make_scene(1500, 96, 64, device, ordered);
     torch::Tensor xys, radii;
     torch::Tensor rgb = forward(s, device, (std::min<int>)(2, s.shDegree), xys, radii);
     torch::Tensor loss = (rgb - 0.5f).pow(2).mean();
@@ -137,6 +167,17 @@ int main(int argc, char **argv) {
         const float d = (cpu_img - gpu_img).abs().mean().item<float>();
         std::printf("{\"mean_abs_diff_cpu_gpu\": %.6g}\n", d);
         if (!(d < 0.05f)) rc |= 2;
+    }
+    if (argc > 1 && std::string(argv[1]) == "--gpu-ordered") {
+        // the depth-ordered scene: the CPU chain (reference statements, ten-argument GPU call on the other
+        // side) and the GPU path composite in the same order — a tight comparison
+        rc = run(torch::kCPU, &cpu_img, true);
+        rc |= run(torch::Device(torch::kCUDA, 0), &gpu_img, true);
+        const float dmax = (cpu_img - gpu_img).abs().max().item<float>();
+        const float dmean = (cpu_img - gpu_img).abs().mean().item<float>();
+        const int64_t over = ((cpu_img - gpu_img).abs().amax(-1) > 1e-5f).sum().item<int64_t>();
+        std::printf("{\"max_abs_diff_cpu_gpu\": %.6g, \"mean_abs_diff_cpu_gpu\": %.6g, \"pixels_over_1e-5\": %lld}\n",
+                    dmax, dmean, (long long)over);
     }
     return rc;
 }

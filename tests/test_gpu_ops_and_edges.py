@@ -371,6 +371,33 @@ def test_row_reduce9_butterfly():
     assert np.array_equal(y[2], np.broadcast_to(np.arange(9) + 1.0, (4, 9)))
 
 
+def test_group_reduce9_on_the_matrix_pipe():
+    """The same nine sums by nine v_mfma_f32_16x16x4_f32 with one-hot B columns + three additions
+    (GS_BWD_MFMA): lane (g, c < 9) receives the total of value c over the sixteen lanes
+    {4 g + q + 16 k : q, k < 4}; exact products (value x 1), fp32 sums."""
+    from opensplat_amd import cabi
+
+    rs = np.random.RandomState(7)
+    x = rs.uniform(-1, 1, (31, 9, 64)).astype(np.float32)
+    x[0] = np.arange(9, dtype=np.float32)[:, None] + 1.0
+    x[1] = 0
+    x[1, :, 37] = 10.0 ** np.arange(9)[::-1] / 1e4            # lane 37 = 4 * 1 + 1 + 16 * 2: group 1
+    x[2] = (np.arange(64)[None, :] == 4 * 3 + 2 + 16 * 1) * (np.arange(9)[:, None] + 1.0)   # group 3
+    lanes = np.arange(64)
+    grp = (lanes >> 2) & 3
+    ref = np.stack([x.astype(np.float64)[:, :, grp == g].sum(axis=2) for g in range(4)], axis=1)
+    y = np_(cabi.debug_group_reduce9(to_dev(x), mfma=True))
+    assert np.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(y[0], np.broadcast_to(16.0 * (np.arange(9) + 1.0), (4, 9)))
+    assert np.array_equal(y[1][1], x[1, :, 37]) and not y[1][[0, 2, 3]].any()
+    assert np.array_equal(y[2][3], np.arange(9) + 1.0) and not y[2][[0, 1, 2]].any()
+    # and the DPP butterfly through the same hook (groups = rows)
+    z = np_(cabi.debug_group_reduce9(to_dev(x), mfma=False))
+    refrow = x.astype(np.float64).reshape(31, 9, 4, 16).sum(axis=3).transpose(0, 2, 1)
+    assert np.allclose(z, refrow, rtol=1e-5, atol=1e-5)
+    assert cabi.lib().gs_debug_backward_uses_mfma() in (0, 1)
+
+
 @pytest.mark.parametrize("N,lo,hi", [(3000, 1024, 8192), (14000, 8192, 1 << 30)])
 def test_long_tile_lists_take_the_big_sort_paths(N, lo, hi, restated):
     """> 1024 and > 8192 intersections in one tile exercise the 64 KiB-LDS and the global-memory

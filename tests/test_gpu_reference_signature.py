@@ -1,0 +1,192 @@
+"""-m gpu: the REFERENCE-SIGNATURE call form against the oracle ("next" 1).
+
+An unmodified OpenSplat calls `RasterizeGaussians::apply(xys, depths, radii, conics, numTilesHit, colors,
+opacity, H, W, background)` — ten arguments, no cov2d (rasterize_gaussians.hpp:23-37, model.cpp:208-218).
+`ProjectGaussians::forward` therefore keeps conics and cov2d in ONE storage and the ten-argument call
+finds the frame's cov2d behind its `conics` argument (torch_ops.cpp: cov2d_channel_*): it must build the
+SAME per-tile lists and render the SAME bits as the eleven-argument call, and — like it — agree with
+gsplat-cpu (`oracle/`): the compositing bit for bit on the device's own 2-D values, the whole chain within
+the flip budget of the projection's fp32 round-off.  A `conics` that is not the operator's untouched output
+(a clone, an edited tensor) falls back to conic^-1 and is counted.
+"""
+import numpy as np
+import pytest
+
+from opensplat_amd import scenes
+from tests.test_gpu_baseline_parity import _cov2d4, image_flips, oracle_chain
+from tests.util import np_, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def needle_scene():
+    """A small SH scene plus Gaussians whose fp32 2-D determinant cancels (needles thousands of pixels
+    long): the projection's `det = max(det, 1e-6)` clamp binds (gsplat_cpu.cpp:101-104), cov2d and
+    conic^-1 then disagree wildly — the case the inversion fallback gets wrong by construction."""
+    s = scenes.camera_scene(3000, 160, 96, K=4, seed=41, znear=1.0, zfar=100.0)
+    rs = np.random.RandomState(42)
+    idx = rs.choice(s.N, 40, replace=False)
+    z = s.means[idx, 2]
+    sig_px = np.exp(rs.uniform(np.log(2e3), np.log(2e5), 40))          # pixel-space sigma of the long axis
+    s.scales[idx, 0] = (sig_px * z / s.fx).astype(np.float32)
+    s.scales[idx, 1:] = np.float32(1e-4)
+    s.extra["needles"] = idx
+    return s
+
+
+SCENES = {
+    "c1": lambda: scenes.config_c1(),
+    "k16": lambda: scenes.camera_scene(60000, 640, 360, K=16, seed=31, znear=1.0, zfar=100.0),
+    "needles": needle_scene,
+}
+
+
+def _chain(s, ten_arguments, conics_hook=None):
+    """Model::forward's GPU branch on the C++ operators; ten_arguments: the reference's call form."""
+    import torch
+
+    from opensplat_amd import ops
+
+    t = lambda a, rg=False: to_dev(a).requires_grad_(rg)
+    P = dict(means=t(s.means, True), scales=t(s.scales, True), quats=t(s.quats, True), opac=t(s.opacities, True))
+    p = ops.project_gaussians(P["means"], P["scales"], 1.0, P["quats"], t(s.viewmat), t(s.projmat),
+                              s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+    p[0].retain_grad()   # model.cpp:171
+    p[3].retain_grad()
+    if s.sh_coeffs is not None:
+        P["coeffs"] = t(s.sh_coeffs, True)
+        rgb = torch.clamp_min(ops.spherical_harmonics(s.degrees_to_use, t(s.dirs), P["coeffs"]) + 0.5, 0.0)
+    else:
+        P["colors"] = t(s.colors, True)
+        rgb = P["colors"]
+    rgb.retain_grad()
+    conics = p[3] if conics_hook is None else conics_hook(p[3])
+    img = ops.rasterize_gaussians(p[0], p[1], p[2], conics, p[4], rgb, P["opac"], s.H, s.W,
+                                  t(s.background), None if ten_arguments else p[6])
+    return P, p, rgb, img
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_ten_argument_call_matches_the_oracle(name, restated):
+    import torch
+
+    from opensplat_amd import ops
+
+    s = SCENES[name]()
+    if s.v_out is None:
+        s.v_out = np.random.RandomState(5).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
+    ops.cov2d_channel_counters(reset=True)
+    P, p, rgb, img = _chain(s, ten_arguments=True)
+    assert ops.cov2d_channel_counters() == (1, 0), "the ten-argument call did not find the frame's cov2d"
+    img.backward(to_dev(s.v_out))
+    torch.cuda.synchronize()
+
+    # (a) the same bits as the eleven-argument call: same rectangles, same lists
+    _, _, _, img11 = _chain(s, ten_arguments=False)
+    assert torch.equal(img, img11)
+
+    # (b) compositing against the oracle on the device's own 2-D values: image bit-exact, 2-D gradients
+    #     to summation order
+    O = restated
+    xys, conics, cov2d, depths = np_(p[0]), np_(p[3]), _cov2d4(np_(p[6])), np_(p[1])
+    colors = np_(rgb)
+    finite = np.isfinite(conics).all(1) & np.isfinite(xys).all(1)
+    assert finite.all()
+    f = O.rasterize_forward(s.W, s.H, xys, conics, colors, s.opacities, s.background, cov2d, depths,
+                            want_contributors=False)
+    assert np.array_equal(np_(img), f["img"]), "ten-argument image differs from gsplat-cpu on the same 2-D inputs"
+    g = O.rasterize_backward(s.W, s.H, xys, conics, colors, s.opacities, s.background, cov2d, depths,
+                             f["final_Ts"], f["state"], s.v_out)
+    assert rel_err(np_(p[0].grad), g["v_xy"]) < 2e-5
+    assert rel_err(np_(p[3].grad), g["v_conic"]) < 2e-5
+    assert rel_err(np_(rgb.grad), g["v_colors"]) < 2e-5
+    assert rel_err(np_(P["opac"].grad).ravel(), g["v_opacity"]) < 2e-5
+
+    # (c) the whole chain against the oracle's OWN projection: the flip budget of fp32 round-off in the
+    #     projection, six parameter gradients
+    if name == "needles":
+        return   # the needles' det clamp makes the oracle's autograd-style projection backward blow up; (b) covers them
+    if s.sh_coeffs is None:
+        o = O.project_forward(s.means, s.scales, s.quats, s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+        fo = O.rasterize_forward(s.W, s.H, o["xys"], o["conics"], s.colors, s.opacities, s.background,
+                                 o["cov2d"], o["depths"], want_contributors=False)
+        go = O.rasterize_backward(s.W, s.H, o["xys"], o["conics"], s.colors, s.opacities, s.background,
+                                  o["cov2d"], o["depths"], fo["final_Ts"], fo["state"], s.v_out)
+        pb = O.project_backward(s.means, s.scales, s.quats, s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy,
+                                s.H, s.W, go["v_xy"], go["v_conic"])
+        ref = dict(img=fo["img"], v_means=pb["v_means"], v_scales=pb["v_scales"], v_quats=pb["v_quats"],
+                   v_opacity=go["v_opacity"], v_colors=go["v_colors"])
+    else:
+        ref = oracle_chain(O, s)
+    flips, worst = image_flips(np_(img), ref["img"])
+    assert flips <= max(4, int(2e-5 * s.W * s.H)), (flips, worst)
+    tol = 2e-5 if flips == 0 else 2e-3   # a flipped (pixel, Gaussian) pair moves that Gaussian's gradient
+    assert rel_err(np_(P["means"].grad), ref["v_means"]) < tol
+    assert rel_err(np_(P["scales"].grad), ref["v_scales"]) < tol
+    assert rel_err(np_(P["quats"].grad), ref["v_quats"]) < tol
+    assert rel_err(np_(P["opac"].grad).ravel(), ref["v_opacity"]) < tol
+    if s.sh_coeffs is not None:
+        assert rel_err(np_(P["coeffs"].grad), ref["v_coeffs"]) < tol
+    else:
+        assert rel_err(np_(P["colors"].grad), ref["v_colors"]) < tol
+
+
+def test_foreign_conics_take_the_counted_fallback():
+    """A clone of conics (another storage) and an edited conics (version counter) miss the channel: the
+    rectangle is re-derived from the conic — close, not pinned — and the miss is counted."""
+    import torch
+
+    from opensplat_amd import ops
+
+    s = scenes.camera_scene(5000, 200, 120, K=0, seed=13, znear=1.0, zfar=100.0)
+    _, _, _, exact = _chain(s, ten_arguments=False)
+    ops.cov2d_channel_counters(reset=True)
+    _, _, _, a = _chain(s, ten_arguments=True, conics_hook=lambda c: c.clone())
+    assert ops.cov2d_channel_counters() == (0, 1)
+
+    def edited(c):
+        with torch.no_grad():
+            c.mul_(1.0)      # same values, bumped version counter: no longer provably the operator's output
+        return c
+    _, _, _, b = _chain(s, ten_arguments=True, conics_hook=edited)
+    assert ops.cov2d_channel_counters() == (0, 2)
+    _, _, _, c = _chain(s, ten_arguments=True)
+    assert ops.cov2d_channel_counters() == (1, 2)
+    assert torch.equal(c, exact)
+    for img in (a, b):
+        d = np.abs(np_(img) - np_(exact)).max(-1)
+        assert (d > 1e-6).mean() < 1e-3
+
+
+def test_channel_survives_interleaved_frames_and_released_storages():
+    """Two frames in flight (project A, project B, rasterize A, rasterize B) each find their OWN cov2d; a
+    released frame's entry cannot be matched by a new tensor that reuses its memory."""
+    import torch
+
+    from opensplat_amd import ops
+
+    sa = scenes.camera_scene(4000, 160, 96, K=0, seed=51, znear=1.0, zfar=100.0)
+    sb = scenes.camera_scene(4000, 160, 96, K=0, seed=52, znear=1.0, zfar=100.0)
+    t = to_dev
+
+    def project(s):
+        return ops.project_gaussians(t(s.means), t(s.scales), 1.0, t(s.quats), t(s.viewmat), t(s.projmat),
+                                     s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+
+    def raster(s, p, cov2d):
+        return ops.rasterize_gaussians(p[0], p[1], p[2], p[3], p[4], t(s.colors), t(s.opacities), s.H, s.W,
+                                       t(s.background), cov2d)
+    pa, pb = project(sa), project(sb)
+    ops.cov2d_channel_counters(reset=True)
+    ia, ib = raster(sa, pa, None), raster(sb, pb, None)
+    assert ops.cov2d_channel_counters() == (2, 0)
+    assert torch.equal(ia, raster(sa, pa, pa[6])) and torch.equal(ib, raster(sb, pb, pb[6]))
+    # release frame A; a fresh [N,3] tensor (very likely the same address) must not match
+    n = sa.N
+    del pa, ia
+    fake = torch.ones((2, n, 3), device="cuda")[0]   # storage of 6 N floats, offset 0: the channel's shape
+    ops.cov2d_channel_counters(reset=True)
+    img = ops.rasterize_gaussians(pb[0], pb[1], pb[2], fake, pb[4], t(sb.colors), t(sb.opacities), sb.H, sb.W,
+                                  t(sb.background), None)
+    assert ops.cov2d_channel_counters() == (0, 1)
+    assert torch.isfinite(img).all()
