@@ -455,7 +455,12 @@ constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_
 // 1: the per-step nine-value reduction runs on the matrix pipe (mfma_reduce9) and a group is one quad of
 // each DPP row; 0: the DPP butterfly (row_reduce9), a group is a DPP row.
 #ifndef GS_BWD_MFMA
-#define GS_BWD_MFMA 1
+#define GS_BWD_MFMA 0
+#endif
+// 1: the two position gradients are formed per lane before the reduction (three more VALU per step, no
+// cancellation for needle-shaped Gaussians); 0: from the reduced moments at the flush (rounds 2-3)
+#ifndef GS_BWD_DIRECT_XY
+#define GS_BWD_DIRECT_XY 1
 #endif
 // One wave of the backward: the pixels [wx0, wx0 + WW) x [wy0, wy0 + WH) of `tile` (WaveGeom<PX>).  The
 // LDS arrays belong to the calling kernel (one wave per workgroup).
@@ -721,14 +726,23 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 if (anym == 0ull) continue;
                 // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
                 const float ux = su * dx;
+#if GS_BWD_DIRECT_XY
+                // v_x / v_y per LANE before the reduction: sum u (A dx + B dy) over the lane's pixels is
+                // (A dx) su + B suy.  Reducing the plain moments sum(u dx), sum(u dy) and forming
+                // A Ux + B Uy once per entry cancels catastrophically for needle-shaped Gaussians (conic
+                // nearly singular: A dx + B dy ~ 0 along the needle while u dx and u dy are large).
+                const float c0v = fmaf(q0.z * dx, su, q0.w * suy), c1v = fmaf(Bdx, su, q1.x * suy);
+#else
+                const float c0v = ux, c1v = suy;
+#endif
 #if GS_BWD_MFMA
-                const float r = mfma_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, onehot);
+                const float r = mfma_reduce9(c0v, c1v, ux * dx, suy * dx, suyy, gr, gg, gb, su, onehot);
                 const int er = (int)((ep >> rgsh) & 0xFFu);   // the entry of the group this lane reports
                 if (rcomp >= 0 && r != 0.0f && er < kChunk)  // (a group without work has nothing to add)
                     __hip_atomic_fetch_add(&acc[rcomp * kAccStride + er], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-                const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
+                const float r = row_reduce9(c0v, c1v, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
                 if (rcomp >= 0 && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
                     __hip_atomic_fetch_add(&acc[rcomp * kAccStride + e], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -748,10 +762,15 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
             const float Ux = acc[0 * kAccStride + lane], Uy = acc[1 * kAccStride + lane];
             const float Uxx = acc[2 * kAccStride + lane], Uxy = acc[3 * kAccStride + lane];
             const float Uyy = acc[4 * kAccStride + lane];
-            const float A = stage[lane].p0.z, B = stage[lane].p0.w, C = stage[lane].p1.x;
             const float mo = -stage[lane].p1.y;          // v_sigma = -opacity * u
+#if GS_BWD_DIRECT_XY
+            acc[0 * kAccStride + lane] = mo * Ux;        // v_x: v_sigma * (A dx + B dy), summed per lane
+            acc[1 * kAccStride + lane] = mo * Uy;        // v_y: v_sigma * (B dx + C dy)
+#else
+            const float A = stage[lane].p0.z, B = stage[lane].p0.w, C = stage[lane].p1.x;
             acc[0 * kAccStride + lane] = mo * fmaf(A, Ux, B * Uy);   // v_x: v_sigma * (A dx + B dy)
             acc[1 * kAccStride + lane] = mo * fmaf(B, Ux, C * Uy);   // v_y: v_sigma * (B dx + C dy)
+#endif
             acc[2 * kAccStride + lane] = 0.5f * mo * Uxx;            // v_A  (gsplat_cpu.cpp:361-363)
             acc[3 * kAccStride + lane] = 0.5f * mo * Uxy;            // v_B
             acc[4 * kAccStride + lane] = 0.5f * mo * Uyy;            // v_C

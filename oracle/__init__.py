@@ -140,16 +140,27 @@ class Restated(_Base):
         return out
 
     def rasterize_forward(self, W, H, xys, conics, colors, opacities, background, cov2d,
-                          cam_depths, want_contributors=True, window=None):
-        """window = (x0, y0, x1, y1): evaluate only those pixels (full-image coordinates)."""
+                          cam_depths, want_contributors=True, window=None, tile_rect=None):
+        """window = (x0, y0, x1, y1): evaluate only those pixels (full-image coordinates).
+        tile_rect [N, 4] int32 {tx0, tx1, ty0, ty1}: a caller-supplied binning contract — Gaussian g is
+        composited only inside those 16 x 16 tiles (orc_rasterize_forward_tiles)."""
         N = len(xys)
         x, xp = _f(xys); cn, cnp = _f(conics); co, cop = _f(colors); o, op = _f(opacities)
         bg, bgp = _f(background); c2, c2p = _f(cov2d); cd, cdp = _f(cam_depths)
         img, ip = _fo((H, W, 3)); fT, fp = _fo((H, W)); cnt, cntp = _io((H, W))
         wx0, wy0, wx1, wy1 = window if window is not None else (0, 0, W, H)
-        st = self.lib.orc_rasterize_forward_window(
-            C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp, c2p, cdp, ip, fp, cntp,
-            C.c_int(wx0), C.c_int(wy0), C.c_int(wx1), C.c_int(wy1))
+        if tile_rect is not None:
+            assert window is None
+            tr = np.ascontiguousarray(tile_rect, dtype=np.int32)
+            assert tr.shape == (N, 4)
+            self.lib.orc_rasterize_forward_tiles.restype = C.c_void_p
+            st = self.lib.orc_rasterize_forward_tiles(
+                C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp, c2p, cdp,
+                tr.ctypes.data_as(_i32p), ip, fp, cntp)
+        else:
+            st = self.lib.orc_rasterize_forward_window(
+                C.c_int(W), C.c_int(H), C.c_int(N), xp, cnp, cop, op, bgp, c2p, cdp, ip, fp, cntp,
+                C.c_int(wx0), C.c_int(wy0), C.c_int(wx1), C.c_int(wy1))
         ids = None
         if want_contributors:
             total = self.lib.orc_rasterize_total(C.c_void_p(st))

@@ -447,11 +447,12 @@ void orc_pixel_rect(float gX, float gY, float cov_xx, float cov_yy, int W, int H
  * recurrence is independent of every other pixel's, so a window is the full image restricted);
  * pixels outside keep T = 1, colour = background, no contributors.  Lets the parity tests check
  * crops of BASELINE-size frames in full-image coordinates (no translation round-off). */
-void *orc_rasterize_forward_window(int W, int H, int N, const float *xys, const float *conics,
-                                   const float *colors, const float *opacities,
-                                   const float *background, const float *cov2d /* N x 2 x 2 */,
-                                   const float *cam_depths, float *out_img, float *final_Ts,
-                                   int32_t *px_counts, int wx0, int wy0, int wx1, int wy1) {
+static void *rasterize_forward_impl(int W, int H, int N, const float *xys, const float *conics,
+                                    const float *colors, const float *opacities,
+                                    const float *background, const float *cov2d /* N x 2 x 2 */,
+                                    const float *cam_depths, float *out_img, float *final_Ts,
+                                    int32_t *px_counts, int wx0, int wy0, int wx1, int wy1,
+                                    const int32_t *tile_rect /* N x 4 or NULL */) {
     int64_t P = (int64_t)W * H;
     if (wx0 < 0) wx0 = 0;
     if (wy0 < 0) wy0 = 0;
@@ -483,6 +484,15 @@ void *orc_rasterize_forward_window(int W, int H, int N, const float *xys, const 
         if (r1 > wy1) r1 = wy1;
         if (c0 < wx0) c0 = wx0;
         if (c1 > wx1) c1 = wx1;
+        if (tile_rect) {
+            /* the caller's binning contract: the Gaussian is in the lists of tiles [tx0,tx1) x [ty0,ty1)
+             * only, and a pixel only walks the list of its own 16 x 16 tile (forward.cu:256-283) */
+            const int32_t *t = tile_rect + 4 * (size_t)g;
+            if (c0 < 16 * t[0]) c0 = 16 * t[0];
+            if (c1 > 16 * t[1]) c1 = 16 * t[1];
+            if (r0 < 16 * t[2]) r0 = 16 * t[2];
+            if (r1 > 16 * t[3]) r1 = 16 * t[3];
+        }
         for (int i = r0; i < r1; i++) {
             for (int j = c0; j < c1; j++) {
                 int64_t pix = (int64_t)i * W + j;
@@ -542,6 +552,29 @@ void *orc_rasterize_forward_window(int W, int H, int N, const float *xys, const 
     free(done);
     free(order);
     return st;
+}
+
+void *orc_rasterize_forward_window(int W, int H, int N, const float *xys, const float *conics,
+                                   const float *colors, const float *opacities,
+                                   const float *background, const float *cov2d /* N x 2 x 2 */,
+                                   const float *cam_depths, float *out_img, float *final_Ts,
+                                   int32_t *px_counts, int wx0, int wy0, int wx1, int wy1) {
+    return rasterize_forward_impl(W, H, N, xys, conics, colors, opacities, background, cov2d, cam_depths,
+                                  out_img, final_Ts, px_counts, wx0, wy0, wx1, wy1, NULL);
+}
+
+/* The same recurrence under a CALLER-SUPPLIED binning contract: tile_rect[g] = {tx0, tx1, ty0, ty1} are the
+ * 16 x 16 tiles whose lists hold Gaussian g (rasterizer/gsplat/forward.cu:86-94 assigns the tiles under the
+ * square of half-width `radius` around the centre, helpers.cuh:17-49; map_gaussian_to_intersects :107-143
+ * writes one list entry per such tile), and a pixel walks the list of its own tile only (:256-283).  Per
+ * pixel the decisions stay gsplat-cpu's (rectangle of gsplat_cpu.cpp:167-168,201-204, sigma, alpha, T): what
+ * the launcher-level functions of this repo compute when they are handed the reference's tile lists. */
+void *orc_rasterize_forward_tiles(int W, int H, int N, const float *xys, const float *conics,
+                                  const float *colors, const float *opacities, const float *background,
+                                  const float *cov2d, const float *cam_depths, const int32_t *tile_rect,
+                                  float *out_img, float *final_Ts, int32_t *px_counts) {
+    return rasterize_forward_impl(W, H, N, xys, conics, colors, opacities, background, cov2d, cam_depths,
+                                  out_img, final_Ts, px_counts, 0, 0, W, H, tile_rect);
 }
 
 void *orc_rasterize_forward(int W, int H, int N, const float *xys, const float *conics,

@@ -52,7 +52,9 @@ static void order_scene(Scene &s, int n) {
         if (k < k1) {
             const double zeta = zeta0 + k * dz, z = d / (c - zeta);
             const double xn = zeta - dz + dz / 3.0, yn = zeta - dz + 2.0 * dz / 3.0;   // in (zeta_{k-1}, zeta_k)
-            m[k][0] = (float)(xn * z); m[k][1] = (float)(yn * z); m[k][2] = (float)z;
+            // NDC x = P00 x / z, NDC y = P11 y / z with P00 = 2 fx / W, P11 = 2 fy / H (make_scene's projMat)
+            const double p00 = 2.0 * s.fx / s.width, p11 = 2.0 * s.fy / s.height;
+            m[k][0] = (float)(xn * z / p00); m[k][1] = (float)(yn * z / p11); m[k][2] = (float)z;
         } else {
             const float z = rz[k] + 1e-4f * (float)k;      // strictly increasing
             m[k][0] *= z / m[k][2]; m[k][1] *= z / m[k][2]; m[k][2] = z;
@@ -156,7 +158,31 @@ static int run(torch::Device device, torch::Tensor *img_out, bool ordered = fals
     return finite ? 0 : 1;
 }
 
+// --check-ordered (CPU only): the ordered scene's as-read keys (element a + 2 of the flattened NDC array, as
+// gsplat_cpu.cpp:128,152,157 reads them) and its true depths are both strictly increasing in the index.
+static int check_ordered() {
+    Scene s = make_scene(1500, 96, 64, torch::kCPU, true);
+    torch::NoGradGuard ng;
+    const int64_t n = s.means.size(0);
+    torch::Tensor fullProj = torch::matmul(s.projMat, s.viewMat);
+    torch::Tensor pHom = torch::nn::functional::pad(s.means, torch::nn::functional::PadFuncOptions({0, 1}).value(1.0f));
+    pHom = torch::einsum("ij,nj->ni", {fullProj, pHom});
+    torch::Tensor rw = 1.0f / torch::clamp_min(pHom.index({Slice(), 3}), 1e-6f);
+    torch::Tensor pProj = (pHom.index({Slice(), Slice(None, 3)}) * rw.index({Slice(), None})).contiguous();
+    torch::Tensor keys = pProj.reshape({-1}).index({Slice(2, 2 + n)});
+    const int64_t key_inv = (keys.index({Slice(1, None)}) <= keys.index({Slice(None, -1)})).sum().item<int64_t>();
+    torch::Tensor z = s.means.index({Slice(), 2});
+    const int64_t z_inv = (z.index({Slice(1, None)}) <= z.index({Slice(None, -1)})).sum().item<int64_t>();
+    if (std::getenv("GS_SHIM_DEBUG")) {
+        auto ka = keys.accessor<float, 1>();
+        for (int i = 0; i < 12; i++) std::printf("key[%d] = %.9g  mean = %.9g %.9g %.9g\n", i, ka[i], s.means[i][0].item<float>(), s.means[i][1].item<float>(), s.means[i][2].item<float>());
+    }
+    std::printf("{\"as_read_key_inversions\": %lld, \"depth_inversions\": %lld}\n", (long long)key_inv, (long long)z_inv);
+    return (key_inv == 0 && z_inv == 0) ? 0 : 3;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--check-ordered") return check_ordered();
     const bool gpu = argc > 1 && std::string(argv[1]) == "--gpu";
     torch::Tensor cpu_img, gpu_img;
     int rc = run(torch::kCPU, &cpu_img);

@@ -1,5 +1,7 @@
-"""CPU, world_size 2, gloo: the multi-GPU exchange step (flat gradient buffer, SH block first,
-two async all-reduces) — the same code bench.py runs over RCCL."""
+"""CPU, world_size 2 and 8, gloo: the multi-GPU exchange step (flat gradient buffer, SH block first,
+two async all-reduces; the factored exchange) — the same code bench.py runs over RCCL.  World 8 is BASELINE
+config 4's rank count: every rank's contribution must arrive in the sum, and the bytes a rank moves must be
+the figures of DESIGN.md §7's table."""
 import os
 
 import numpy as np
@@ -27,10 +29,9 @@ def _worker(rank, world, port, N, K, q, one_collective=False):
     gen = torch.Generator().manual_seed(100 + rank)
     buf.flat.copy_(torch.randn(buf.flat.numel(), generator=gen))
     # each rank only "sees" part of the Gaussians: zero rows elsewhere, like a camera would
-    if rank == 0:
-        buf.v_means[N // 2:] = 0
-    else:
-        buf.v_means[: N // 2] = 0
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    buf.v_means[:lo] = 0
+    buf.v_means[hi:] = 0
     if one_collective:   # the fused per-Gaussian backward delivers everything at once
         gdist.wait_all(gdist.allreduce_all_async(buf))
     else:
@@ -46,9 +47,10 @@ def _worker(rank, world, port, N, K, q, one_collective=False):
 import pytest
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("one_collective", [False, True], ids=["two_blocks", "one_collective"])
-def test_allreduce_of_flat_grad_buffer_world2(one_collective):
-    N, K, world = 257, 16, 2
+def test_allreduce_of_flat_grad_buffer(one_collective, world):
+    N, K = 257, 16
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -71,13 +73,15 @@ def test_allreduce_of_flat_grad_buffer_world2(one_collective):
         b = GradBuffer(N, K, torch.device("cpu"))
         gen = torch.Generator().manual_seed(100 + rank)
         b.flat.copy_(torch.randn(b.flat.numel(), generator=gen))
-        if rank == 0:
-            b.v_means[N // 2:] = 0
-        else:
-            b.v_means[: N // 2] = 0
+        lo, hi = rank * N // world, (rank + 1) * N // world
+        b.v_means[:lo] = 0
+        b.v_means[hi:] = 0
         exp += b.flat
-    assert torch.equal(got[0], got[1]), "ranks disagree after all-reduce"
-    assert torch.allclose(got[0], exp, atol=1e-6)
+    for rank in range(1, world):
+        assert torch.equal(got[0], got[rank]), "ranks disagree after all-reduce"
+    assert torch.allclose(got[0], exp, atol=1e-5)
+    # what one flat all-reduce moves per rank over a ring: 2 (W - 1) / W x 4 N (11 + 3 K) bytes
+    assert b.nbytes == 4 * N * (11 + 3 * K)
 
 
 def test_single_process_is_noop():
@@ -155,11 +159,12 @@ def _fx_worker(rank, world, port, N, K, cpr, q):
     torch.distributed.destroy_process_group()
 
 
-def test_factored_exchange_messages_world2():
-    """dist.FactoredExchange on two gloo ranks: the geometry block is summed, the SH block is left
-    alone, and both ranks hold, per local-camera slot, both ranks' messages [camera centre | colour
-    cotangent] in rank order."""
-    N, K, world, cpr = 37, 16, 2, 2
+@pytest.mark.parametrize("world,cpr", [(2, 2), (8, 1), (8, 2)])
+def test_factored_exchange_messages(world, cpr):
+    """dist.FactoredExchange on two / eight gloo ranks: the geometry block is summed, the SH block is left
+    alone, and every rank holds, per local-camera slot, every rank's message [camera centre | colour
+    cotangent] in rank order; the bytes moved are DESIGN §7's."""
+    N, K = 37, 16
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -176,7 +181,8 @@ def test_factored_exchange_messages_world2():
     for rank in range(world):
         flat, msg, moved = got[rank]
         assert np.array_equal(flat[:sh], base[:sh] * (rank + 1))          # SH block: not exchanged
-        assert np.array_equal(flat[sh:], base[sh:] * 3)                   # geometry: summed (1 + 2)
+        # geometry: summed over the ranks (factors 1 .. W; exact in fp32: integers below 2^24)
+        assert np.array_equal(flat[sh:], base[sh:] * (world * (world + 1) // 2))
         one = 4 + N * 3                                  # one camera's message
         assert msg.shape == (cpr, world * one)            # slot j: the world's cameras j, in rank order
         for j in range(cpr):
@@ -184,4 +190,6 @@ def test_factored_exchange_messages_world2():
                 m = msg[j, r * one:(r + 1) * one]
                 assert list(m[0:3]) == [r, j, 7.0]
                 assert np.all(m[4:] == 10.0 * r + j)
-        assert moved == int(2 * 0.5 * 11 * N * 4 + cpr * one * 4)
+        # ring all-reduce of the 11 geometry floats per Gaussian + all-gather of cpr messages from W - 1 peers
+        assert moved == int(2 * (world - 1) / world * 11 * N * 4 + (world - 1) * cpr * one * 4)
+        assert moved < int(2 * (world - 1) / world * 4 * N * (11 + 3 * K))   # ... less than the flat exchange

@@ -5,9 +5,12 @@ torch::sort -> gather -> get_tile_bin_edges_tensor -> rasterize_forward_tensor; 
 rasterize_backward_tensor), compared with the native path of this repo.
 
 At this level tiles are assigned by the GPU reference's radius square (forward.cu:86-94), natively by
-the tightened CPU pixel rectangle; a Gaussian whose rectangle reaches a tile its radius square does not
-(~1 in 10^4 pixel-Gaussian pairs) is taken out of the scene (opacity 0), after which
-both paths composite the same contributor lists and must agree BIT FOR BIT in the forward."""
+the tightened CPU pixel rectangle.  The launcher image and gradients are compared with the ORACLE under the
+same contract (oracle/gsplat_oracle.c orc_rasterize_forward_tiles: gsplat-cpu's per-pixel decisions, each
+Gaussian confined to the tiles of its radius square — the lists the reference's own glue hands over) on the
+WHOLE scene, bit for bit in the forward (VERDICT r03 "next" 9: round 3 compared HIP with HIP after zeroing
+the Gaussians on which the two contracts disagree).  The native path is compared too, on the sub-population
+where both contracts coincide."""
 import numpy as np
 import pytest
 
@@ -102,7 +105,48 @@ def test_reference_operator_glue_on_the_launcher_functions(W, H, N):
     colors = torch.clamp_min(sh + 0.5, 0.0)
     opac = to_dev(s.opacities.reshape(-1, 1)).clone()
 
-    # Gaussians whose tightened rectangle reaches a tile outside their radius square: out of the scene
+    # ---- launcher level on the WHOLE scene against the oracle under the radius-square contract ----
+    from oracle import restated as _restated
+
+    O = _restated()
+    xn, cn, rn = np_(xys), np_(conics), np_(radii).astype(np.float32)
+    trunc_ = lambda v: np.trunc(v).astype(np.int64)
+    # helpers.cuh:17-49 get_tile_bbox: tile_center = xy / 16, tile_radius = radius / 16, min = (int)(c - r),
+    # max = (int)(c + r + 1), both clamped to [0, tiles]
+    tx0 = np.clip(trunc_(xn[:, 0] / 16 - rn / 16), 0, tiles_x); tx1 = np.clip(trunc_(xn[:, 0] / 16 + rn / 16 + 1), 0, tiles_x)
+    ty0 = np.clip(trunc_(xn[:, 1] / 16 - rn / 16), 0, tiles_y); ty1 = np.clip(trunc_(xn[:, 1] / 16 + rn / 16 + 1), 0, tiles_y)
+    tile_rect = np.stack([tx0, tx1, ty0, ty1], -1).astype(np.int32)
+    tile_rect[rn <= 0] = 0
+    assert np.array_equal(np.where(rn > 0, (tx1 - tx0) * (ty1 - ty0), 0), np_(tiles_hit))
+    # the launcher's pixel rectangle comes from conic^-1 (no cov2d at this level): xx = C / det, yy = A / det
+    A_, B_, C_ = cn[:, 0], cn[:, 1], cn[:, 2]
+    det_ = A_ * C_ - B_ * B_
+    cov = np.zeros((N, 2, 2), np.float32)
+    cov[:, 0, 0] = C_ / det_
+    cov[:, 1, 1] = A_ / det_
+    Mw, idsw, gidsw, binsw = _glue_bin_and_sort(T, xys, depths, radii, tiles_hit, tiles_x, tiles_y)
+    bgw = to_dev(s.background)
+    imgw, Tsw, fidxw = T.launcher_rasterize_forward(tiles_x, tiles_y, W, H, gidsw, binsw, xys, conics, colors,
+                                                    opac, bgw)
+    gw = T.launcher_rasterize_backward(H, W, gidsw, binsw, xys, conics, colors, opac, bgw, Tsw, fidxw,
+                                       to_dev(s.v_out), torch.zeros((H, W), device="cuda"))
+    torch.cuda.synchronize()
+    fo = O.rasterize_forward(W, H, xn, cn, np_(colors), np_(opac).reshape(-1), s.background, cov, np_(depths),
+                             want_contributors=False, tile_rect=tile_rect)
+    assert np.array_equal(np_(imgw), fo["img"]), "launcher image differs from the oracle under the radius-square contract"
+    assert np.array_equal(np_(Tsw), fo["final_Ts"])
+    go = O.rasterize_backward(W, H, xn, cn, np_(colors), np_(opac).reshape(-1), s.background, cov, np_(depths),
+                              fo["final_Ts"], fo["state"], s.v_out)
+    for a, name in zip(gw, ("v_xy", "v_conic", "v_colors", "v_opacity")):
+        assert rel_err(np_(a).reshape(go[name].shape), go[name]) < 2e-5, name
+    # and the contract matters: without the tile confinement the oracle renders another image
+    ff = O.rasterize_forward(W, H, xn, cn, np_(colors), np_(opac).reshape(-1), s.background, cov, np_(depths),
+                             want_contributors=False)
+    O.rasterize_free(ff["state"])
+    contract_matters = not np.array_equal(ff["img"], fo["img"])
+
+    # ---- launcher against the native path: Gaussians whose tightened rectangle reaches a tile outside
+    #      their radius square are taken out of the scene, after which both composite the same lists ----
     nat = cabi.bin_and_sort(W, H, xys, depths, radii, conics, colors, opac.reshape(-1).contiguous(), None)
     pk = np_(nat.packed).view(np.uint32)
     rx, ry = pk[:, 7], pk[:, 11]
@@ -115,6 +159,7 @@ def test_reference_operator_glue_on_the_launcher_functions(W, H, N):
     inside = (x0 // 16 >= sx0) & ((x1 + 15) // 16 <= sx1) & (y0 // 16 >= sy0) & ((y1 + 15) // 16 <= sy1)
     bad = ~(inside | empty)
     assert bad.mean() < 0.2
+    assert contract_matters or not bad.any()
     opac[torch.from_numpy(bad).cuda()] = 0.0
 
     # ---- launcher level, driven like rasterize_gaussians.cpp ----

@@ -30,3 +30,34 @@ def test_window_equals_full_frame_restricted(restated):
     gf = O.rasterize_backward(*args, full["final_Ts"], gfull_state, v)
     for k in gw:
         assert np.array_equal(gw[k], gf[k]), k
+
+
+def test_tile_contract_restricts_each_gaussian_to_its_tiles(restated):
+    """orc_rasterize_forward_tiles (the launcher-level contract, forward.cu:86-94 + :256-283): with every tile
+    allowed it IS the plain oracle; with Gaussians confined to a tile range, pixels outside it never see them
+    and pixels inside composite exactly the confined set."""
+    from opensplat_amd import scenes
+
+    O = restated
+    s = scenes.camera_scene(2500, 160, 96, K=0, seed=5, znear=1.0, zfar=100.0)
+    o = O.project_forward(s.means, s.scales, s.quats, s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+    args = (s.W, s.H, o["xys"], o["conics"], s.colors, s.opacities, s.background, o["cov2d"], o["depths"])
+    full = O.rasterize_forward(*args)
+    tr = np.tile(np.array([0, 10, 0, 6], np.int32), (s.N, 1))
+    a = O.rasterize_forward(*args, tile_rect=tr)
+    assert np.array_equal(a["img"], full["img"]) and np.array_equal(a["contributors"], full["contributors"])
+    # odd Gaussians confined to the left half, even ones to the top half
+    tr[1::2, 1] = 5
+    tr[0::2, 3] = 3
+    b = O.rasterize_forward(*args, tile_rect=tr)
+    # reference: render the two sub-populations' allowed regions by zeroing opacities
+    op_odd = s.opacities.copy(); op_odd[0::2] = 0
+    op_even = s.opacities.copy(); op_even[1::2] = 0
+    only_odd = O.rasterize_forward(s.W, s.H, o["xys"], o["conics"], s.colors, op_odd, s.background, o["cov2d"], o["depths"])
+    only_even = O.rasterize_forward(s.W, s.H, o["xys"], o["conics"], s.colors, op_even, s.background, o["cov2d"], o["depths"])
+    assert np.array_equal(b["img"][:48, :80], full["img"][:48, :80])          # both populations allowed
+    assert np.array_equal(b["img"][48:, :80], only_odd["img"][48:, :80])      # bottom left: odd only
+    assert np.array_equal(b["img"][:48, 80:], only_even["img"][:48, 80:])     # top right: even only
+    assert np.allclose(b["img"][48:, 80:], s.background)                      # bottom right: nobody
+    for st in (full, a, b, only_odd, only_even):
+        O.rasterize_free(st["state"])
