@@ -76,6 +76,25 @@ typedef struct GsAdamGroup {
 int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t step, double beta1, double beta2,
                  double eps, gs_stream_t stream);
 
+/* The same step for a CAPTURED HIP GRAPH (the training iteration of a small frame is launch-bound: ~25
+ * launches of a few microseconds each; replayed as one graph it is not).  A graph replays its
+ * launches with the arguments of the capture, so whatever changes from step to step must come from device
+ * memory: the per-step scalars sit in a table the host fills ahead of time,
+ *     row = { sqrt(1 - beta2^step), -(lr_g / (1 - beta1^step)) for the GS_ADAM_MAX_GROUPS groups }
+ * (gs_adam_schedule_row: the very expressions gs_adam_step evaluates, so both forms move the same bits), the
+ * kernel takes row *row_index_dev, and gs_adam_advance — one thread, also captured — steps the index.
+ * guard_dev (optional): the launch does nothing when *guard_dev > guard_max — the caller points it at the
+ * intersection count of a speculative binning (gs_bin_scan's num_isects_dev) with guard_max = the id list's
+ * capacity: a step whose lists were truncated leaves parameters, moments and the row index untouched, and
+ * the host, seeing the count afterwards, re-runs it with a larger list.  GsAdamGroup.lr is ignored here. */
+#define GS_ADAM_ROW_FLOATS (1 + GS_ADAM_MAX_GROUPS)
+int gs_adam_schedule_row(int num_groups, const double *lrs /* host */, int64_t step, double beta1,
+                         double beta2, float *row /* host, GS_ADAM_ROW_FLOATS */);
+int gs_adam_step_scheduled(int num_groups, const GsAdamGroup *groups /* host */, const float *rows_dev,
+                           const int32_t *row_index_dev, int32_t num_rows, const int32_t *guard_dev,
+                           int32_t guard_max, double beta1, double beta2, double eps, gs_stream_t stream);
+int gs_adam_advance(int32_t *row_index_dev, const int32_t *guard_dev, int32_t guard_max, gs_stream_t stream);
+
 /* exp(log(lr_init) (1 - t) + log(lr_final) t), t = clamp(step / max_steps, 0, 1)
  * (optim_scheduler.cpp:4-7; Model uses it for the means only, model.cpp:68,245-247). */
 float gs_sched_lr(float lr_init, float lr_final, int max_steps, int step);

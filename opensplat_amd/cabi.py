@@ -38,7 +38,7 @@ SYMBOLS = [
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
-                 "gs_sched_lr"]
+                 "gs_adam_schedule_row", "gs_adam_step_scheduled", "gs_adam_advance", "gs_sched_lr"]
 # every symbol include/gsplat_densify.h declares
 DENSIFY_SYMBOLS = ["gs_densify_stats", "gs_densify_workspace_bytes", "gs_densify_plan",
                    "gs_densify_apply", "gs_reset_opacity"]
@@ -492,6 +492,15 @@ def main_loss(rendered, gt, ssim_weight=0.2, grad_scale=1.0, want_grad=True, out
 def adam_step(groups, step, beta1=0.9, beta2=0.999, eps=1e-8):
     """groups: list of (param, grad, exp_avg, exp_avg_sq, lr) flat GPU tensors, updated in place
     (Model::optimizersStep, model.cpp:236-243; lr per group as in model.cpp:61-66)."""
+    arr = _adam_group_array(groups)
+    _check(lib().gs_adam_step(C.c_int(len(groups)), arr, C.c_int64(step), C.c_double(beta1),
+                              C.c_double(beta2), C.c_double(eps), _stream()), "gs_adam_step")
+
+
+GS_ADAM_ROW_FLOATS = 9   # include/gsplat_train.h: 1 + GS_ADAM_MAX_GROUPS
+
+
+def _adam_group_array(groups):
     arr = (GsAdamGroup * len(groups))()
     for i, (p, g, m, v, lr) in enumerate(groups):
         n = p.numel()
@@ -501,8 +510,38 @@ def adam_step(groups, step, beta1=0.9, beta2=0.999, eps=1e-8):
         for t in (p, g, m, v):
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
         arr[i].n, arr[i].lr = n, float(lr)
-    _check(lib().gs_adam_step(C.c_int(len(groups)), arr, C.c_int64(step), C.c_double(beta1),
-                              C.c_double(beta2), C.c_double(eps), _stream()), "gs_adam_step")
+    return arr
+
+
+def adam_schedule_rows(lrs_per_step, first_step, beta1=0.9, beta2=0.999):
+    """Host: rows [len(lrs_per_step), GS_ADAM_ROW_FLOATS] of the scalars gs_adam_step(step) hands its kernel,
+    for steps first_step, first_step + 1, ... with that step's learning rates (one list per step)."""
+    rows = np.zeros((len(lrs_per_step), GS_ADAM_ROW_FLOATS), np.float32)
+    f32p = C.POINTER(C.c_float)
+    for r, lrs in enumerate(lrs_per_step):
+        arr = (C.c_double * len(lrs))(*[float(x) for x in lrs])
+        _check(lib().gs_adam_schedule_row(C.c_int(len(lrs)), arr, C.c_int64(first_step + r),
+                                          C.c_double(beta1), C.c_double(beta2),
+                                          rows[r].ctypes.data_as(f32p)), "gs_adam_schedule_row")
+    return rows
+
+
+def adam_step_scheduled(groups, rows_dev, row_index_dev, guard_dev=None, guard_max=0, beta1=0.9,
+                        beta2=0.999, eps=1e-8):
+    """gs_adam_step with the per-step scalars taken from row *row_index_dev of rows_dev [R, 9] (device); does
+    nothing when guard_dev[0] > guard_max.  groups as in adam_step (lr ignored).  Graph-capturable."""
+    arr = _adam_group_array(groups)
+    assert rows_dev.is_cuda and rows_dev.dtype == torch.float32 and rows_dev.is_contiguous()
+    assert rows_dev.shape[-1] == GS_ADAM_ROW_FLOATS and row_index_dev.dtype == torch.int32
+    _check(lib().gs_adam_step_scheduled(C.c_int(len(groups)), arr, _p(rows_dev), _p(row_index_dev),
+                                        C.c_int32(rows_dev.shape[0]), _p(guard_dev), C.c_int32(guard_max),
+                                        C.c_double(beta1), C.c_double(beta2), C.c_double(eps), _stream()),
+           "gs_adam_step_scheduled")
+
+
+def adam_advance(row_index_dev, guard_dev=None, guard_max=0):
+    _check(lib().gs_adam_advance(_p(row_index_dev), _p(guard_dev), C.c_int32(guard_max), _stream()),
+           "gs_adam_advance")
 
 
 def sched_lr(lr_init, lr_final, max_steps, step):

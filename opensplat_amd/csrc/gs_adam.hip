@@ -41,7 +41,7 @@ static __device__ __forceinline__ void adam1(float &p, float g, float &m, float 
     p = p + (nss * m) / denom;
 }
 
-__global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
+static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
     const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= a.chunk_start[a.num]) return;
     int grp = 0;
@@ -82,7 +82,106 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a) { adam_chunk(a); }
+
+// The same update with the per-step scalars read from DEVICE memory (gs_adam_step_scheduled): row
+// *row_index of `rows` = {sqrt(1 - beta2^step), -(lr_g / (1 - beta1^step)) for every group}, written by the
+// host with gs_adam_schedule_row — so that a captured HIP graph replays the launch unchanged while the step
+// count advances.  Nothing happens when the guard says the step is void (*guard > guard_max: a speculative
+// id list upstream was too small, the gradients are not to be used) or the row index is outside the table.
+__global__ void __launch_bounds__(256)
+k_adam_scheduled(AdamArgs a, const float *__restrict__ rows, const int32_t *__restrict__ row_index,
+                 int num_rows, const int32_t *__restrict__ guard, int guard_max) {
+    if (guard && *guard > guard_max) return;
+    const int r = *row_index;
+    if (r < 0 || r >= num_rows) return;
+    const float *row = rows + (size_t)r * GS_ADAM_ROW_FLOATS;
+    a.bc2_sqrt = row[0];
+#pragma unroll
+    for (int i = 0; i < GS_ADAM_MAX_GROUPS; i++) a.neg_step_size[i] = row[1 + i];
+    adam_chunk(a);
+}
+
+__global__ void k_adam_advance(int32_t *__restrict__ row_index, const int32_t *__restrict__ guard,
+                               int guard_max) {
+    if (guard && *guard > guard_max) return;
+    *row_index += 1;
+}
+
+// host side of both entry points: everything of AdamArgs that does not depend on the step
+static int fill_adam_args(AdamArgs &a, int num_groups, const GsAdamGroup *groups, double beta1, double beta2,
+                          double eps, int64_t &chunks) {
+    a.num = num_groups;
+    a.beta1 = (float)beta1;
+    a.beta2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1);
+    a.omb2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    chunks = 0;
+    for (int i = 0; i < num_groups; i++) {
+        const GsAdamGroup &gr = groups[i];
+        if (gr.n < 0) return GS_ERR_INVALID_ARGUMENT;
+        if (gr.n > 0 && (!gr.param || !gr.grad || !gr.exp_avg || !gr.exp_avg_sq))
+            return GS_ERR_INVALID_ARGUMENT;
+        a.p[i] = gr.param;
+        a.g[i] = gr.grad;
+        a.m[i] = gr.exp_avg;
+        a.v[i] = gr.exp_avg_sq;
+        a.n[i] = gr.n;
+        const uintptr_t bits = (uintptr_t)gr.param | (uintptr_t)gr.grad | (uintptr_t)gr.exp_avg |
+                               (uintptr_t)gr.exp_avg_sq;
+        if ((bits & 15u) == 0) a.aligned |= 1u << i;
+        a.chunk_start[i] = chunks;
+        chunks += (gr.n + 3) / 4;
+    }
+    for (int i = num_groups; i <= GS_ADAM_MAX_GROUPS; i++) a.chunk_start[i] = chunks;
+    return GS_OK;
+}
+
 }  // namespace gs
+
+extern "C" int gs_adam_schedule_row(int num_groups, const double *lrs, int64_t step, double beta1,
+                                    double beta2, float *row) {
+    if (num_groups < 0 || num_groups > GS_ADAM_MAX_GROUPS || step < 1 || !row || (num_groups && !lrs))
+        return GS_ERR_INVALID_ARGUMENT;
+    // (the expressions of gs_adam_step, so that both forms hand the kernel the same bits)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    row[0] = (float)sqrt(bc2);
+    for (int i = 0; i < GS_ADAM_MAX_GROUPS; i++) row[1 + i] = i < num_groups ? (float)(-(lrs[i] / bc1)) : 0.0f;
+    return GS_OK;
+}
+
+extern "C" int gs_adam_step_scheduled(int num_groups, const GsAdamGroup *groups, const float *rows_dev,
+                                      const int32_t *row_index_dev, int32_t num_rows,
+                                      const int32_t *guard_dev, int32_t guard_max, double beta1,
+                                      double beta2, double eps, gs_stream_t stream) {
+    using namespace gs;
+    if (num_groups < 0 || num_groups > GS_ADAM_MAX_GROUPS || num_rows < 1) return GS_ERR_INVALID_ARGUMENT;
+    if (!rows_dev || !row_index_dev) return GS_ERR_INVALID_ARGUMENT;
+    if (num_groups == 0) return GS_OK;
+    if (!groups) return GS_ERR_INVALID_ARGUMENT;
+    AdamArgs a = {};
+    int64_t chunks = 0;
+    const int rc = fill_adam_args(a, num_groups, groups, beta1, beta2, eps, chunks);
+    if (rc != GS_OK) return rc;
+    if (chunks == 0) return GS_OK;
+    const int64_t blocks = (chunks + 255) / 256;
+    if (blocks > 0x7fffffffLL) return GS_ERR_UNSUPPORTED;
+    GS_LAUNCH(k_adam_scheduled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, rows_dev,
+              row_index_dev, (int)num_rows, guard_dev, (int)guard_max);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" int gs_adam_advance(int32_t *row_index_dev, const int32_t *guard_dev, int32_t guard_max,
+                               gs_stream_t stream) {
+    if (!row_index_dev) return GS_ERR_INVALID_ARGUMENT;
+    GS_LAUNCH(gs::k_adam_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, row_index_dev, guard_dev,
+              (int)guard_max);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
 
 extern "C" int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t step, double beta1,
                             double beta2, double eps, gs_stream_t stream) {
@@ -94,32 +193,11 @@ extern "C" int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t s
     // libtorch computes the bias corrections in double and casts scalars to the tensors' float
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    a.num = num_groups;
-    a.beta1 = (float)beta1;
-    a.beta2 = (float)beta2;
-    a.omb1 = (float)(1.0 - beta1);
-    a.omb2 = (float)(1.0 - beta2);
-    a.bc2_sqrt = (float)sqrt(bc2);
-    a.eps = (float)eps;
     int64_t chunks = 0;
-    for (int i = 0; i < num_groups; i++) {
-        const GsAdamGroup &gr = groups[i];
-        if (gr.n < 0) return GS_ERR_INVALID_ARGUMENT;
-        if (gr.n > 0 && (!gr.param || !gr.grad || !gr.exp_avg || !gr.exp_avg_sq))
-            return GS_ERR_INVALID_ARGUMENT;
-        a.p[i] = gr.param;
-        a.g[i] = gr.grad;
-        a.m[i] = gr.exp_avg;
-        a.v[i] = gr.exp_avg_sq;
-        a.n[i] = gr.n;
-        a.neg_step_size[i] = (float)(-(gr.lr / bc1));
-        const uintptr_t bits = (uintptr_t)gr.param | (uintptr_t)gr.grad | (uintptr_t)gr.exp_avg |
-                               (uintptr_t)gr.exp_avg_sq;
-        if ((bits & 15u) == 0) a.aligned |= 1u << i;
-        a.chunk_start[i] = chunks;
-        chunks += (gr.n + 3) / 4;
-    }
-    for (int i = num_groups; i <= GS_ADAM_MAX_GROUPS; i++) a.chunk_start[i] = chunks;
+    const int rc = fill_adam_args(a, num_groups, groups, beta1, beta2, eps, chunks);
+    if (rc != GS_OK) return rc;
+    a.bc2_sqrt = (float)sqrt(bc2);
+    for (int i = 0; i < num_groups; i++) a.neg_step_size[i] = (float)(-(groups[i].lr / bc1));
     if (chunks == 0) return GS_OK;
     const int64_t blocks = (chunks + 255) / 256;
     if (blocks > 0x7fffffffLL) return GS_ERR_UNSUPPORTED;

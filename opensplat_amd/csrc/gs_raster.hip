@@ -92,10 +92,20 @@ struct __attribute__((aligned(16))) SRec {
 // (<= 1.5e-6 relative in vis at sigma = 5.5) and the roundings of the threshold itself.
 struct __attribute__((aligned(16))) SRecB {
     float4 p0, p1, p2;
-    float2 p3;
-    float2 pad;
+    float4 p3;   // {rx, ry, A, B}: read by the rare exact paths and by the flush
+    float4 p4;   // {C, -, -, -}
 };
-constexpr float kVisBand = 4.0e-6f;
+// GS_BWD_LOG2E (round 4): the staged record carries the conic and sigma_max multiplied by log2(e), so that the
+// per-pixel pass gets sigma' = sigma log2(e) straight from its two fused multiply-adds and the exponential is
+// ONE instruction (v_exp_f32 is 2^x: exp(-sigma) = 2^(-sigma')) instead of a multiply and v_exp_f32; the
+// original A, B, C sit in p3 / p4 for the exact re-evaluations and the flush.  The scaled entries are
+// rounded once (6e-8 relative): another <= 1e-6 relative in vis at sigma = 5.5, inside kVisBand's budget
+// (fast exponential 2^-21 = 4.8e-7, fused sigma 1.5e-6, the scaling 1e-6, the thresholds' own roundings).
+#ifndef GS_BWD_LOG2E
+#define GS_BWD_LOG2E 1
+#endif
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kVisBand = GS_BWD_LOG2E ? 5.0e-6f : 4.0e-6f;
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -457,11 +467,6 @@ constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_
 #ifndef GS_BWD_MFMA
 #define GS_BWD_MFMA 0
 #endif
-// 1: the two position gradients are formed per lane before the reduction (three more VALU per step, no
-// cancellation for needle-shaped Gaussians); 0: from the reduced moments at the flush (rounds 2-3)
-#ifndef GS_BWD_DIRECT_XY
-#define GS_BWD_DIRECT_XY 1
-#endif
 // One wave of the backward: the pixels [wx0, wx0 + WW) x [wy0, wy0 + WH) of `tile` (WaveGeom<PX>).  The
 // LDS arrays belong to the calling kernel (one wave per workgroup).
 template <bool EXACT, bool DET, int PX>
@@ -506,7 +511,8 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     // running <colour buffer, v_out> (one accumulator: the difference is what v_alpha needs),
     // cotangent, list index of the last contributor
     float pyf[PX], T[PX], D[PX], vo0[PX], vo1[PX], vo2[PX];
-    int last[PX];
+    int last[PX];   // list index of the pixel's last contributor; inside the chunk loop: RELATIVE to the
+                    // chunk (slot t has list index hi - t: it is needed iff t >= hi - last)
     int gl = -1;
 #pragma unroll
     for (int p = 0; p < PX; p++) {
@@ -574,7 +580,11 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
         }
 #endif
     }
+#pragma unroll
+    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p] + kChunk;   // (no contributor: beyond any slot)
     for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
+#pragma unroll
+        for (int p = 0; p < PX; p++) last[p] -= kChunk;   // now relative to this chunk's first slot
         __syncthreads();
         const uint32_t touch = ntouch;
         bool binds_t = false;   // this lane's entry needs the per-pixel rectangle test
@@ -587,10 +597,19 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 #endif
             // (an opacity <= 0 never reaches 1/255: threshold +inf)
             const float tv = n1.y > 0.0f ? (1.0f / 255.0f) / n1.y : __builtin_inff();
+#if GS_BWD_LOG2E
+            // (sigma_max keeps its flag bit; its +2e-3 of slack scales along)
+            const uint32_t sb = __float_as_uint(n1.z);
+            const float sm = __uint_as_float((__float_as_uint(__uint_as_float(sb & ~1u) * kLog2e) & ~1u) | (sb & 1u));
+            stage[lane].p0 = make_float4(n0.x, n0.y, n0.z * kLog2e, n0.w * kLog2e);
+            stage[lane].p1 = make_float4(n1.x * kLog2e, n1.y, sm, tv * (1.0f + kVisBand));
+#else
             stage[lane].p0 = n0;
             stage[lane].p1 = make_float4(n1.x, n1.y, n1.z, tv * (1.0f + kVisBand));
+#endif
             stage[lane].p2 = make_float4(n2.x, n2.y, n2.z, tv * (1.0f - kVisBand));
-            stage[lane].p3 = make_float2(n1.w, n2.w);
+            stage[lane].p3 = make_float4(n1.w, n2.w, n0.z, n0.w);
+            stage[lane].p4 = make_float4(n1.x, 0.0f, 0.0f, 0.0f);
             binds_t = (__float_as_uint(n1.z) & 1u) != 0u;
         }
         if (hi - lane >= range.x) sid[lane] = ng;
@@ -632,7 +651,6 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
                 { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
                 const uint32_t sbits = __float_as_uint(q1.z);
-                const int idx = hi - e;  // index of this entry in the sorted list
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
                 const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
@@ -653,21 +671,21 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                         asm volatile("; rectangle binds");
                         if (sbits & 1u) {
                             // decide exactly like the forward: its op order for sigma, rectangle applied
-                            float se = Adxdx + (q1.x * dy) * dy;
+                            const float4 q3 = stage[e].p3;
+                            float se = ((q3.z * dx) * dx) + (stage[e].p4.x * dy) * dy;
                             se = 0.5f * se;
-                            se = se + Bdx * dy;
-                            const float2 q3 = stage[e].p3;
+                            se = se + (q3.w * dx) * dy;
                             const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y);
                             const uint32_t pyu = (uint32_t)(py0 + p * G::LH);
                             const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
                                             pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
-                            sg = in ? se + 0.0f : qnan();
+                            sg = in ? (GS_BWD_LOG2E ? (se + 0.0f) * kLog2e : se + 0.0f) : qnan();
                         }
                     }
                     // lane masks are combined as 64-bit scalars (ballot of each compare, s_and) and turned
                     // back into a lane predicate with inverse_ballot: a ballot of `a && b` costs a
                     // v_cndmask + v_cmp pair per use
-                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(idx <= last[p]) &
+                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(e >= last[p]) &
                                            __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
                     if (mneed == 0ull) continue;
                     anym |= mneed;
@@ -676,7 +694,11 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                     // vis = exp(-sigma), alpha = min(0.99, opacity * vis), gsplat_cpu.cpp:337-338.  Lanes
                     // that do not need the entry keep whatever the exponential makes of their sigma
                     // (possibly inf or NaN) until `ok` discards it: they end with vis = alpha = 0
+#if GS_BWD_LOG2E
+                    float vis = __builtin_amdgcn_exp2f(-sg);   // sg = sigma log2(e)
+#else
                     float vis = __expf(-sg);
+#endif
                     uint64_t mok;
                     if (EXACT) {
                         // the forward's >= 1/255 decision, taken on vis against the entry's thresholds
@@ -689,9 +711,10 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                             asm volatile("; threshold ambiguous");
                             bool in = false;
                             if (__builtin_amdgcn_inverse_ballot_w64(mneed & blo & ~bhi)) {
-                                float se = Adxdx + (q1.x * dy) * dy;
+                                const float4 q3 = stage[e].p3;
+                                float se = ((q3.z * dx) * dx) + (stage[e].p4.x * dy) * dy;
                                 se = 0.5f * se;
-                                se = se + Bdx * dy;
+                                se = se + (q3.w * dx) * dy;
                                 vis = expf_glibc_cmem(-se);
                                 in = q1.y * vis >= (1.0f / 255.0f);
                             }
@@ -726,23 +749,14 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 if (anym == 0ull) continue;
                 // ---- the nine sums over the group's 16 lanes: lane c of the row ends up with total c ----
                 const float ux = su * dx;
-#if GS_BWD_DIRECT_XY
-                // v_x / v_y per LANE before the reduction: sum u (A dx + B dy) over the lane's pixels is
-                // (A dx) su + B suy.  Reducing the plain moments sum(u dx), sum(u dy) and forming
-                // A Ux + B Uy once per entry cancels catastrophically for needle-shaped Gaussians (conic
-                // nearly singular: A dx + B dy ~ 0 along the needle while u dx and u dy are large).
-                const float c0v = fmaf(q0.z * dx, su, q0.w * suy), c1v = fmaf(Bdx, su, q1.x * suy);
-#else
-                const float c0v = ux, c1v = suy;
-#endif
 #if GS_BWD_MFMA
-                const float r = mfma_reduce9(c0v, c1v, ux * dx, suy * dx, suyy, gr, gg, gb, su, onehot);
+                const float r = mfma_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, onehot);
                 const int er = (int)((ep >> rgsh) & 0xFFu);   // the entry of the group this lane reports
                 if (rcomp >= 0 && r != 0.0f && er < kChunk)  // (a group without work has nothing to add)
                     __hip_atomic_fetch_add(&acc[rcomp * kAccStride + er], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-                const float r = row_reduce9(c0v, c1v, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
+                const float r = row_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, odd, bit1);
                 if (rcomp >= 0 && r != 0.0f && e < kChunk)  // (a group without work has nothing to add)
                     __hip_atomic_fetch_add(&acc[rcomp * kAccStride + e], r, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -763,14 +777,9 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
             const float Uxx = acc[2 * kAccStride + lane], Uxy = acc[3 * kAccStride + lane];
             const float Uyy = acc[4 * kAccStride + lane];
             const float mo = -stage[lane].p1.y;          // v_sigma = -opacity * u
-#if GS_BWD_DIRECT_XY
-            acc[0 * kAccStride + lane] = mo * Ux;        // v_x: v_sigma * (A dx + B dy), summed per lane
-            acc[1 * kAccStride + lane] = mo * Uy;        // v_y: v_sigma * (B dx + C dy)
-#else
-            const float A = stage[lane].p0.z, B = stage[lane].p0.w, C = stage[lane].p1.x;
+            const float A = stage[lane].p3.z, B = stage[lane].p3.w, C = stage[lane].p4.x;
             acc[0 * kAccStride + lane] = mo * fmaf(A, Ux, B * Uy);   // v_x: v_sigma * (A dx + B dy)
             acc[1 * kAccStride + lane] = mo * fmaf(B, Ux, C * Uy);   // v_y: v_sigma * (B dx + C dy)
-#endif
             acc[2 * kAccStride + lane] = 0.5f * mo * Uxx;            // v_A  (gsplat_cpu.cpp:361-363)
             acc[3 * kAccStride + lane] = 0.5f * mo * Uxy;            // v_B
             acc[4 * kAccStride + lane] = 0.5f * mo * Uyy;            // v_C
