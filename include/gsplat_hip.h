@@ -197,6 +197,12 @@ int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
                 int32_t *num_isects_host /*pinned host int32[2], nullable*/, void *workspace,
                 size_t workspace_bytes, gs_stream_t stream);
 
+/* gs_bin_scan also leaves M on the DEVICE: one int32 at this byte offset inside its workspace (valid until the
+ * workspace is reused).  Kernels enqueued behind a speculative gs_bin_sort can compare it with the capacity
+ * they were given without the host in between — gs_adam_step_scheduled's guard (gsplat_train.h) does, so that
+ * a captured training iteration whose id list turned out too small changes nothing. */
+size_t gs_bin_num_isects_offset(int W, int H);
+
 /* Fills every tile's segment of gaussian_ids_sorted[capacity] with the ids of the Gaussians
  * overlapping the tile, ordered by `depths` (any finite float key sorts correctly; ties in
  * Gaussian-index order) — the result of the reference's global (tile | depth) sort + gather,

@@ -88,6 +88,15 @@ int gs_adam_step(int num_groups, const GsAdamGroup *groups, int64_t step, double
  * capacity: a step whose lists were truncated leaves parameters, moments and the row index untouched, and
  * the host, seeing the count afterwards, re-runs it with a larger list.  GsAdamGroup.lr is ignored here. */
 #define GS_ADAM_ROW_FLOATS (1 + GS_ADAM_MAX_GROUPS)
+/* Inputs of a captured iteration that change from replay to replay (the camera, which target image) are
+ * written by the host into PINNED, device-mapped memory and fetched by the graph's own first nodes:
+ *   gs_stage_f32          dst_dev[0..count) <- src_pinned_host[0..count)            (count <= 4096)
+ *   gs_copy_indirect_f32  dst_dev[0..count) <- (*src_ptr_pinned_host)[0..count): the pinned word holds the
+ *                         DEVICE address of the source (e.g. this iteration's ground-truth image)
+ * so that nothing but the graph launch itself is enqueued between the host's writes and the replay. */
+int gs_stage_f32(float *dst_dev, const float *src_pinned_host, int count, gs_stream_t stream);
+int gs_copy_indirect_f32(float *dst_dev, const float *const *src_ptr_pinned_host, int64_t count,
+                         gs_stream_t stream);
 int gs_adam_schedule_row(int num_groups, const double *lrs /* host */, int64_t step, double beta1,
                          double beta2, float *row /* host, GS_ADAM_ROW_FLOATS */);
 int gs_adam_step_scheduled(int num_groups, const GsAdamGroup *groups /* host */, const float *rows_dev,

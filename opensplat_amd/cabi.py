@@ -11,6 +11,7 @@ import ctypes as C
 import os
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 
 from . import _build
@@ -31,14 +32,15 @@ GS_CAM_LOG_SCALES = 1
 # every symbol include/gsplat_hip.h declares (tests check they are all exported)
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
-    "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan",
+    "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan", "gs_bin_num_isects_offset",
     "gs_bin_sort", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_timeline", "gs_debug_timeline_read", "gs_debug_row_reduce9", "gs_debug_group_reduce9", "gs_debug_backward_uses_mfma", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
 ]
 # every symbol include/gsplat_train.h declares
 TRAIN_SYMBOLS = ["gs_ssim_window", "gs_loss_workspace_bytes", "gs_main_loss", "gs_adam_step",
-                 "gs_adam_schedule_row", "gs_adam_step_scheduled", "gs_adam_advance", "gs_sched_lr"]
+                 "gs_adam_schedule_row", "gs_adam_step_scheduled", "gs_adam_advance", "gs_stage_f32",
+                 "gs_copy_indirect_f32", "gs_sched_lr"]
 # every symbol include/gsplat_densify.h declares
 DENSIFY_SYMBOLS = ["gs_densify_stats", "gs_densify_workspace_bytes", "gs_densify_plan",
                    "gs_densify_apply", "gs_reset_opacity"]
@@ -71,6 +73,7 @@ def lib() -> C.CDLL:
         l.gs_strerror.restype = C.c_char_p
         l.gs_last_hip_error.restype = C.c_char_p
         l.gs_bin_workspace_bytes.restype = C.c_size_t
+        l.gs_bin_num_isects_offset.restype = C.c_size_t
         l.gs_bin_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int]
         l.gs_rasterize_backward_workspace_bytes.restype = C.c_size_t
         l.gs_rasterize_backward_workspace_bytes.argtypes = [C.c_int]
@@ -542,6 +545,20 @@ def adam_step_scheduled(groups, rows_dev, row_index_dev, guard_dev=None, guard_m
 def adam_advance(row_index_dev, guard_dev=None, guard_max=0):
     _check(lib().gs_adam_advance(_p(row_index_dev), _p(guard_dev), C.c_int32(guard_max), _stream()),
            "gs_adam_advance")
+
+
+def stage_f32(dst_dev, src_pinned, count):
+    """dst_dev[:count] <- src_pinned[:count] by a kernel (graph-capturable); src_pinned: a pinned host tensor."""
+    assert dst_dev.is_cuda and src_pinned.is_pinned() and src_pinned.dtype == torch.float32
+    _check(lib().gs_stage_f32(_p(dst_dev), C.c_void_p(src_pinned.data_ptr()), C.c_int(count), _stream()),
+           "gs_stage_f32")
+
+
+def copy_indirect_f32(dst_dev, src_ptr_pinned, count):
+    """dst_dev[:count] <- the float array whose DEVICE address sits in src_ptr_pinned[0] (pinned int64 tensor)."""
+    assert dst_dev.is_cuda and src_ptr_pinned.is_pinned() and src_ptr_pinned.dtype == torch.int64
+    _check(lib().gs_copy_indirect_f32(_p(dst_dev), C.c_void_p(src_ptr_pinned.data_ptr()), C.c_int64(count),
+                                      _stream()), "gs_copy_indirect_f32")
 
 
 def sched_lr(lr_init, lr_final, max_steps, step):

@@ -15,6 +15,8 @@
 //   p = p + (-(lr / (1 - b1^t)) * m) / denom      p.addcdiv_(m, denom, -step_size)
 #include <math.h>
 
+#include <algorithm>
+
 #include "gs_device.h"
 #include "../../include/gsplat_train.h"
 
@@ -34,14 +36,17 @@ struct AdamArgs {
 };
 
 static __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float nss,
-                                             const AdamArgs &a) {
+                                             float bc2_sqrt, const AdamArgs &a) {
     m = fmaf(a.omb1, g, m * a.beta1);
     v = fmaf(a.omb2 * g, g, v * a.beta2);
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
     p = p + (nss * m) / denom;
 }
 
-static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
+// `row` (nullable): the per-step scalars {bc2_sqrt, neg_step_size[groups]} in device memory; NULL: those of
+// the argument block.  (The block itself is never written: a kernel that modifies its by-value argument
+// gets a private copy of all of it — 464 bytes of scratch per lane here.)
+static __device__ __forceinline__ void adam_chunk(const AdamArgs &a, const float *__restrict__ row) {
     const int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= a.chunk_start[a.num]) return;
     int grp = 0;
@@ -52,7 +57,8 @@ static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
     const int64_t n = a.n[grp];
     float *p = a.p[grp] + i0, *m = a.m[grp] + i0, *v = a.v[grp] + i0;
     const float *g = a.g[grp] + i0;
-    const float nss = a.neg_step_size[grp];
+    const float nss = row ? row[1 + grp] : a.neg_step_size[grp];
+    const float bc2 = row ? row[0] : a.bc2_sqrt;
     if (i0 + 4 <= n && ((a.aligned >> grp) & 1u)) {
         // streaming: every byte is touched once per step and the working set (1.65 GB at N = 1 M)
         // is far beyond any cache -> non-temporal loads and stores
@@ -64,7 +70,7 @@ static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
         float pe[4] = {P.x, P.y, P.z, P.w}, me[4] = {M.x, M.y, M.z, M.w}, ve[4] = {V.x, V.y, V.z, V.w};
         const float ge[4] = {G.x, G.y, G.z, G.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) adam1(pe[k], ge[k], me[k], ve[k], nss, a);
+        for (int k = 0; k < 4; k++) adam1(pe[k], ge[k], me[k], ve[k], nss, bc2, a);
         P.x = pe[0]; P.y = pe[1]; P.z = pe[2]; P.w = pe[3];
         M.x = me[0]; M.y = me[1]; M.z = me[2]; M.w = me[3];
         V.x = ve[0]; V.y = ve[1]; V.z = ve[2]; V.w = ve[3];
@@ -74,7 +80,7 @@ static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
     } else {
         for (int k = 0; k < 4 && i0 + k < n; k++) {
             float P = p[k], M = m[k], V = v[k];
-            adam1(P, g[k], M, V, nss, a);
+            adam1(P, g[k], M, V, nss, bc2, a);
             p[k] = P;
             m[k] = M;
             v[k] = V;
@@ -82,7 +88,7 @@ static __device__ __forceinline__ void adam_chunk(const AdamArgs &a) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_adam(AdamArgs a) { adam_chunk(a); }
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a) { adam_chunk(a, nullptr); }
 
 // The same update with the per-step scalars read from DEVICE memory (gs_adam_step_scheduled): row
 // *row_index of `rows` = {sqrt(1 - beta2^step), -(lr_g / (1 - beta1^step)) for every group}, written by the
@@ -95,11 +101,7 @@ k_adam_scheduled(AdamArgs a, const float *__restrict__ rows, const int32_t *__re
     if (guard && *guard > guard_max) return;
     const int r = *row_index;
     if (r < 0 || r >= num_rows) return;
-    const float *row = rows + (size_t)r * GS_ADAM_ROW_FLOATS;
-    a.bc2_sqrt = row[0];
-#pragma unroll
-    for (int i = 0; i < GS_ADAM_MAX_GROUPS; i++) a.neg_step_size[i] = row[1 + i];
-    adam_chunk(a);
+    adam_chunk(a, rows + (size_t)r * GS_ADAM_ROW_FLOATS);
 }
 
 __global__ void k_adam_advance(int32_t *__restrict__ row_index, const int32_t *__restrict__ guard,
@@ -139,6 +141,53 @@ static int fill_adam_args(AdamArgs &a, int num_groups, const GsAdamGroup *groups
 }
 
 }  // namespace gs
+
+namespace gs {
+// Staging inside a captured graph: what changes from replay to replay is written by the HOST into pinned,
+// device-mapped memory before the launch and fetched by the first nodes of the graph itself — no stream copy
+// stands between the host and the replay.
+__global__ void __launch_bounds__(64) k_stage_words(uint32_t *__restrict__ dst,
+                                                    const uint32_t *__restrict__ src_host, int n) {
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = src_host[i];
+}
+__global__ void __launch_bounds__(256) k_copy_indirect(float *__restrict__ dst,
+                                                       const float *const *__restrict__ src_ptr_host,
+                                                       int64_t n) {
+    const float *__restrict__ src = *src_ptr_host;   // (uniform: one scalar load of the pinned word)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int64_t i = t; i < n / 4; i += stride) d4[i] = s4[i];
+        for (int64_t i = (n / 4) * 4 + t; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = t; i < n; i += stride) dst[i] = src[i];
+    }
+}
+}  // namespace gs
+
+extern "C" int gs_stage_f32(float *dst_dev, const float *src_pinned_host, int count, gs_stream_t stream) {
+    if (count < 0 || count > 4096) return GS_ERR_INVALID_ARGUMENT;
+    if (count == 0) return GS_OK;
+    if (!dst_dev || !src_pinned_host) return GS_ERR_INVALID_ARGUMENT;
+    GS_LAUNCH(gs::k_stage_words, dim3(1), dim3(64), 0, (hipStream_t)stream,
+              reinterpret_cast<uint32_t *>(dst_dev), reinterpret_cast<const uint32_t *>(src_pinned_host), count);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
+
+extern "C" int gs_copy_indirect_f32(float *dst_dev, const float *const *src_ptr_pinned_host, int64_t count,
+                                    gs_stream_t stream) {
+    if (count < 0) return GS_ERR_INVALID_ARGUMENT;
+    if (count == 0) return GS_OK;
+    if (!dst_dev || !src_ptr_pinned_host) return GS_ERR_INVALID_ARGUMENT;
+    const int64_t blocks = std::min<int64_t>((count / 4 + 255) / 256 + 1, 2048);
+    GS_LAUNCH(gs::k_copy_indirect, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst_dev,
+              src_ptr_pinned_host, count);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+}
 
 extern "C" int gs_adam_schedule_row(int num_groups, const double *lrs, int64_t step, double beta1,
                                     double beta2, float *row) {

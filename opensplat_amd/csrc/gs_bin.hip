@@ -1002,6 +1002,11 @@ extern "C" size_t gs_bin_workspace_bytes(int N, int64_t num_isects, int W, int H
     return gs::bin_layout(N, num_isects, W, H).total;
 }
 
+extern "C" size_t gs_bin_num_isects_offset(int W, int H) {
+    if (W <= 0 || H <= 0) return 0;
+    return gs::bin_layout(0, 0, W, H).total_dev;
+}
+
 extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *tile_bins,
                            int32_t *tile_order, int32_t *num_isects_host, void *workspace,
                            size_t workspace_bytes, gs_stream_t stream) {

@@ -106,6 +106,17 @@ struct __attribute__((aligned(16))) SRecB {
 #endif
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kVisBand = GS_BWD_LOG2E ? 5.0e-6f : 4.0e-6f;
+// GS_BWD_SIGMA_THRESH (round 4, needs GS_BWD_LOG2E): the forward's alpha = o exp(-sigma) >= 1/255 decision is
+// taken on sigma' BEFORE the exponential, against the entry's own thresholds L' -+ kSigBand with
+// L' = log2(255 o) — one compare tells "possibly a contributor" (it replaces the sigma <= sigma_max filter:
+// the staged record's sigma_max IS L' + kSigBand), a second one "certainly"; between the two the pass redoes
+// the forward's exact arithmetic.  One compare and one scalar AND less per pass than deciding on vis.
+// Budget of the band, in sigma' units (sigma' <= 8): fused / scaled sigma' 3.6e-6, v_log_f32 of the
+// threshold 1e-6, the forward's own roundings (expf, the product, 1/255) 2e-7, the flag bit 1e-6.
+#ifndef GS_BWD_SIGMA_THRESH
+#define GS_BWD_SIGMA_THRESH GS_BWD_LOG2E
+#endif
+constexpr float kSigBand = 7.5e-6f;
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -598,11 +609,23 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
             // (an opacity <= 0 never reaches 1/255: threshold +inf)
             const float tv = n1.y > 0.0f ? (1.0f / 255.0f) / n1.y : __builtin_inff();
 #if GS_BWD_LOG2E
-            // (sigma_max keeps its flag bit; its +2e-3 of slack scales along)
             const uint32_t sb = __float_as_uint(n1.z);
+#if GS_BWD_SIGMA_THRESH
+            // L' -+ band; an opacity that cannot reach 1/255 at all gets the empty interval [0, 0]
+            float s_hi = 0.0f, s_lo = -1.0f;
+            if (n1.y > 0.0f) {
+                const float Lp = __builtin_amdgcn_logf(255.0f * n1.y);   // v_log_f32: log2
+                if (Lp + kSigBand >= 0.0f) { s_hi = Lp + kSigBand; s_lo = Lp - kSigBand; }
+            }
+            const float sm = __uint_as_float((__float_as_uint(s_hi) & ~1u) | (sb & 1u));
+            const float p1w = s_lo;
+#else
+            // (sigma_max keeps its flag bit; its +2e-3 of slack scales along)
             const float sm = __uint_as_float((__float_as_uint(__uint_as_float(sb & ~1u) * kLog2e) & ~1u) | (sb & 1u));
+            const float p1w = tv * (1.0f + kVisBand);
+#endif
             stage[lane].p0 = make_float4(n0.x, n0.y, n0.z * kLog2e, n0.w * kLog2e);
-            stage[lane].p1 = make_float4(n1.x * kLog2e, n1.y, sm, tv * (1.0f + kVisBand));
+            stage[lane].p1 = make_float4(n1.x * kLog2e, n1.y, sm, p1w);
 #else
             stage[lane].p0 = n0;
             stage[lane].p1 = make_float4(n1.x, n1.y, n1.z, tv * (1.0f + kVisBand));
@@ -701,13 +724,19 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 #endif
                     uint64_t mok;
                     if (EXACT) {
-                        // the forward's >= 1/255 decision, taken on vis against the entry's thresholds
-                        // (SRecB); inside the band the forward's own arithmetic is redone — its sigma,
+                        // the forward's >= 1/255 decision, taken against the entry's thresholds (SRecB) — on
+                        // sigma' (GS_BWD_SIGMA_THRESH: mneed already holds "possibly", q1.w is "certainly")
+                        // or on vis; inside the band the forward's own arithmetic is redone — its sigma,
                         // the exact exponential, alpha = o * vis — and decides
+#if GS_BWD_SIGMA_THRESH
+                        const uint64_t bhi = __builtin_amdgcn_ballot_w64(sg <= q1.w);
+                        const uint64_t blo = ~0ull;
+#else
                         const uint64_t bhi = __builtin_amdgcn_ballot_w64(vis >= q1.w);
                         const uint64_t blo = __builtin_amdgcn_ballot_w64(vis >= q2.w);
+#endif
                         mok = mneed & bhi;
-                        if (bhi != blo) {   // some lane sits in the band (one scalar compare when none does)
+                        if (GS_BWD_SIGMA_THRESH ? mok != mneed : bhi != blo) {   // some lane sits in the band
                             asm volatile("; threshold ambiguous");
                             bool in = false;
                             if (__builtin_amdgcn_inverse_ballot_w64(mneed & blo & ~bhi)) {
