@@ -275,7 +275,13 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                                  C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
             if w.scan_done is None:
                 w.scan_done = torch.cuda.Event()
-            w.scan_done.record()   # validate_binning waits for THIS, not for the whole stream
+            # validate_binning waits for THIS, not for the whole stream.  (Not while the stream is being
+            # captured: an event recorded inside a graph cannot be waited for outside it, and replaying a
+            # graph that holds the record node after the event has been recorded eagerly again — a render()
+            # between two replays — ended in GPU memory faults on ROCm 7.0; a captured iteration is validated
+            # from the pinned count once the replay has completed, train.py.)
+            if not torch.cuda.is_current_stream_capturing():
+                w.scan_done.record()
             _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
                                  _p(depths), _p(tile_bins), _p(ids), _p(masks), w.list_stats, _p(ws),
                                  C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")

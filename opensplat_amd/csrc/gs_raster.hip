@@ -16,9 +16,8 @@
 // in an exponential pass.  Here a wave owns 2 x 2 BLOCKS of pixels (WaveGeom: 4x4
 // blocks with one pixel per lane in the forward; 8x8 blocks with FOUR pixels per lane in the backward,
 // one wave per tile — 4x8 / 4x4 blocks with two / one pixel per lane on frames that do not fill the chip
-// and for tiles with outlying lists), each block belongs to one 16-lane group (forward: a DPP row;
-// backward: one quad out of each DPP row, the lanes a v_mfma_f32_16x16x4_f32 sums), and each group walks ITS OWN
-// list: the entries of the staged chunk whose (tightened) rectangle touches that block.  The four
+// and for tiles with outlying lists), each block belongs to one 16-lane group (a DPP row), and each group
+// walks ITS OWN list: the entries of the staged chunk whose coverage mask touches that block.  The four
 // groups execute one instruction stream on four different Gaussians:
 //   * per chunk of 64 list entries (staged by the wave itself: lane t gathers entry t, the next
 //     chunk's gather is in flight while the current one is consumed), four ballots give four
@@ -39,16 +38,18 @@
 //     automatically shared by several waves, tiles are launched longest list first;
 //   * a pixel that is skipped gets alpha = 0, which composites exactly nothing — no per-pixel
 //     branches; saturation (once per pixel and frame) is a wave-uniform rare path;
-//   * backward: the exponential is v_exp_f32, with the exact fp64 evaluation re-run only for
-//     lanes whose alpha lies within 2.5e-6 (relative) of the 1/255 threshold, so the decision
-//     equals the forward's (decided on vis against per-entry thresholds staged once per chunk, SRecB);
-//     1/(1-alpha) is v_rcp_f32 alone (T is a running product either way); the running colour
-//     buffer is tracked as its dot product with the pixel's cotangent; the moments sum(u),
-//     sum(u dy), sum(u dy^2) are accumulated over a lane's pixels (they share xCam);
-//   * the nine partial sums are reduced over the group's 16 lanes on the MATRIX pipe (mfma_reduce9: nine
-//     v_mfma_f32_16x16x4_f32 with one-hot B columns + three additions; the DPP butterfly row_reduce9 of
-//     rounds 2-3 stays selectable, GS_BWD_MFMA=0), added to per-entry accumulators in LDS (ds_add_f32),
-//     converted from moments to (v_x, v_y, v_A, v_B, v_C) once per entry and flushed once per
+//   * backward: the staged record carries the conic times log2(e), so sigma' = sigma log2(e) comes
+//     straight out of two fused multiply-adds and the exponential is ONE v_exp_f32; the forward's
+//     alpha >= 1/255 decision is taken on sigma' BEFORE the exponential against the entry's own
+//     thresholds log2(255 o) -+ 7.5e-6 (staged once per chunk, SRecB), and only lanes between the two
+//     redo the forward's exact arithmetic (its sigma, the glibc-exact fp64 exponential), so the decision
+//     equals the forward's; 1/(1-alpha) is v_rcp_f32 alone (T is a running product either way); the
+//     running colour buffer is tracked as its dot product with the pixel's cotangent; the moments
+//     sum(u), sum(u dy), sum(u dy^2) are accumulated over a lane's pixels (they share xCam);
+//   * the nine partial sums are reduced over the group's 16 lanes in registers by a transposing DPP
+//     butterfly (row_reduce9, 21 VALU; the same sums on the matrix pipe — mfma_reduce9, GS_BWD_MFMA=1 —
+//     measured 0.40 against 0.29 ms at C2 and stay a build option), added to per-entry accumulators in
+//     LDS (ds_add_f32), converted from moments to (v_x, v_y, v_A, v_B, v_C) once per entry and flushed once per
 //     chunk with one atomic lane per (entry, component): a Gaussian costs one global atomic
 //     line-request per wave it contributes to (its nine lanes hit ONE 64-byte record).
 //

@@ -25,8 +25,6 @@ optimiser-state surgery and the alpha reset, all on the device (include/gsplat_d
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 import torch
 
@@ -75,7 +73,7 @@ class Trainer:
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
                  reference_alpha_reset: bool = False, grad_buckets: int = 4, exchange: str = "auto",
-                 graph: bool = False, deterministic: bool = False):
+                 deterministic: bool = False):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -134,22 +132,9 @@ class Trainer:
         assert exchange in ("auto", "flat", "factored")
         self.factored = exchange == "factored" or (exchange == "auto" and 1 < self.world <= 32)
         self.fx = None
-        # graph=True (one rank): train_step replays the whole iteration — per-Gaussian forward, binning,
-        # compositing, loss, both backward kernels, Adam — as ONE captured HIP graph per (image size, Gaussian
-        # buffers, SH degree, id-list capacity); see _train_step_graph.  The iteration of a small frame is ~25
-        # launches of a few microseconds each and launch-bound; replayed it is not.
         # deterministic=True: the compositing backward sums in 64-bit fixed point (GS_FLAG_DETERMINISTIC):
         # bit-reproducible gradients, hence bit-reproducible training (tests compare whole runs)
         self.deterministic = bool(deterministic)
-        self.graph = bool(graph) and self.world == 1
-        if self.graph and reference_alpha_reset:
-            raise ValueError("graph=True keeps one optimiser step count for all groups: not with "
-                             "reference_alpha_reset (the opacities' Adam state lags behind there)")
-        self._graphs = {}
-        self._buf_gen = 0            # bumped whenever a device buffer a captured graph points at is replaced
-        self._g_rows = None          # device table of the per-step Adam scalars (gs_adam_step_scheduled)
-        self._g_rows_first = 0       # optimiser step of row 0
-        self.graph_stats = dict(captures=0, replays=0, eager=0, overflows=0)
 
     def degrees_to_use(self, step: int) -> int:
         """model.cpp:178: one more SH degree every sh_degree_interval steps."""
@@ -197,16 +182,6 @@ class Trainer:
                                    dtype=torch.uint8)
         self.loss_out = (torch.empty(3, **f), torch.empty((H, W, 3), **f))
         self._shape = (W, H)
-        self._buf_gen += 1
-        self._graphs.clear()
-        if self.graph:
-            # what changes from step to step sits in device memory a captured launch reads through a fixed
-            # pointer: [viewmat 16 | projmat 16 | camera centre 3 | -] and the ground-truth image
-            self._g_cam = torch.zeros(36, **f)
-            self._g_cam_host = torch.zeros(36, dtype=torch.float32).pin_memory()
-            self._g_gt = torch.empty((H, W, 3), **f)
-            self._g_gt_ptr = torch.zeros(1, dtype=torch.int64).pin_memory()   # device address of the target
-            self._g_done = torch.cuda.Event()
 
     def render(self, cam: dict, background, degrees_to_use: int):
         """Model::forward (model.cpp:83-225) for one camera -> clamped rgb [H, W, 3]."""
@@ -314,141 +289,9 @@ class Trainer:
         self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps,
                                       self.step_count)
 
-    # ---- the iteration as one captured HIP graph (graph=True) ---------------------------------------
-    ADAM_ROWS = 2048
-
-    def _adam_lrs(self, step: int):
-        """Learning rates of optimiser step `step` (1-based), in adam_groups() order: the means' follows
-        the schedule — optimizer_step() sets it from the number of steps already taken (model.cpp:245-247)."""
-        lr = dict(self.LR, means=cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps, step - 1)
-                  if step > 1 else self.LR["means"])
-        order = ["features_rest", "features_dc", "means", "scales", "quats", "opacities"]
-        if self.K == 1:
-            order = order[1:]
-        return [lr[n] for n in order]
-
-    def _ensure_adam_rows(self):
-        """The device table holds the scalars of steps [first, first + ADAM_ROWS); row index (device) = steps
-        taken since `first`.  Refilled — between iterations, stream-ordered — when the next step runs off it."""
-        nxt = self.step_count + 1
-        if self._g_rows is not None and self._g_rows_first <= nxt < self._g_rows_first + self.ADAM_ROWS:
-            return
-        rows = cabi.adam_schedule_rows([self._adam_lrs(nxt + r) for r in range(self.ADAM_ROWS)], nxt)
-        if self._g_rows is None:
-            self._g_rows = torch.empty((self.ADAM_ROWS, cabi.GS_ADAM_ROW_FLOATS), device=self.dev,
-                                       dtype=torch.float32)
-            self._g_row_index = torch.zeros(1, device=self.dev, dtype=torch.int32)
-        self._g_rows.copy_(torch.from_numpy(rows))       # (synchronising copy: once per ADAM_ROWS steps)
-        self._g_row_index.zero_()
-        self._g_rows_first = nxt
-
-    def _iteration_launches(self, gcam, deg, background, W, H):
-        """Every launch of one training iteration, on the current stream, reading the camera and the target
-        from the fixed device buffers: what the graph captures and what a first (or repeated) step runs
-        eagerly.  The Adam step is guarded by the intersection count the scan left on the device."""
-        flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
-        c = self._g_cam
-        # the iteration's own first nodes fetch what the host left in pinned memory: the camera block and the
-        # target image (through its device address).  (Staging them with stream copies in front of the replay —
-        # `static.copy_(x); graph.replay()` — ended in GPU memory faults after a few dozen replays on ROCm 7.0 /
-        # torch 2.10: scripts/debug/graph_train_cases.py, profiles/HISTORY.md.)
-        cabi.stage_f32(c, self._g_cam_host, 36)
-        cabi.copy_indirect_f32(self._g_gt, self._g_gt_ptr, H * W * 3)
-        vm, pm, pos = c[0:16], c[16:32], c[32:35]
-        p = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
-                                  self.features_dc, self.features_rest if self.K > 1 else None, pos, deg,
-                                  flags, out=self.proj, viewmat_dev=vm, projmat_dev=pm)
-        b = cabi.bin_and_sort(W, H, None, p["depths"], None, None, None, None, None, self.bin_ws,
-                              speculative=True, packed=p["packed"])
-        f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
-        loss, v_rgb = cabi.main_loss(f["img_clamped"], self._g_gt, self.ssim_weight, 1.0, True,
-                                     out=self.loss_out, workspace=self.loss_ws)
-        cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
-                                flags | cabi.GS_FLAG_KEEP_RECORDS |
-                                (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0),
-                                workspace=self.bwd_ws, img_raw=f["img"])
-        cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits, pos,
-                               self.K, deg, p["radii"], p["rgb_raw"], self.bwd_ws, self.gout, flags,
-                               v_xy=self.v_xy, viewmat_dev=vm, projmat_dev=pm)
-        off = cabi.lib().gs_bin_num_isects_offset(W, H)
-        guard = self.bin_ws.bufs["ws"][off:off + 4].view(torch.int32)
-        groups = [g[:5] for g in self.adam_groups()]
-        cabi.adam_step_scheduled(groups, self._g_rows, self._g_row_index, guard, b.capacity)
-        cabi.adam_advance(self._g_row_index, guard, b.capacity)
-        return p, b, f, loss, flags
-
-    def _train_step_graph(self, cam: dict, gt, background, degrees_to_use: int):
-        W, H = cam["W"], cam["H"]
-        self._buffers(W, H)
-        self._ensure_adam_rows()
-        vm = np.asarray(cam["viewmat"], dtype=np.float32)
-        h = self._g_cam_host.numpy()
-        h[0:16] = vm.reshape(-1)
-        h[16:32] = np.asarray(cam["projmat"], dtype=np.float32).reshape(-1)
-        h[32:35] = -vm[:3, :3].T @ vm[:3, 3]                      # model.cpp:95
-        # (the previous iteration has completed — we waited for it below — so the pinned words are free)
-        assert gt.is_cuda and gt.is_contiguous() and gt.dtype == torch.float32 and tuple(gt.shape) == (H, W, 3)
-        self._g_gt_ptr[0] = gt.data_ptr()
-        self._g_gt_ref = gt          # (alive until the iteration that reads it has completed)
-        # intrinsics and sizes are kernel ARGUMENTS (captured by value): part of the key; the matrices the
-        # struct carries are ignored in favour of the device copies
-        gcam = cabi.make_camera(np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32), cam["fx"], cam["fy"],
-                                cam["cx"], cam["cy"], W, H, flags=cabi.GS_CAM_LOG_SCALES)
-        bgk = tuple(float(x) for x in np.asarray(background).reshape(-1))
-        while True:
-            key = (self._buf_gen, degrees_to_use, float(cam["fx"]), float(cam["fy"]), float(cam["cx"]),
-                   float(cam["cy"]), bgk, self.bin_ws.capacity, self._opacity_frozen)
-            hit = self._graphs.get(key)
-            if hit is None:
-                # first iteration under this key: run it launch by launch; capture the same launches for the
-                # following ones (a capture executes nothing)
-                p, b, f, loss, flags = self._iteration_launches(gcam, degrees_to_use, background, W, H)
-                self.graph_stats["eager"] += 1
-            else:
-                graph, (p, b, f, loss, flags) = hit
-                # whatever the caller enqueued since the last iteration (afterTrain's statistics kernel, torch
-                # operators building the next target, a refinement) has to be DONE before the replay: a graph
-                # launched behind stream work still in flight is what the faults of profiles/HISTORY.md
-                # ("Round 4: the training iteration as one captured HIP graph") came from
-                torch.cuda.current_stream().synchronize()
-                graph.replay()
-                self.graph_stats["replays"] += 1
-            self._g_done.record()
-            self._g_done.synchronize()
-            M, longest = int(b.m_host[0]), int(b.m_host[1])
-            b.num_isects = M
-            b.workspace.list_stats[0], b.workspace.list_stats[1] = M, longest
-            if M > b.capacity:
-                # the id list was too small: the guard kept Adam and the row index from moving; grow the
-                # list (a new key: the old graph is dropped with its buffers) and repeat the iteration
-                self.graph_stats["overflows"] += 1
-                self.bin_ws.capacity = M + M // 8 + 1024
-                self._graphs.pop(key, None)
-                continue
-            break
-        if hit is None and self.bin_ws.capacity == b.capacity:
-            if len(self._graphs) >= 8:
-                self._graphs.clear()
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(g, stream=side):
-                objs = self._iteration_launches(gcam, degrees_to_use, background, W, H)
-            torch.cuda.current_stream().wait_stream(side)
-            self._graphs[key] = (g, objs)
-            self.graph_stats["captures"] += 1
-        self.step_count += 1
-        self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps, self.step_count)
-        self._visible = M > 0
-        cam_pos = h[32:35].copy()
-        self._ctx = (gcam, cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
-        return loss
-
     def train_step(self, cam: dict, gt, background, degrees_to_use: int):
         """One iteration of opensplat.cpp:151-170 for this rank's camera of the batch.
         Returns the device tensor {mainLoss, l1, ssim} of THIS camera (no host sync)."""
-        if self.graph:
-            return self._train_step_graph(cam, gt, background, degrees_to_use)
         rgb = self.render(cam, background, degrees_to_use)
         loss, v_rgb = cabi.main_loss(rgb, gt, self.ssim_weight, 1.0 / self.world, True,
                                      out=self.loss_out, workspace=self.loss_ws)
@@ -537,5 +380,4 @@ class Trainer:
         self.N = counts["new_n"]
         self.grads = dist.GradBuffer(self.N, self.K, self.dev)
         self._shape = None               # per-N render buffers are rebuilt on the next render
-        self._graphs.clear()             # (captured graphs point at the replaced buffers)
         return counts

@@ -61,8 +61,6 @@ def main():
                     help="write the capture as a COLMAP project (sparse/0/*.bin + images/*.npy) and train "
                          "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
                          "Model-style initialisation from the sparse points (row f3)")
-    ap.add_argument("--graph", action="store_true",
-                    help="Trainer(graph=True): every iteration replayed as one captured HIP graph")
     a = ap.parse_args()
     rs = np.random.RandomState(0)
     K, W, H = 16, a.width, a.height
@@ -102,8 +100,7 @@ def main():
     # --resolution-schedule 3000) are meant for 30 000 iterations
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
                       morton_order=True, sh_degree_interval=max(a.iters // 4, 1),
-                      num_downscales=a.num_downscales, resolution_schedule=max(a.iters // 6, 1),
-                      graph=a.graph)
+                      num_downscales=a.num_downscales, resolution_schedule=max(a.iters // 6, 1))
     sh_interval = T.sh_degree_interval
 
     def reduced(cam, f):
@@ -182,7 +179,6 @@ def main():
            "input": "COLMAP project on disk (opensplat_amd.colmap)" if a.via_colmap else "in-memory capture",
            "psnr_curve": curve, "refinements": refinements, "final_gaussians": T.N,
            "train_seconds": train_time, "iterations_per_s": a.iters / train_time,
-           "captured_iterations": T.graph_stats if a.graph else None,
            "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,
            "ply_round_trip_renders_identically": same}
 

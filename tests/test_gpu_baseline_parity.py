@@ -23,7 +23,7 @@ chain: the device projection differs from the oracle's by fp32 round-off (xys 2e
 can flip an alpha >= 1/255 or T <= 1e-4 decision for a handful of pixels: at most max(4, 2e-5 P)
 pixels may differ by more than 1e-5, and every gradient tensor must satisfy
 max|d| / max|ref| < 2e-5 (measured: 0 flipped pixels and 3e-7 .. 2e-6 on every configuration,
-profiles/parity_r02.json; the tests rewrite gpurun_out/parity_r02.json).
+profiles/parity_r04.json; the tests rewrite gpurun_out/parity_r04.json).
 """
 import json
 import os
@@ -45,7 +45,7 @@ def _report(name, **kv):
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "parity_r02.json"), "w") as f:
+        with open(os.path.join(d, "parity_r04.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
