@@ -2,7 +2,7 @@
 # One complete evidence run for a round: -m gpu suite, bench lines (C2 default incl. cpu_baseline, C3,
 # fast-exp, moving camera, hot spot, 2 ranks over gloo on the one GPU), work counters, rocprofv3 passes.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -148,3 +148,23 @@ def test_deterministic_training_is_bit_reproducible():
     assert na == nb and len(na) >= 2, (na, nb)          # refinements happened, identically
     assert a.N == b.N and a.step_count == b.step_count == 40
     assert _same(_params(a), _params(b))
+
+
+def test_scan_leaves_the_intersection_count_on_the_device():
+    """gs_bin_num_isects_offset: the int32 the scan kernel leaves in its workspace is the count it also stores
+    in pinned host memory — what a guard of gs_adam_step_scheduled compares with the id list's capacity."""
+    import torch
+
+    from opensplat_amd import cabi, scenes
+    from tests.util import hip_pipeline
+
+    for W, H, N in ((160, 96, 1500), (400, 240, 20000)):
+        s = scenes.camera_scene(N, W, H, K=0, seed=7, znear=1.0, zfar=100.0)
+        p = hip_pipeline(s, backward=False)
+        ws = cabi.BinWorkspace()
+        b = cabi.bin_and_sort(W, H, p["xys"], p["depths"], p["radii"], p["conics"], p["colors"],
+                              torch.as_tensor(s.opacities.reshape(-1)).cuda(), p["cov2d"], ws, speculative=True)
+        torch.cuda.synchronize()
+        off = cabi.lib().gs_bin_num_isects_offset(W, H)
+        on_device = int(ws.bufs["ws"][off:off + 4].view(torch.int32).item())
+        assert on_device == int(b.m_host[0]) == p["binned"].num_isects > 0
