@@ -157,7 +157,11 @@ def main():
     ap.add_argument("--out", help="write the patched files here instead of editing in place")
     ap.add_argument("--cmake", action="store_true", help="print the CMakeLists.txt snippet and exit")
     ap.add_argument("--fused", action="store_true",
-                    help="also patch model.cpp onto SplatRender / MainLoss / the fused Adam step / densify")
+                    help="also patch model.cpp onto SplatRender / MainLoss / the fused Adam step / densify "
+                         "(NB: by default the alpha reset keeps the opacities trainable — the evident intent — "
+                         "where the reference freezes them until the next refinement: trajectories differ from "
+                         "the first reset on; build with -DGS_FUSED_REFERENCE_ALPHA_RESET for the reference's "
+                         "behaviour, INTEGRATION.md §7)")
     a = ap.parse_args()
     if a.cmake or not a.checkout:
         print(CMAKE_SNIPPET)

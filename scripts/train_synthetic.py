@@ -61,6 +61,13 @@ def main():
                     help="write the capture as a COLMAP project (sparse/0/*.bin + images/*.npy) and train "
                          "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
                          "Model-style initialisation from the sparse points (row f3)")
+    ap.add_argument("--reference-schedules", action="store_true",
+                    help="the reference's CLI defaults as they are (--sh-degree-interval 1000, "
+                         "--resolution-schedule 3000: what `opensplat -n 7000` runs) instead of schedules "
+                         "scaled to the run's length")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="also time the reference's own CPU chain (oracle/_ref) on one iteration of the initial "
+                         "set at every resolution of the schedule, and extrapolate the run")
     a = ap.parse_args()
     rs = np.random.RandomState(0)
     K, W, H = 16, a.width, a.height
@@ -98,9 +105,11 @@ def main():
         init = colmap.init_from_points(data.points_xyz, data.points_rgb, sh_degree=3)
     # schedules scaled to the run: the CLI defaults (--sh-degree-interval 1000, --num-downscales 2,
     # --resolution-schedule 3000) are meant for 30 000 iterations
+    sched = dict(sh_degree_interval=1000, resolution_schedule=3000) if a.reference_schedules else \
+        dict(sh_degree_interval=max(a.iters // 4, 1), resolution_schedule=max(a.iters // 6, 1))
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
-                      morton_order=True, sh_degree_interval=max(a.iters // 4, 1),
-                      num_downscales=a.num_downscales, resolution_schedule=max(a.iters // 6, 1))
+                      morton_order=True, num_downscales=a.num_downscales, **sched)
+    n_initial = T.N
     sh_interval = T.sh_degree_interval
 
     def reduced(cam, f):
@@ -178,11 +187,53 @@ def main():
                        f"{a.iters} iterations with the reference's densification defaults",
            "input": "COLMAP project on disk (opensplat_amd.colmap)" if a.via_colmap else "in-memory capture",
            "psnr_curve": curve, "refinements": refinements, "final_gaussians": T.N,
+           "schedules": "reference CLI defaults" if a.reference_schedules else "scaled to the run",
+           "initial_gaussians": n_initial,
            "train_seconds": train_time, "iterations_per_s": a.iters / train_time,
            "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,
            "ply_round_trip_renders_identically": same}
 
+    if a.cpu_baseline:
+        out["cpu_baseline"] = cpu_iterations(init, cams[0], W, H, a, T)
     print(json.dumps(out))
+
+
+def cpu_iterations(init, cam, W, H, a, T):
+    """The reference's own CPU chain (oracle/_ref: ProjectGaussiansCPU -> SphericalHarmonicsCPU ->
+    RasterizeGaussiansCPU forward + backward, then ssim.cpp's loss) on ONE iteration of the initial point set at
+    each resolution the schedule visits; the run's CPU time is extrapolated from the iterations spent at each
+    (lower bound: the set grows, the optimiser and afterTrain are not counted)."""
+    import oracle
+
+    if not oracle.have_reference():
+        return {"error": "oracle/_ref is not built"}
+    R = oracle.reference()
+    means, ls, q, lo, dc, rest = [np.asarray(x, np.float32) for x in init]
+    vm = np.asarray(cam["viewmat"], np.float32)
+    cam_pos = (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)
+    dirs = means - cam_pos
+    dirs = (dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).astype(np.float32)
+    coeffs = np.concatenate([dc[:, None, :], rest], 1)
+    res, total = {}, 0.0
+    for f in sorted({T.downscale_factor(s) for s in range(1, a.iters + 1)}, reverse=True):
+        Wc, Hc = int(W / f), int(H / f)
+        fovx, fovy = 2.0 * math.atan(Wc / (2.0 * cam["fx"] / f)), 2.0 * math.atan(Hc / (2.0 * cam["fy"] / f))
+        pm = (scenes.projection_matrix(0.001, 1000.0, fovx, fovy) @ vm).astype(np.float32)
+        v = np.random.RandomState(2).uniform(-1e-4, 1e-4, (Hc, Wc, 3)).astype(np.float32)
+        r = R.chain_fwd_bwd(means, np.exp(ls), q / np.linalg.norm(q, axis=1, keepdims=True), dirs, coeffs,
+                            (1 / (1 + np.exp(-lo))).astype(np.float32), vm, pm, cam["fx"] / f,
+                            cam["fy"] / f, cam["cx"] / f, cam["cy"] / f, Hc, Wc, np.zeros(3, np.float32), v,
+                            degrees_to_use=3)
+        x, y = scenes.loss_images(Wc, Hc, seed=2)
+        R.main_loss(x, y, 0.2)
+        n_it = sum(1 for s in range(1, a.iters + 1) if T.downscale_factor(s) == f)
+        sec = (r["fwd_ms"] + r["bwd_ms"] + R.last_ms) / 1e3
+        res["%dx%d" % (Wc, Hc)] = {"iterations": n_it, "render_fwd_bwd_s": (r["fwd_ms"] + r["bwd_ms"]) / 1e3,
+                                   "main_loss_s": R.last_ms / 1e3}
+        total += n_it * sec
+    return {"kind": "reference", "cores": os.cpu_count(), "gaussians": int(means.shape[0]),
+            "per_resolution": res, "extrapolated_run_seconds_lower_bound": total,
+            "sample": "one iteration (render forward + backward + loss) of the INITIAL point set per resolution"}
 
 
 if __name__ == "__main__":
