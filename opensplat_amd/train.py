@@ -73,7 +73,7 @@ class Trainer:
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
                  reference_alpha_reset: bool = False, grad_buckets: int = 4, exchange: str = "auto",
-                 deterministic: bool = False):
+                 deterministic: bool = False, graph: bool = False):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
@@ -135,6 +135,19 @@ class Trainer:
         # deterministic=True: the compositing backward sums in 64-bit fixed point (GS_FLAG_DETERMINISTIC):
         # bit-reproducible gradients, hence bit-reproducible training (tests compare whole runs)
         self.deterministic = bool(deterministic)
+        # graph=True (one rank): train_step replays the whole iteration — per-Gaussian forward, binning,
+        # compositing, loss, both backward kernels, Adam — as ONE captured HIP graph per (buffers, SH degree,
+        # intrinsics, id-list capacity) on a stream of its own; see _train_step_graph.
+        self.graph = bool(graph) and self.world == 1
+        if self.graph and reference_alpha_reset:
+            raise ValueError("graph=True keeps one optimiser step count for all groups: not with "
+                             "reference_alpha_reset (the opacities' Adam state lags behind there)")
+        self._graphs = {}
+        self._buf_gen = 0            # bumped whenever a device buffer a captured graph points at is replaced
+        self._g_rows = None          # device table of the per-step Adam scalars (gs_adam_step_scheduled)
+        self._g_rows_first = 0       # optimiser step of row 0
+        self._g_stream = None        # the replays' own stream: nothing else is ever enqueued on it
+        self.graph_stats = dict(captures=0, replays=0, eager=0, overflows=0)
 
     def degrees_to_use(self, step: int) -> int:
         """model.cpp:178: one more SH degree every sh_degree_interval steps."""
@@ -182,6 +195,22 @@ class Trainer:
                                    dtype=torch.uint8)
         self.loss_out = (torch.empty(3, **f), torch.empty((H, W, 3), **f))
         self._shape = (W, H)
+        self._buf_gen += 1
+        self._graphs.clear()
+        if self.graph:
+            # what changes from step to step is written by the host into pinned memory and fetched by the
+            # graph's own first nodes: [viewmat 16 | projmat 16 | camera centre 3 | -] and the ADDRESS of the
+            # ground-truth image
+            self._g_cam = torch.zeros(36, **f)
+            self._g_cam_host = torch.zeros(36, dtype=torch.float32).pin_memory()
+            self._g_cam_np = self._g_cam_host.numpy()
+            self._g_gt = torch.empty((H, W, 3), **f)
+            self._g_gt_ptr = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._g_gt_ptr_np = self._g_gt_ptr.numpy()
+            self._g_mhost_np = self.bin_ws.m_host.numpy()
+            self._g_done = torch.cuda.Event()
+            if self._g_stream is None:
+                self._g_stream = torch.cuda.Stream()
 
     def render(self, cam: dict, background, degrees_to_use: int):
         """Model::forward (model.cpp:83-225) for one camera -> clamped rgb [H, W, 3]."""
@@ -289,9 +318,154 @@ class Trainer:
         self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps,
                                       self.step_count)
 
-    def train_step(self, cam: dict, gt, background, degrees_to_use: int):
+    # ---- the iteration as one captured HIP graph (graph=True) ---------------------------------------
+    ADAM_ROWS = 2048
+
+    class PreparedCamera:
+        """What a replayed iteration needs of a camera, computed once: the 36-float block the graph's first
+        node fetches ([viewmat | projmat | centre | -]), the intrinsics (kernel ARGUMENTS, hence part of the
+        capture key) and the host-side GsCamera of the launches."""
+
+        def __init__(self, cam: dict):
+            vm = np.asarray(cam["viewmat"], dtype=np.float32)
+            self.W, self.H = int(cam["W"]), int(cam["H"])
+            self.block = np.zeros(36, np.float32)
+            self.block[0:16] = vm.reshape(-1)
+            self.block[16:32] = np.asarray(cam["projmat"], dtype=np.float32).reshape(-1)
+            self.block[32:35] = -vm[:3, :3].T @ vm[:3, 3]                      # model.cpp:95
+            self.cam_pos = self.block[32:35].copy()
+            self.intr = (float(cam["fx"]), float(cam["fy"]), float(cam["cx"]), float(cam["cy"]), self.W, self.H)
+            # (the matrices the struct carries are ignored in favour of the device copies)
+            eye = np.eye(4, dtype=np.float32)
+            self.gcam = cabi.make_camera(eye, eye, cam["fx"], cam["fy"], cam["cx"], cam["cy"], self.W, self.H,
+                                         flags=cabi.GS_CAM_LOG_SCALES)
+
+    def prepare_camera(self, cam) -> "Trainer.PreparedCamera":
+        return cam if isinstance(cam, Trainer.PreparedCamera) else Trainer.PreparedCamera(cam)
+
+    def _adam_lrs(self, step: int):
+        """Learning rates of optimiser step `step` (1-based), in adam_groups() order: the means' follows
+        the schedule — optimizer_step() sets it from the number of steps already taken (model.cpp:245-247)."""
+        lr = dict(self.LR, means=cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps, step - 1)
+                  if step > 1 else self.LR["means"])
+        order = ["features_rest", "features_dc", "means", "scales", "quats", "opacities"]
+        if self.K == 1:
+            order = order[1:]
+        return [lr[n] for n in order]
+
+    def _ensure_adam_rows(self):
+        """The device table holds the scalars of steps [first, first + ADAM_ROWS); row index (device) = steps
+        taken since `first`.  Refilled — between iterations — when the next step runs off it."""
+        nxt = self.step_count + 1
+        if self._g_rows is not None and self._g_rows_first <= nxt < self._g_rows_first + self.ADAM_ROWS:
+            return
+        rows = cabi.adam_schedule_rows([self._adam_lrs(nxt + r) for r in range(self.ADAM_ROWS)], nxt)
+        if self._g_rows is None:
+            self._g_rows = torch.empty((self.ADAM_ROWS, cabi.GS_ADAM_ROW_FLOATS), device=self.dev,
+                                       dtype=torch.float32)
+            self._g_row_index = torch.zeros(1, device=self.dev, dtype=torch.int32)
+        self._g_rows.copy_(torch.from_numpy(rows))       # (synchronising copy: once per ADAM_ROWS steps)
+        self._g_row_index.zero_()
+        torch.cuda.synchronize()
+        self._g_rows_first = nxt
+
+    def _iteration_launches(self, gcam, deg, background, W, H):
+        """Every launch of one training iteration, on the current stream, reading the camera and the target
+        through the pinned words: what the graph captures and what a first (or repeated) step runs
+        eagerly.  The Adam step is guarded by the intersection count the scan left on the device."""
+        flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
+        c = self._g_cam
+        cabi.stage_f32(c, self._g_cam_host, 36)
+        cabi.copy_indirect_f32(self._g_gt, self._g_gt_ptr, H * W * 3)
+        vm, pm, pos = c[0:16], c[16:32], c[32:35]
+        p = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
+                                  self.features_dc, self.features_rest if self.K > 1 else None, pos, deg,
+                                  flags, out=self.proj, viewmat_dev=vm, projmat_dev=pm)
+        b = cabi.bin_and_sort(W, H, None, p["depths"], None, None, None, None, None, self.bin_ws,
+                              speculative=True, packed=p["packed"])
+        f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
+        loss, v_rgb = cabi.main_loss(f["img_clamped"], self._g_gt, self.ssim_weight, 1.0, True,
+                                     out=self.loss_out, workspace=self.loss_ws)
+        cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
+                                flags | cabi.GS_FLAG_KEEP_RECORDS |
+                                (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0),
+                                workspace=self.bwd_ws, img_raw=f["img"])
+        cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits, pos,
+                               self.K, deg, p["radii"], p["rgb_raw"], self.bwd_ws, self.gout, flags,
+                               v_xy=self.v_xy, viewmat_dev=vm, projmat_dev=pm)
+        off = cabi.lib().gs_bin_num_isects_offset(W, H)
+        guard = self.bin_ws.bufs["ws"][off:off + 4].view(torch.int32)
+        groups = [g[:5] for g in self.adam_groups()]
+        cabi.adam_step_scheduled(groups, self._g_rows, self._g_row_index, guard, b.capacity)
+        cabi.adam_advance(self._g_row_index, guard, b.capacity)
+        return p, b, f, loss, flags
+
+    def _train_step_graph(self, cam, gt, background, degrees_to_use: int):
+        pc = self.prepare_camera(cam)
+        W, H = pc.W, pc.H
+        self._buffers(W, H)
+        self._ensure_adam_rows()
+        # (the previous iteration has completed — we waited for it below — so the pinned words are free)
+        self._g_cam_np[:] = pc.block
+        self._g_gt_ptr_np[0] = gt.data_ptr()
+        self._g_gt_ref = gt          # (alive until the iteration that reads it has completed)
+        bgk = background.tobytes() if isinstance(background, np.ndarray) else tuple(float(x) for x in background)
+        mh = self._g_mhost_np
+        while True:
+            key = (self._buf_gen, degrees_to_use, pc.intr, bgk, self.bin_ws.capacity)
+            hit = self._graphs.get(key)
+            if hit is None:
+                # first iteration under this key: run it launch by launch on the caller's stream; the same
+                # launches are captured for the following ones (a capture executes nothing)
+                p, b, f, loss, flags = self._iteration_launches(pc.gcam, degrees_to_use, background, W, H)
+                self.graph_stats["eager"] += 1
+                self._g_done.record()
+            else:
+                graph, (p, b, f, loss, flags) = hit
+                # The replays run on a stream of their own, behind whatever the caller's stream holds (a
+                # render for evaluation, afterTrain's statistics kernel, a refinement) — graphs replayed on
+                # the stream that also carried such eager launches ended in GPU memory faults on ROCm 7.0
+                # (profiles/HISTORY.md)
+                gs = self._g_stream
+                gs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(gs):
+                    graph.replay()
+                    self._g_done.record()
+                self.graph_stats["replays"] += 1
+            self._g_done.synchronize()
+            M, longest = int(mh[0]), int(mh[1])
+            b.num_isects = M
+            ls = b.workspace.list_stats
+            ls[0], ls[1] = M, longest
+            if M > b.capacity:
+                # the id list was too small: the guard kept Adam and the row index from moving; grow the
+                # list (a new key: the old graph is dropped) and repeat the iteration
+                self.graph_stats["overflows"] += 1
+                self.bin_ws.capacity = M + M // 8 + 1024
+                self._graphs.pop(key, None)
+                continue
+            break
+        if hit is None and self.bin_ws.capacity == b.capacity:
+            if len(self._graphs) >= 8:
+                self._graphs.clear()
+            g = torch.cuda.CUDAGraph()
+            self._g_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=self._g_stream):
+                objs = self._iteration_launches(pc.gcam, degrees_to_use, background, W, H)
+            torch.cuda.current_stream().wait_stream(self._g_stream)
+            self._graphs[key] = (g, objs)
+            self.graph_stats["captures"] += 1
+        self.step_count += 1
+        self.means_lr = cabi.sched_lr(self.LR["means"], self.MEANS_LR_FINAL, self.max_steps, self.step_count)
+        self._visible = M > 0
+        self._ctx = (pc.gcam, pc.cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
+        return loss
+
+    def train_step(self, cam, gt, background, degrees_to_use: int):
         """One iteration of opensplat.cpp:151-170 for this rank's camera of the batch.
         Returns the device tensor {mainLoss, l1, ssim} of THIS camera (no host sync)."""
+        if self.graph:
+            return self._train_step_graph(cam, gt, background, degrees_to_use)
         rgb = self.render(cam, background, degrees_to_use)
         loss, v_rgb = cabi.main_loss(rgb, gt, self.ssim_weight, 1.0 / self.world, True,
                                      out=self.loss_out, workspace=self.loss_ws)
@@ -380,4 +554,5 @@ class Trainer:
         self.N = counts["new_n"]
         self.grads = dist.GradBuffer(self.N, self.K, self.dev)
         self._shape = None               # per-N render buffers are rebuilt on the next render
+        self._graphs.clear()             # (captured graphs point at the replaced buffers)
         return counts

@@ -61,6 +61,8 @@ def main():
                     help="write the capture as a COLMAP project (sparse/0/*.bin + images/*.npy) and train "
                          "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
                          "Model-style initialisation from the sparse points (row f3)")
+    ap.add_argument("--graph", action="store_true",
+                    help="Trainer(graph=True): every iteration replayed as one captured HIP graph")
     ap.add_argument("--reference-schedules", action="store_true",
                     help="the reference's CLI defaults as they are (--sh-degree-interval 1000, "
                          "--resolution-schedule 3000: what `opensplat -n 7000` runs) instead of schedules "
@@ -108,7 +110,7 @@ def main():
     sched = dict(sh_degree_interval=1000, resolution_schedule=3000) if a.reference_schedules else \
         dict(sh_degree_interval=max(a.iters // 4, 1), resolution_schedule=max(a.iters // 6, 1))
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
-                      morton_order=True, num_downscales=a.num_downscales, **sched)
+                      morton_order=True, num_downscales=a.num_downscales, graph=a.graph, **sched)
     n_initial = T.N
     sh_interval = T.sh_degree_interval
 
@@ -123,7 +125,7 @@ def main():
         c["projmat"] = (scenes.projection_matrix(0.001, 1000.0, fovx, fovy) @ cam["viewmat"]).astype(np.float32)
         return c
 
-    pyramid = {}
+    pyramid, prepared = {}, {}
 
     def target(ci, f):
         """Camera::getImage(downscaleFactor) (input_data.cpp:96-114): area-averaged pyramid, cached."""
@@ -151,7 +153,12 @@ def main():
         ci = int(order.randint(0, n_train))
         deg = T.degrees_to_use(step)             # model.cpp:178
         f = T.downscale_factor(step)             # model.cpp:249-251
-        loss = T.train_step(reduced(cams[ci], f), target(ci, f), bg, deg)
+        if a.graph:     # (the 36-float camera block and the GsCamera of a (camera, scale) pair, made once)
+            if (ci, f) not in prepared:
+                prepared[(ci, f)] = T.prepare_camera(reduced(cams[ci], f))
+            loss = T.train_step(prepared[(ci, f)], target(ci, f), bg, deg)
+        else:
+            loss = T.train_step(reduced(cams[ci], f), target(ci, f), bg, deg)
         if step % max(a.iters // 6, 1) == 0:
             last_loss = [float(x) for x in loss.cpu()]   # before a refinement reallocates buffers
         c = T.after_train(step)
@@ -188,6 +195,7 @@ def main():
            "input": "COLMAP project on disk (opensplat_amd.colmap)" if a.via_colmap else "in-memory capture",
            "psnr_curve": curve, "refinements": refinements, "final_gaussians": T.N,
            "schedules": "reference CLI defaults" if a.reference_schedules else "scaled to the run",
+           "captured_iterations": T.graph_stats if a.graph else None,
            "initial_gaussians": n_initial,
            "train_seconds": train_time, "iterations_per_s": a.iters / train_time,
            "ply_bytes": size, "splat_bytes": splat_size, "ply_round_trip_step": step_loaded,

@@ -7,10 +7,8 @@
   * Trainer(deterministic=True): the compositing backward sums in fixed point, so two whole training runs —
     refinements, SH-degree and resolution changes included — leave the SAME BITS in every parameter.
 
-(Round 4 also replayed the whole iteration as one captured graph on top of these — bit for bit equal to
-launch-by-launch training in this file's scenes — and took it out again: it only wins on frames of a few
-dozen tiles and faulted in long runs on ROCm 7.0 whenever eager work touched the same buffers between two
-replays; profiles/HISTORY.md)
+(The whole iteration replayed as one captured graph on top of these: Trainer(graph=True),
+tests/test_gpu_train_graph.py.)
 """
 import math
 import os
