@@ -95,7 +95,7 @@ const char *gs_last_hip_error(void); /* thread-local text of the last failing HI
  * argument list (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0: round 4).  A consumer
  * compiled against another header must refuse the library instead of calling through shifted arguments:
  * opensplat_amd/cabi.py and libgsplat_torch.so compare gs_version() with this constant when they load. */
-#define GS_ABI_VERSION 400
+#define GS_ABI_VERSION 401
 int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 
 /* ---------------------------------------------------------------------------------------------
@@ -301,6 +301,44 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const int32_t *list_stats /*host int32[2], nullable*/,
                           const int32_t *tile_order /*device [tiles], nullable*/, uint32_t flags,
                           gs_stream_t stream);
+
+/* Frames of few tiles (at most 1280: the reduced resolutions OpenSplat's resolution schedule starts a run
+ * with, model.cpp:85-92; small captures): four waves per tile cannot fill the chip, the launch lasts as long
+ * as one wave needs for the LONGEST list.  No counterpart in the reference, which gives a tile's list to
+ * one workgroup (forward.cu:256-378, backward.cu:161-355).  Two things help, both scheduling only:
+ *  - the forward takes two list entries per step on such frames (same bits; chosen by itself);
+ *  - the backward can start anywhere in a list if it is handed the state in front of that entry.  With a
+ *    checkpoint buffer the forward stores {T, r, g, b} per pixel every `seg_len` entries of a tile's list
+ *    (and the final state), and the backward runs every piece of every list as a wave of its own; the
+ *    pieces of a Gaussian's gradient meet in its record with the same atomics as the tiles' always did
+ *    (sums differ by their order, as between any two runs).  A piece starts from the forward's own
+ *    transmittance product instead of the product of reciprocals the one-pass backward (and
+ *    gsplat_cpu.cpp:337-345) unwinds to there: the two differ by the rounding of that unwinding.
+ * gs_rasterize_checkpoint_plan: from the scan's {M, longest list} of the previous frame (host, nullable)
+ *   -> seg_len (a power of two >= 64), max_segments, bytes of the buffer; bytes = 0: not worthwhile (frame
+ *   of many tiles, no statistics yet, short lists) — call the plain entry points.  A list that outgrows
+ *   the plan is finished by its last piece.
+ * gs_rasterize_forward_ckpt / gs_rasterize_backward_ckpt: the entry points above + the buffer (16-byte
+ *   aligned, >= tiles * max_segments * 4096 bytes; NULL: exactly the plain call).  The backward must be
+ *   given the buffer, seg_len and max_segments its forward wrote with. */
+int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_stats /*host int32[2], nullable*/,
+                                 int32_t *seg_len, int32_t *max_segments, size_t *bytes);
+int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_ids_sorted,
+                              const uint16_t *block_masks, const int32_t *tile_bins, const float *packed,
+                              const float *background, float *out_img, float *final_Ts,
+                              int32_t *final_idx, float *out_img_clamped, const int32_t *list_stats,
+                              const int32_t *tile_order, uint32_t flags, void *checkpoints,
+                              size_t checkpoint_bytes, int32_t seg_len, int32_t max_segments,
+                              gs_stream_t stream);
+int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+                               const uint16_t *block_masks, const int32_t *tile_bins, const float *packed,
+                               const float *background, const float *final_Ts, const int32_t *final_idx,
+                               const float *v_out, const float *v_out_alpha, const float *out_img,
+                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                               void *workspace, size_t workspace_bytes, const int32_t *list_stats,
+                               const int32_t *tile_order, uint32_t flags, const void *checkpoints,
+                               size_t checkpoint_bytes, int32_t seg_len, int32_t max_segments,
+                               gs_stream_t stream);
 
 /* Test hook: y[i] = the exponential exactly as the compositing kernels evaluate it (glibc-bit-exact
  * by default, hardware v_exp_f32 with GS_FLAG_FAST_EXP); valid for |x| < 87. */

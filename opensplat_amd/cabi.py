@@ -18,7 +18,7 @@ from . import _build
 
 GS_TILE = 16
 GS_SPLAT_DWORDS = 12
-GS_ABI_VERSION = 400   # include/gsplat_hip.h
+GS_ABI_VERSION = 401   # include/gsplat_hip.h
 GS_FLAG_FAST_EXP = 1
 GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
@@ -33,7 +33,8 @@ GS_CAM_LOG_SCALES = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan", "gs_bin_num_isects_offset",
-    "gs_bin_sort", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
+    "gs_bin_sort", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_checkpoint_plan", "gs_rasterize_forward_ckpt",
+    "gs_rasterize_backward_ckpt", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_timeline", "gs_debug_timeline_read", "gs_debug_row_reduce9", "gs_debug_group_reduce9", "gs_debug_backward_uses_mfma", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
 ]
@@ -322,25 +323,66 @@ def validate_binning(b: Binned) -> bool:
     return True
 
 
-def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None):
+class Checkpoints:
+    """The compositing forward's per-pixel state every `seg_len` entries of a tile's list, from which the
+    backward runs every piece of a list as a wave of its own (frames of few tiles; gsplat_hip.h:
+    gs_rasterize_checkpoint_plan).  `plan` sizes the buffer from the previous frame's {M, longest list} and
+    says whether the frame is worth it; the same object goes to rasterize_forward and rasterize_backward."""
+
+    def __init__(self):
+        self.buf = None
+        self.seg_len = 0
+        self.max_segments = 0
+        self.bytes = 0
+
+    def plan(self, W, H, list_stats, device, seg_len=None, max_segments=None):
+        """True if the next forward / backward pair should be given this object.  seg_len / max_segments
+        override the library's choice (tests, measurements)."""
+        sl, ms, nb = C.c_int32(0), C.c_int32(0), C.c_size_t(0)
+        _check(lib().gs_rasterize_checkpoint_plan(C.c_int(W), C.c_int(H), list_stats, C.byref(sl), C.byref(ms),
+                                                  C.byref(nb)), "gs_rasterize_checkpoint_plan")
+        env = os.environ.get("GSPLAT_SEG_LEN")   # measurements: another piece length than the library's
+        if env and seg_len is None and nb.value:
+            seg_len = int(env)
+            max_segments = (int(list_stats[1]) * 5 // 4 + seg_len - 1) // seg_len + 1
+        if seg_len is not None:
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            sl.value, ms.value = seg_len, max_segments
+            nb.value = tiles * max_segments * 4096
+        self.seg_len, self.max_segments, self.bytes = sl.value, ms.value, nb.value
+        if self.bytes == 0:
+            return False
+        if self.buf is None or self.buf.numel() < self.bytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty((self.bytes + self.bytes // 4,), device=device, dtype=torch.uint8)
+        return True
+
+    def args(self):
+        return _p(self.buf), C.c_size_t(self.buf.numel()), C.c_int32(self.seg_len), C.c_int32(self.max_segments)
+
+
+_NO_CHECKPOINTS = (None, C.c_size_t(0), C.c_int32(0), C.c_int32(0))
+
+
+def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None, checkpoints=None):
     dev = binned.packed.device
     if out is None:
         out = dict(img=torch.empty((H, W, 3), device=dev, dtype=torch.float32),
                    final_Ts=torch.empty((H, W), device=dev, dtype=torch.float32),
                    final_idx=torch.empty((H, W), device=dev, dtype=torch.int32))
     bg = _vec3(background)
-    _check(lib().gs_rasterize_forward(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
-                                      _p(binned.block_masks), _p(binned.tile_bins),
-                                      _p(binned.packed), bg, _p(out["img"]),
-                                      _p(out["final_Ts"]), _p(out["final_idx"]),
-                                      _p(out.get("img_clamped")), getattr(binned, "list_stats", None),
-                                      _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
-                                      _stream()), "gs_rasterize_forward")
+    ck = checkpoints.args() if checkpoints is not None else _NO_CHECKPOINTS
+    _check(lib().gs_rasterize_forward_ckpt(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
+                                           _p(binned.block_masks), _p(binned.tile_bins),
+                                           _p(binned.packed), bg, _p(out["img"]),
+                                           _p(out["final_Ts"]), _p(out["final_idx"]),
+                                           _p(out.get("img_clamped")), getattr(binned, "list_stats", None),
+                                           _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
+                                           *ck, _stream()), "gs_rasterize_forward")
     return out
 
 
 def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx, v_out, flags=0,
-                       v_out_alpha=None, out=None, workspace=None, img_raw=None):
+                       v_out_alpha=None, out=None, workspace=None, img_raw=None, checkpoints=None):
     dev = binned.packed.device
     if flags & GS_FLAG_KEEP_RECORDS:   # gradients stay in the workspace records (gaussian_backward)
         out = dict(v_xy=None, v_conic=None, v_colors=None, v_opacity=None)
@@ -353,7 +395,8 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
     bg = _vec3(background)
-    _check(lib().gs_rasterize_backward(C.c_int(W), C.c_int(H), C.c_int(N),
+    ck = checkpoints.args() if checkpoints is not None else _NO_CHECKPOINTS
+    _check(lib().gs_rasterize_backward_ckpt(C.c_int(W), C.c_int(H), C.c_int(N),
                                        _p(binned.gaussian_ids_sorted), _p(binned.block_masks),
                                        _p(binned.tile_bins),
                                        _p(binned.packed), bg, _p(final_Ts), _p(final_idx), _p(v_out),
@@ -362,7 +405,7 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
                                        C.c_size_t(workspace.numel()),
                                        getattr(binned, "list_stats", None),
                                        _p(getattr(binned, "tile_order", None)), C.c_uint32(flags),
-                                       _stream()),
+                                       *ck, _stream()),
            "gs_rasterize_backward")
     return out
 

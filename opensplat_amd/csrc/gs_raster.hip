@@ -202,7 +202,11 @@ __device__ __forceinline__ void stage_sentinel(R *s) {
 constexpr uint32_t kWalkDone = 0x40404040u;   // the packed word of four exhausted groups (slot kChunk = 64)
 
 // ---------------------------------------------------------------------------------------------
-template <bool EXACT>
+// ILP: entries of a group's list taken per step (1: full frames; 2: frames of few tiles, see walk2).
+// ckpt (nullable): per tile max_seg records of 256 pixels {T, r, g, b} — record k >= 1 is the state in front
+// of entry range.x + (k << seg_shift) of the tile's list, record 0 the final state: what the segmented
+// backward (k_rasterize_backward_seg) starts a piece of a list from.
+template <bool EXACT, int ILP>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                     const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
@@ -210,7 +214,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                     const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
                     const float *__restrict__ bg_dev, float *__restrict__ out_img,
                     float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
-                    float *__restrict__ out_clamped) {
+                    float *__restrict__ out_clamped, float4 *__restrict__ ckpt, int seg_shift,
+                    int max_seg) {
     __shared__ SRec stage[kChunk + 1];
     __shared__ uint64_t exp_tab[EXACT ? kExpTabLds : 1];
     const int lane = threadIdx.x;
@@ -247,9 +252,16 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
         }
     }
+    // the lane's pixel inside its tile, row-major: the index of a checkpoint record
+    const int pid = ((py & (GS_TILE - 1)) << 4) | (px & (GS_TILE - 1));
+    if (ckpt) ckpt += (size_t)tile * max_seg * (GS_TILE * GS_TILE) + pid;
     for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
         const uint64_t alive = __builtin_amdgcn_ballot_w64(pyf == pyf);
         if (alive == 0ull) break;
+        if (ckpt && c0 != range.x && ((c0 - range.x) & ((1 << seg_shift) - 1)) == 0) {
+            const int k = (c0 - range.x) >> seg_shift;
+            if (k < max_seg && inimg) ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T, a0, a1, a2);
+        }
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
         const uint32_t touch = ntouch;
         if (touch) {
@@ -337,7 +349,91 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             le = ok ? e : le;
           }
         };
-        if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
+        // Two entries of a group's list per step: the second entry's sigma / exponential / alpha do not
+        // depend on the first one's compositing, so the two chains overlap in ONE wave's instruction
+        // stream — what the other waves of a SIMD do for a full frame and nobody does on a frame of a few
+        // hundred tiles, where a lone wave pays the full latency of every dependent step (measured 170 ns
+        // per step against 40 ns of issue, profiles/timeline_sweep_*_r04.json).  The compositing itself
+        // stays in list order (a, then b with the transmittance a leaves), so the bits are the same.
+        auto walk2 = [&](auto binds_tag) {
+          constexpr bool BINDS = decltype(binds_tag)::value;
+          uint32_t epa_next, epb_next;
+          { GS_WALK_PACK(wa0_) epa_next = wa0_; }
+          { GS_WALK_PACK(wb0_) epb_next = wb0_; }
+          while (epa_next != kWalkDone) {   // (slot a exhausted: slot b too)
+            const int ea = (int)((epa_next >> gsh) & 0xFFu), eb = (int)((epb_next >> gsh) & 0xFFu);
+            const float4 qa0 = stage[ea].p0, qa1 = stage[ea].p1, qa2 = stage[ea].p2;
+            const float4 qb0 = stage[eb].p0, qb1 = stage[eb].p1, qb2 = stage[eb].p2;
+            { GS_WALK_PACK(wa1_) epa_next = wa1_; }
+            { GS_WALK_PACK(wb1_) epb_next = wb1_; }
+            asm volatile("" : "+s"(epa_next), "+s"(epb_next));
+            const uint32_t sba = __float_as_uint(qa1.z), sbb = __float_as_uint(qb1.z);
+            GS_STAT(0, 1);
+            const float dxa = qa0.x - pxf, dya = qa0.y - pyf, dxb = qb0.x - pxf, dyb = qb0.y - pyf;
+            float sga = (qa0.z * dxa) * dxa + (qa1.x * dya) * dya;
+            float sgb = (qb0.z * dxb) * dxb + (qb1.x * dyb) * dyb;
+            sga = 0.5f * sga;
+            sgb = 0.5f * sgb;
+            sga = sga + (qa0.w * dxa) * dya;
+            sgb = sgb + (qb0.w * dxb) * dyb;
+            const uint64_t mbinds = BINDS ? __builtin_amdgcn_ballot_w64(((sba | sbb) & 1u) != 0u) : 0ull;
+            if (BINDS && mbinds != 0ull) {
+                asm volatile("; rectangle binds");
+                if (sba & 1u) {
+                    const uint32_t rx = __float_as_uint(qa1.w), ry = __float_as_uint(qa2.w);
+                    const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                    (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
+                    sga = in ? sga + 0.0f : qnan();
+                }
+                if (sbb & 1u) {
+                    const uint32_t rx = __float_as_uint(qb1.w), ry = __float_as_uint(qb2.w);
+                    const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                    (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
+                    sgb = in ? sgb + 0.0f : qnan();
+                }
+            }
+            const uint64_t mna = __builtin_amdgcn_ballot_w64(__float_as_uint(sga) <= sba);
+            const uint64_t mnb = __builtin_amdgcn_ballot_w64(__float_as_uint(sgb) <= sbb);
+            if ((mna | mnb) == 0ull) continue;
+            GS_STAT(1, 1);
+            GS_STAT(2, __builtin_popcountll(mna) + __builtin_popcountll(mnb));
+            const float visa = gs_exp<EXACT>(-sga, exp_tab);
+            const float visb = gs_exp<EXACT>(-sgb, exp_tab);
+            float aa = __builtin_amdgcn_fmed3f(qa1.y * visa, 0.0f, 0.999f);
+            float ab = __builtin_amdgcn_fmed3f(qb1.y * visb, 0.0f, 0.999f);
+            bool oka = __builtin_amdgcn_inverse_ballot_w64(
+                mna & __builtin_amdgcn_ballot_w64(aa >= (1.0f / 255.0f)));
+            bool okb = __builtin_amdgcn_inverse_ballot_w64(
+                mnb & __builtin_amdgcn_ballot_w64(ab >= (1.0f / 255.0f)));
+            aa = oka ? aa : 0.0f;
+            ab = okb ? ab : 0.0f;
+            float nTa = T * (1.0f - aa);
+            float nTb = nTa * (1.0f - ab);
+            if (__builtin_amdgcn_ballot_w64(nTa <= 1e-4f || nTb <= 1e-4f) != 0ull) {
+                asm volatile("; pixel saturates");
+                if (nTa <= 1e-4f) {          // a finishes the pixel: neither a nor b is rendered
+                    pyf = qnan(); aa = 0.0f; ab = 0.0f; nTa = T; nTb = T; oka = false; okb = false;
+                } else if (nTb <= 1e-4f) {   // b finishes it: a is rendered, b is not
+                    pyf = qnan(); ab = 0.0f; nTb = nTa; okb = false;
+                }
+            }
+            const float wa = aa * T;
+            a0 = a0 + wa * qa2.x;
+            a1 = a1 + wa * qa2.y;
+            a2 = a2 + wa * qa2.z;
+            const float wb = ab * nTa;
+            a0 = a0 + wb * qb2.x;
+            a1 = a1 + wb * qb2.y;
+            a2 = a2 + wb * qb2.z;
+            T = nTb;
+            le = okb ? eb : (oka ? ea : le);
+          }
+        };
+        if constexpr (ILP == 2) {
+            if (chunk_binds) walk2(std::true_type{}); else walk2(std::false_type{});
+        } else {
+            if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
+        }
         last = le >= 0 ? c0 + le : last;
         le = -1;
     }
@@ -354,6 +450,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         }
         final_Ts[pix] = T;
         final_idx[pix] = last;
+        if (ckpt) ckpt[0] = make_float4(T, a0, a1, a2);
     }
 }
 
@@ -481,7 +578,14 @@ constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_
 #endif
 // One wave of the backward: the pixels [wx0, wx0 + WW) x [wy0, wy0 + WH) of `tile` (WaveGeom<PX>).  The
 // LDS arrays belong to the calling kernel (one wave per workgroup).
-template <bool EXACT, bool DET, int PX>
+// A piece [lo, hi) of a tile's list for the segmented backward (SEG): front = the forward's checkpoint record
+// of the state in front of entry hi (null: hi is the end of the list), final_ = record 0 (the final state).
+struct ListPiece {
+    int lo, hi;
+    const float4 *front, *final_;
+};
+
+template <bool EXACT, bool DET, int PX, bool SEG = false>
 __device__ __forceinline__ void
 backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__restrict__ sid,
               float *__restrict__ acc, int W, int H, const int32_t *__restrict__ ids,
@@ -490,7 +594,8 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
               const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
               const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
               const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-              float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+              float *__restrict__ gacc, unsigned long long *__restrict__ gfix,
+              const ListPiece piece = ListPiece{0, 0, nullptr, nullptr}) {
     using G = WaveGeom<PX>;
     const int lane = threadIdx.x;
     if (bg_dev) {
@@ -549,6 +654,21 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
         pyf[p] = (float)py;
         T[p] = Tfin;
         D[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
+        if (SEG) {
+            // the pixel's part of this piece of the list: nothing (its last contributor lies in front of
+            // the piece), from its last contributor down (which lies inside), or — the list goes on behind
+            // the piece — from the piece's last entry with the state the forward left in front of entry hi:
+            // that transmittance, and the colour composited behind it (final - front) taken off D
+            if (last[p] < piece.lo) {
+                last[p] = -1;
+            } else if (last[p] >= piece.hi) {
+                const int pid = ((py & (GS_TILE - 1)) << 4) | (px & (GS_TILE - 1));
+                const float4 cf = piece.front[pid], ce = piece.final_[pid];
+                T[p] = cf.x;
+                D[p] = D[p] - ((ce.y - cf.y) * vo0[p] + (ce.z - cf.z) * vo1[p] + (ce.w - cf.w) * vo2[p]);
+                last[p] = piece.hi - 1;
+            }
+        }
         gl = max(gl, last[p]);
     }
     // last contributor of each block (one group of lanes) and of the wave
@@ -568,7 +688,8 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     const int gl2 = __builtin_amdgcn_readlane(gl, 32), gl3 = __builtin_amdgcn_readlane(gl, 48);
 #endif
     const int wave_last = max(max(gl0, gl1), max(gl2, gl3));
-    const int2 range = bins[tile];
+    int2 range = bins[tile];
+    if (SEG) range.x = piece.lo;      // (a piece ends where the walk does: at its first entry)
     if (wave_last < range.x) return;  // (also covers empty tiles / no contributors)
 
     if (lane == 0) stage_sentinel(&stage[kChunk]);
@@ -914,6 +1035,50 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
     backward_wave<EXACT, DET, 4>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
                                  bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
 }
+// Frames of few tiles (the reduced resolutions a training run starts with, small captures): four waves per
+// tile leave most of the chip's wave slots empty, and a lone wave issues one instruction every four cycles
+// whatever it is — the launch lasts as long as the LONGEST list takes one wave (170 - 200 ns per entry,
+// profiles/timeline_sweep_*_r04.json).  The backward, unlike the forward, can start anywhere in a list if
+// it is handed the state in front of that entry: the forward stores it (a checkpoint record per pixel every
+// 1 << seg_shift entries, k_rasterize_forward), and here every piece of every list is a wave of its own —
+// tile-major (the pieces of a tile on one XCD), longest list first.  The pieces of a Gaussian's gradient meet
+// in its record like the tiles' always did.  (The reference walks a tile's list in one workgroup,
+// backward.cu:217-353; its transmittance recurrence is the one of backward_wave.)
+template <bool EXACT, bool DET>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward_seg(int W, int H, int tiles_x, int num_tiles, int seg_shift, int max_seg,
+                         const float4 *__restrict__ ckpt, const int32_t *__restrict__ order,
+                         const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
+                         const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0,
+                         float bg1, float bg2, const float *__restrict__ bg_dev,
+                         const float *__restrict__ final_Ts, const int32_t *__restrict__ final_idx,
+                         const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
+                         const float *__restrict__ img_raw, float *__restrict__ gacc,
+                         unsigned long long *__restrict__ gfix) {
+    __shared__ SRecB stage[kChunk + 1];
+    __shared__ int sid[kChunk];
+    __shared__ float acc[kAcc * kAccStride];
+    // block -> (XCD x, k): k = (slot / 8, piece, quadrant), like decode_wave<1> with 4 * max_seg parts
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int per_tile = 4 * max_seg;
+    const int part = k % per_tile, slot = ((k / per_tile) << 3) + x;
+    if (slot >= num_tiles) return;
+    const int tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
+    const int seg = part >> 2, quad = part & 3;
+    const int2 r = bins[tile];
+    const int lo = r.x + (seg << seg_shift);
+    if (lo >= r.y) return;
+    // (the last piece the buffer has a record for takes whatever is left of a list that outgrew the plan)
+    const bool tail = seg == max_seg - 1 || lo + (1 << seg_shift) >= r.y;
+    const int hi = tail ? r.y : lo + (1 << seg_shift);
+    const int wx0 = (tile % tiles_x) * GS_TILE + 8 * (quad & 1), wy0 = (tile / tiles_x) * GS_TILE + 8 * (quad >> 1);
+    if (wx0 >= W || wy0 >= H) return;
+    const float4 *rec = ckpt + (size_t)tile * max_seg * (GS_TILE * GS_TILE);
+    const ListPiece piece{lo, hi, tail ? nullptr : rec + (size_t)(seg + 1) * (GS_TILE * GS_TILE), rec};
+    backward_wave<EXACT, DET, 1, true>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1,
+                                       bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
+                                       gfix, piece);
+}
 #undef GS_WALK_STEP
 #undef GS_WALK_PACK
 
@@ -1080,13 +1245,46 @@ extern "C" size_t gs_rasterize_backward_workspace_bytes_det(int N) {
     return N > 0 ? (size_t)N * gs::kGradRec * (sizeof(float) + sizeof(long long)) : 0;
 }
 
-extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
-                                    const uint16_t *block_masks, const int32_t *tile_bins,
-                                    const float *packed,
-                                    const float *background, float *out_img, float *final_Ts,
-                                    int32_t *final_idx, float *out_img_clamped,
-                                    const int32_t *list_stats, const int32_t *tile_order,
-                                    uint32_t flags, gs_stream_t stream) {
+// A frame of at most this many tiles is composited by lone waves (four per tile cannot fill 256 CUs x 4 SIMDs
+// x 5 waves): the forward takes two entries per step there, the backward gives every tile four waves — or,
+// with checkpoints, every piece of every list.
+constexpr int kWaveSlots = 5120;
+
+static bool checkpoint_args_ok(const void *checkpoints, size_t checkpoint_bytes, int32_t seg_len,
+                               int32_t max_segments, int tiles) {
+    if (!checkpoints) return true;
+    if (seg_len < 64 || (seg_len & (seg_len - 1)) != 0 || max_segments < 2) return false;
+    if ((uintptr_t)checkpoints & 15u) return false;
+    return checkpoint_bytes >= (size_t)tiles * (size_t)max_segments * GS_TILE * GS_TILE * sizeof(float4);
+}
+
+extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_stats, int32_t *seg_len,
+                                            int32_t *max_segments, size_t *bytes) {
+    if (W <= 0 || H <= 0 || !seg_len || !max_segments || !bytes) return GS_ERR_INVALID_ARGUMENT;
+    *seg_len = 0; *max_segments = 0; *bytes = 0;
+    const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    if (4 * tiles > kWaveSlots || !list_stats || list_stats[0] <= 0) return GS_OK;
+    // pieces of one chunk (64 entries): 6000 Gaussians at 384x288 47.6 us, against 58.9 / 75.3 / 126.8 us with
+    // 128 / 256 / 512 and 141 us in one pass; 96x72: 25 / 40 / 65 / 107 / 263 us (profiles/HISTORY.md)
+    const int32_t len = 64;
+    const int64_t longest = list_stats[1];
+    if (longest <= 2 * len) return GS_OK;   // nothing worth cutting
+    // the longest list of the frame the statistics come from + a quarter: a list that outgrows it is
+    // finished by its last piece (slower, correct)
+    const int64_t segs = std::min<int64_t>((longest + longest / 4 + len - 1) / len + 1, 4096);
+    *seg_len = len;
+    *max_segments = (int32_t)segs;
+    *bytes = (size_t)tiles * (size_t)segs * GS_TILE * GS_TILE * sizeof(float4);
+    return GS_OK;
+}
+
+extern "C" int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_ids_sorted,
+                                         const uint16_t *block_masks, const int32_t *tile_bins,
+                                         const float *packed, const float *background, float *out_img,
+                                         float *final_Ts, int32_t *final_idx, float *out_img_clamped,
+                                         const int32_t *list_stats, const int32_t *tile_order,
+                                         uint32_t flags, void *checkpoints, size_t checkpoint_bytes,
+                                         int32_t seg_len, int32_t max_segments, gs_stream_t stream) {
     GS_TRACE("gs_rasterize_forward");
     if (W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img_clamped) return GS_ERR_INVALID_ARGUMENT;
@@ -1105,30 +1303,52 @@ extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_so
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
+    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
+        return GS_ERR_INVALID_ARGUMENT;
+    float4 *ck = static_cast<float4 *>(checkpoints);
+    const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
+    // entries per step: two on a frame of lone waves (flag bits 23..24 force 1 / 2: measurements, tests)
+    int ilp = 4 * tiles <= kWaveSlots ? 2 : 1;
+    if (((flags >> 23) & 3u) != 0u) ilp = (int)((flags >> 23) & 3u) == 2 ? 2 : 1;
     gs::ev_before(s);
-    if (flags & GS_FLAG_FAST_EXP)
-        GS_LAUNCH((gs::k_rasterize_forward<false>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
-                           tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,
-                           bg_dev, out_img, final_Ts, final_idx, clamped);
-    else
-        GS_LAUNCH((gs::k_rasterize_forward<true>), dim3(units), dim3(64), 0, s, W, H, tiles_x,
-                           tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,
-                           bg_dev, out_img, final_Ts, final_idx, clamped);
+#define GS_FWD_LAUNCH(EX, IL)                                                                            \
+    GS_LAUNCH((gs::k_rasterize_forward<EX, IL>), dim3(units), dim3(64), 0, s, W, H, tiles_x, tiles,       \
+              tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2, bg_dev, out_img,     \
+              final_Ts, final_idx, clamped, ck, seg_shift, (int)max_segments)
+    if (flags & GS_FLAG_FAST_EXP) {
+        if (ilp == 2) GS_FWD_LAUNCH(false, 2); else GS_FWD_LAUNCH(false, 1);
+    } else {
+        if (ilp == 2) GS_FWD_LAUNCH(true, 2); else GS_FWD_LAUNCH(true, 1);
+    }
+#undef GS_FWD_LAUNCH
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
 
-extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
-                                     const uint16_t *block_masks, const int32_t *tile_bins,
-                                     const float *packed,
-                                     const float *background, const float *final_Ts,
-                                     const int32_t *final_idx, const float *v_out,
-                                     const float *v_out_alpha, const float *out_img, float *v_xy,
-                                     float *v_conic, float *v_colors, float *v_opacity,
-                                     void *workspace, size_t workspace_bytes,
-                                     const int32_t *list_stats, const int32_t *tile_order,
-                                     uint32_t flags, gs_stream_t stream) {
+extern "C" int gs_rasterize_forward(int W, int H, const int32_t *gaussian_ids_sorted,
+                                    const uint16_t *block_masks, const int32_t *tile_bins,
+                                    const float *packed,
+                                    const float *background, float *out_img, float *final_Ts,
+                                    int32_t *final_idx, float *out_img_clamped,
+                                    const int32_t *list_stats, const int32_t *tile_order,
+                                    uint32_t flags, gs_stream_t stream) {
+    return gs_rasterize_forward_ckpt(W, H, gaussian_ids_sorted, block_masks, tile_bins, packed, background,
+                                     out_img, final_Ts, final_idx, out_img_clamped, list_stats, tile_order,
+                                     flags, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+                                          const uint16_t *block_masks, const int32_t *tile_bins,
+                                          const float *packed, const float *background,
+                                          const float *final_Ts, const int32_t *final_idx,
+                                          const float *v_out, const float *v_out_alpha,
+                                          const float *out_img, float *v_xy, float *v_conic,
+                                          float *v_colors, float *v_opacity, void *workspace,
+                                          size_t workspace_bytes, const int32_t *list_stats,
+                                          const int32_t *tile_order, uint32_t flags,
+                                          const void *checkpoints, size_t checkpoint_bytes,
+                                          int32_t seg_len, int32_t max_segments, gs_stream_t stream) {
     GS_TRACE("gs_rasterize_backward");
     if (W <= 0 || H <= 0 || N < 0) return GS_ERR_INVALID_ARGUMENT;
     if ((flags & GS_FLAG_CLAMP_IMAGE) && !out_img) return GS_ERR_INVALID_ARGUMENT;
@@ -1181,11 +1401,15 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
     // a small frame does not fill the chip with one wave per tile (256 CUs x 4 SIMDs x 5 waves = 5120 slots;
     // the quarter-resolution frames a training run starts with have a few dozen tiles): more waves per
     // tile then cost 1.1 / 1.5 x the work and take a half / a quarter of the time
-    constexpr int kWaveSlots = 5120;
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    const int units = px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
+    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
+        return GS_ERR_INVALID_ARGUMENT;
+    const float4 *ck = static_cast<const float4 *>(checkpoints);
+    const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
+    const int units = ck ? 4 * max_segments * 8 * ((tiles + 7) / 8)
+                    : px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
                                        : (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // PER_TILE waves per tile
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
@@ -1197,7 +1421,12 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                        bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);                                                   \
+        if (ck)                                                                                            \
+            GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x,   \
+                      tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted,            \
+                      block_masks, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out,            \
+                      v_out_alpha, img_raw, gacc, gfix);                                                   \
+        else if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);                                              \
         else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);                                              \
         else if (px_per_lane == 4) GS_BWD_LAUNCH3(EX, DT, 4);                                              \
         else                                                                                               \
@@ -1228,4 +1457,20 @@ extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussia
                        v_opacity);
     GS_LAUNCH_CHECK();
     return GS_OK;
+}
+
+extern "C" int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorted,
+                                     const uint16_t *block_masks, const int32_t *tile_bins,
+                                     const float *packed,
+                                     const float *background, const float *final_Ts,
+                                     const int32_t *final_idx, const float *v_out,
+                                     const float *v_out_alpha, const float *out_img, float *v_xy,
+                                     float *v_conic, float *v_colors, float *v_opacity,
+                                     void *workspace, size_t workspace_bytes,
+                                     const int32_t *list_stats, const int32_t *tile_order,
+                                     uint32_t flags, gs_stream_t stream) {
+    return gs_rasterize_backward_ckpt(W, H, N, gaussian_ids_sorted, block_masks, tile_bins, packed,
+                                      background, final_Ts, final_idx, v_out, v_out_alpha, out_img, v_xy,
+                                      v_conic, v_colors, v_opacity, workspace, workspace_bytes, list_stats,
+                                      tile_order, flags, nullptr, 0, 0, 0, stream);
 }

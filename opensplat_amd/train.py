@@ -73,9 +73,12 @@ class Trainer:
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
                  reference_alpha_reset: bool = False, grad_buckets: int = 4, exchange: str = "auto",
-                 deterministic: bool = False, graph: bool = False):
+                 deterministic: bool = False, graph: bool = False, segmented: bool = True):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
-        [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3]."""
+        [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3].
+        segmented: on frames of few tiles the compositing backward runs the pieces of a tile's list side by
+        side from checkpoints the forward leaves (cabi.Checkpoints; scheduling only)."""
+        self.segmented, self._ckpt = segmented, cabi.Checkpoints()
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
                                       dtype=torch.float32).to(device)
         N = means.shape[0]
@@ -229,6 +232,9 @@ class Trainer:
                 hit = cam["_cam_pos_dev"] = (key, torch.from_numpy(cam_pos).to(self.dev))
             self._cam_pos_dev = hit[1]
         flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
+        # a frame of few tiles with long lists: the forward leaves checkpoints along the lists and the
+        # backward runs their pieces side by side (planned from the previous frame's list statistics)
+        ck = self._ckpt if self.segmented and self._ckpt.plan(W, H, self.bin_ws.list_stats, self.dev) else None
         while True:
             p = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats,
                                       self.opacity_logits, self.features_dc,
@@ -236,9 +242,10 @@ class Trainer:
                                       degrees_to_use, flags, out=self.proj)
             b = cabi.bin_and_sort(W, H, None, p["depths"], None, None, None, None, None, self.bin_ws,
                                   speculative=True, packed=p["packed"])
-            f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd)
+            f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd, checkpoints=ck)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
+        f["checkpoints"] = ck
         # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
         # no gradient and afterTrain returns at once (model.cpp:315)
         self._visible = b.num_isects > 0
@@ -250,7 +257,8 @@ class Trainer:
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
         keep = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0)
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
-                                flags | keep, workspace=self.bwd_ws, img_raw=f["img"])
+                                flags | keep, workspace=self.bwd_ws, img_raw=f["img"],
+                                checkpoints=f.get("checkpoints"))
         if self.factored:
             if self.fx is None or self.fx.N != self.N:      # (a refinement changes N)
                 self.fx = dist.FactoredExchange(self.N, self.K, 1, self.dev)

@@ -28,7 +28,8 @@ def main():
     G = train.Trainer(*gt, dev)
     bg = np.zeros(3, np.float32)
     images = [G.render(c, bg, 3).clone() for c in cams]
-    T = train.Trainer(*sfm_like_init(gt, n_init, K, rs), dev, max_steps=10000)
+    segmented = os.environ.get("GSPLAT_SEGMENTED", "1") != "0"
+    T = train.Trainer(*sfm_like_init(gt, n_init, K, rs), dev, max_steps=10000, segmented=segmented)
     for s in range(1, 40):
         T.train_step(cams[s % 8], images[s % 8], bg, 3)
         T.after_train(s)
@@ -50,16 +51,18 @@ def main():
     for s in range(100, 400):
         T.train_step(cams[s % 8], images[s % 8], bg, 3)
         T.after_train(s)
+    host_it = (time.perf_counter() - t0) / 300 * 1e6    # the last launch has been queued
     torch.cuda.synchronize()
     per_it = (time.perf_counter() - t0) / 300 * 1e6
     rows = [(k, v[0] / reps * 1e3, v[1] / reps) for k, v in agg.items()]
-    out = {"gaussians": n_init, "width": W, "height": H, "us_per_iteration_plain_loop": per_it,
+    out = {"gaussians": n_init, "width": W, "height": H, "segmented_backward": segmented,
+           "us_per_iteration_plain_loop": per_it, "us_per_iteration_host_side": host_it,
            "sum_of_kernel_us": sum(r[1] for r in rows), "launches_per_iteration": sum(r[2] for r in rows),
            "kernels": [{"kernel": k, "us": round(us, 2), "launches": n} for k, us, n in rows]}
     print(json.dumps(out))
     for k, us, n in rows:
         print("%-40s %7.2f us x %.1f" % (k, us, n), file=sys.stderr)
-    print("sum %.1f us, %d launches; loop %.1f us/iteration" % (out["sum_of_kernel_us"], out["launches_per_iteration"], per_it), file=sys.stderr)
+    print("sum %.1f us, %d launches; loop %.1f us/iteration (host side %.1f)" % (out["sum_of_kernel_us"], out["launches_per_iteration"], per_it, host_it), file=sys.stderr)
 
 
 if __name__ == "__main__":
