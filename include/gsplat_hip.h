@@ -302,14 +302,16 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const int32_t *tile_order /*device [tiles], nullable*/, uint32_t flags,
                           gs_stream_t stream);
 
-/* Frames of few tiles (at most 1280: the reduced resolutions OpenSplat's resolution schedule starts a run
+/* Frames of few tiles (at most 2560: the reduced resolutions OpenSplat's resolution schedule starts a run
  * with, model.cpp:85-92; small captures): four waves per tile cannot fill the chip, the launch lasts as long
  * as one wave needs for the LONGEST list.  No counterpart in the reference, which gives a tile's list to
  * one workgroup (forward.cu:256-378, backward.cu:161-355).  Two things help, both scheduling only:
  *  - the forward takes two list entries per step on such frames (same bits; chosen by itself);
  *  - the backward can start anywhere in a list if it is handed the state in front of that entry.  With a
- *    checkpoint buffer the forward stores {T, r, g, b} per pixel every `seg_len` entries of a tile's list
- *    (and the final state), and the backward runs every piece of every list as a wave of its own; the
+ *    checkpoint buffer the forward stores four floats per pixel every `seg_len` entries of a tile's list
+ *    (and at its end) — the state of the BACKWARD's recurrence there: transmittance and colour buffer as
+ *    gsplat_cpu.cpp:337-352 would have them, i.e. with alpha clamped at 0.99 where the forward clamps at
+ *    0.999 (:220, :338) — and the backward runs every piece of every list as a wave of its own; the
  *    pieces of a Gaussian's gradient meet in its record with the same atomics as the tiles' always did
  *    (sums differ by their order, as between any two runs).  A piece starts from the forward's own
  *    transmittance product instead of the product of reciprocals the one-pass backward (and

@@ -342,7 +342,8 @@ class Checkpoints:
         _check(lib().gs_rasterize_checkpoint_plan(C.c_int(W), C.c_int(H), list_stats, C.byref(sl), C.byref(ms),
                                                   C.byref(nb)), "gs_rasterize_checkpoint_plan")
         env = os.environ.get("GSPLAT_SEG_LEN")   # measurements: another piece length than the library's
-        if env and seg_len is None and nb.value:
+        if env and seg_len is None and list_stats is not None and list_stats[1] > 0 and \
+                (nb.value or os.environ.get("GSPLAT_SEG_FORCE")):
             seg_len = int(env)
             max_segments = (int(list_stats[1]) * 5 // 4 + seg_len - 1) // seg_len + 1
         if seg_len is not None:
@@ -361,6 +362,7 @@ class Checkpoints:
 
 
 _NO_CHECKPOINTS = (None, C.c_size_t(0), C.c_int32(0), C.c_int32(0))
+_FWD_FLAGS_ENV = int(os.environ.get("GSPLAT_FWD_FLAGS", "0"), 0)   # measurements (e.g. bits 23..24: entries per step)
 
 
 def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None, checkpoints=None):
@@ -371,6 +373,7 @@ def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None, check
                    final_idx=torch.empty((H, W), device=dev, dtype=torch.int32))
     bg = _vec3(background)
     ck = checkpoints.args() if checkpoints is not None else _NO_CHECKPOINTS
+    flags |= _FWD_FLAGS_ENV
     _check(lib().gs_rasterize_forward_ckpt(C.c_int(W), C.c_int(H), _p(binned.gaussian_ids_sorted),
                                            _p(binned.block_masks), _p(binned.tile_bins),
                                            _p(binned.packed), bg, _p(out["img"]),

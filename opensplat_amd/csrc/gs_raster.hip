@@ -203,10 +203,18 @@ constexpr uint32_t kWalkDone = 0x40404040u;   // the packed word of four exhaust
 
 // ---------------------------------------------------------------------------------------------
 // ILP: entries of a group's list taken per step (1: full frames; 2: frames of few tiles, see walk2).
-// ckpt (nullable): per tile max_seg records of 256 pixels {T, r, g, b} — record k >= 1 is the state in front
-// of entry range.x + (k << seg_shift) of the tile's list, record 0 the final state: what the segmented
-// backward (k_rasterize_backward_seg) starts a piece of a list from.
-template <bool EXACT, int ILP>
+// CK: checkpoints for the segmented backward (k_rasterize_backward_seg) — per tile max_seg records of 256
+// pixels; record k >= 1 describes the state in front of entry range.x + (k << seg_shift) of the tile's list,
+// record 0 the end of the list.  What a record holds is the state of the BACKWARD's recurrence, not the
+// forward's: the reference clamps alpha at 0.999 here (gsplat_cpu.cpp:220) and at 0.99 there (:338), and its
+// backward unwinds T = T_final * prod 1 / (1 - min(alpha, 0.99)) and sums the colour buffer with those
+// alphas and that T — behind an entry with alpha > 0.99 ("hot") neither is the forward's value.  With
+//   g_j = (1 - alpha_j) / (1 - 0.99) for a hot entry, 1 otherwise;  invG(k) = prod_{j < k} 1 / g_j
+// the backward's transmittance in front of entry k is T_fwd(k) * invG(k) / invG(end) and its buffer behind
+// k is (S(end) - S(k)) / invG(end), S(k) = sum_{j < k} colour_j min(alpha_j, 0.99) T_fwd(j) invG(j):
+//   record k = {T_fwd(k) invG(k), S(k)},  record 0 = {invG(end), S(end)}.
+// Without hot entries invG = 1 and S is the image's own colour sum, bit for bit.
+template <bool EXACT, int ILP, bool CK>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                     const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
@@ -235,6 +243,19 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     // NaN once the pixel is finished (or outside the image): a NaN row makes sigma NaN
     float pyf = inimg ? (float)py : qnan();
     float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    // (CK) the backward's view of the state, see above.  (Kept up on every step: behind a wave-level "some lane
+    // has a hot entry, or one composited behind a hot one" branch with the image's own colour sum + a
+    // correction the forward took 115 us instead of 98 on the 6000-Gaussian training frame — 87 without
+    // checkpoints.)
+    float invG = 1.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    // one composited entry's share of it (alpha: 0 where the entry does not contribute; Tf: T in front of it)
+    auto track = [&](float alpha, float Tf, const float4 &c) {
+        const float ws = (fminf(alpha, 0.99f) * Tf) * invG;
+        s0 = s0 + ws * c.x;
+        s1 = s1 + ws * c.y;
+        s2 = s2 + ws * c.z;
+        if (alpha > 0.99f) invG = invG * ((1.0f - 0.99f) * __builtin_amdgcn_rcpf(1.0f - alpha));
+    };
     int last = -1;   // list index of the last composited entry
     int le = -1;     // ... as a slot of the current chunk (turned into an index once per chunk)
 
@@ -254,13 +275,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     }
     // the lane's pixel inside its tile, row-major: the index of a checkpoint record
     const int pid = ((py & (GS_TILE - 1)) << 4) | (px & (GS_TILE - 1));
-    if (ckpt) ckpt += (size_t)tile * max_seg * (GS_TILE * GS_TILE) + pid;
+    if (CK) ckpt += (size_t)tile * max_seg * (GS_TILE * GS_TILE) + pid;
     for (int c0 = range.x; c0 < range.y; c0 += kChunk) {
         const uint64_t alive = __builtin_amdgcn_ballot_w64(pyf == pyf);
         if (alive == 0ull) break;
-        if (ckpt && c0 != range.x && ((c0 - range.x) & ((1 << seg_shift) - 1)) == 0) {
+        if (CK && c0 != range.x && ((c0 - range.x) & ((1 << seg_shift) - 1)) == 0) {
             const int k = (c0 - range.x) >> seg_shift;
-            if (k < max_seg && inimg) ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T, a0, a1, a2);
+            if (k < max_seg && inimg)
+                ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T * invG, s0, s1, s2);
         }
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
         const uint32_t touch = ntouch;
@@ -345,6 +367,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a0 = a0 + w * q2.x;
             a1 = a1 + w * q2.y;
             a2 = a2 + w * q2.z;
+            if (CK) track(alpha, T, q2);
             T = nT;
             le = ok ? e : le;
           }
@@ -425,6 +448,10 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a0 = a0 + wb * qb2.x;
             a1 = a1 + wb * qb2.y;
             a2 = a2 + wb * qb2.z;
+            if (CK) {
+                track(aa, T, qa2);
+                track(ab, nTa, qb2);
+            }
             T = nTb;
             le = okb ? eb : (oka ? ea : le);
           }
@@ -450,7 +477,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         }
         final_Ts[pix] = T;
         final_idx[pix] = last;
-        if (ckpt) ckpt[0] = make_float4(T, a0, a1, a2);
+        if (CK) ckpt[0] = make_float4(invG, s0, s1, s2);
     }
 }
 
@@ -663,9 +690,11 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 last[p] = -1;
             } else if (last[p] >= piece.hi) {
                 const int pid = ((py & (GS_TILE - 1)) << 4) | (px & (GS_TILE - 1));
+                // (records in the backward's terms, k_rasterize_forward: {T invG, S} and {invG(end), S(end)})
                 const float4 cf = piece.front[pid], ce = piece.final_[pid];
-                T[p] = cf.x;
-                D[p] = D[p] - ((ce.y - cf.y) * vo0[p] + (ce.z - cf.z) * vo1[p] + (ce.w - cf.w) * vo2[p]);
+                const float Gt = __builtin_amdgcn_rcpf(ce.x);   // (exactly 1 without a hot entry)
+                T[p] = cf.x * Gt;
+                D[p] = D[p] - Gt * ((ce.y - cf.y) * vo0[p] + (ce.z - cf.z) * vo1[p] + (ce.w - cf.w) * vo2[p]);
                 last[p] = piece.hi - 1;
             }
         }
@@ -1245,9 +1274,11 @@ extern "C" size_t gs_rasterize_backward_workspace_bytes_det(int N) {
     return N > 0 ? (size_t)N * gs::kGradRec * (sizeof(float) + sizeof(long long)) : 0;
 }
 
-// A frame of at most this many tiles is composited by lone waves (four per tile cannot fill 256 CUs x 4 SIMDs
-// x 5 waves): the forward takes two entries per step there, the backward gives every tile four waves — or,
-// with checkpoints, every piece of every list.
+// Wave slots of the chip (256 CUs x 4 SIMDs x 5 waves).  A frame whose tiles cannot fill them with four / two
+// waves each (1280 / 2560 tiles) is composited by lone waves: the backward gives every tile four / two waves
+// — or, with checkpoints, every piece of every list a wave — and the forward takes two entries per step up
+// to 2560 tiles (measured: 640x480 119 -> 105 us, 1008x756 114 -> 103 us at 20 000 Gaussians, level at
+// 1504x1000; pieces: 752x500 234 -> 171 us, 1008x756 290 -> 282 us, 1504x1000 330 -> 581 us).
 constexpr int kWaveSlots = 5120;
 
 static bool checkpoint_args_ok(const void *checkpoints, size_t checkpoint_bytes, int32_t seg_len,
@@ -1263,7 +1294,7 @@ extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_st
     if (W <= 0 || H <= 0 || !seg_len || !max_segments || !bytes) return GS_ERR_INVALID_ARGUMENT;
     *seg_len = 0; *max_segments = 0; *bytes = 0;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    if (4 * tiles > kWaveSlots || !list_stats || list_stats[0] <= 0) return GS_OK;
+    if (2 * tiles > kWaveSlots || !list_stats || list_stats[0] <= 0) return GS_OK;
     // pieces of one chunk (64 entries): 6000 Gaussians at 384x288 47.6 us, against 58.9 / 75.3 / 126.8 us with
     // 128 / 256 / 512 and 141 us in one pass; 96x72: 25 / 40 / 65 / 107 / 263 us (profiles/HISTORY.md)
     const int32_t len = 64;
@@ -1308,19 +1339,24 @@ extern "C" int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_i
     float4 *ck = static_cast<float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
     // entries per step: two on a frame of lone waves (flag bits 23..24 force 1 / 2: measurements, tests)
-    int ilp = 4 * tiles <= kWaveSlots ? 2 : 1;
+    int ilp = 2 * tiles <= kWaveSlots ? 2 : 1;
     if (((flags >> 23) & 3u) != 0u) ilp = (int)((flags >> 23) & 3u) == 2 ? 2 : 1;
     gs::ev_before(s);
-#define GS_FWD_LAUNCH(EX, IL)                                                                            \
-    GS_LAUNCH((gs::k_rasterize_forward<EX, IL>), dim3(units), dim3(64), 0, s, W, H, tiles_x, tiles,       \
+#define GS_FWD_LAUNCH3(EX, IL, CK)                                                                       \
+    GS_LAUNCH((gs::k_rasterize_forward<EX, IL, CK>), dim3(units), dim3(64), 0, s, W, H, tiles_x, tiles,   \
               tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2, bg_dev, out_img,     \
               final_Ts, final_idx, clamped, ck, seg_shift, (int)max_segments)
+#define GS_FWD_LAUNCH(EX, IL)                                                                            \
+    do {                                                                                                 \
+        if (ck) GS_FWD_LAUNCH3(EX, IL, true); else GS_FWD_LAUNCH3(EX, IL, false);                        \
+    } while (0)
     if (flags & GS_FLAG_FAST_EXP) {
         if (ilp == 2) GS_FWD_LAUNCH(false, 2); else GS_FWD_LAUNCH(false, 1);
     } else {
         if (ilp == 2) GS_FWD_LAUNCH(true, 2); else GS_FWD_LAUNCH(true, 1);
     }
 #undef GS_FWD_LAUNCH
+#undef GS_FWD_LAUNCH3
     gs::ev_after(s);
     GS_LAUNCH_CHECK();
     return GS_OK;

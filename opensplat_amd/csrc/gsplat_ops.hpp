@@ -245,3 +245,8 @@ private:
 // expf (contributor sets identical to gsplat-cpu); true = hardware v_exp_f32 (GS_FLAG_FAST_EXP).
 void gsplatSetFastExp(bool enabled);
 bool gsplatGetFastExp();
+// Process-wide switch for SplatRender on frames of few tiles (gsplat_hip.h: gs_rasterize_checkpoint_plan):
+// true (default) = the forward leaves checkpoints along the tile lists and the backward runs the pieces of a
+// list side by side; false = the one-pass backward everywhere.  Scheduling only.
+void gsplatSetSegmentedBackward(bool enabled);
+bool gsplatGetSegmentedBackward();

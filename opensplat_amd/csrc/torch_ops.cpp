@@ -37,6 +37,7 @@ using torch::autograd::variable_list;
 namespace {
 
 std::atomic<bool> g_fast_exp{false};
+std::atomic<bool> g_segmented{true};   // SplatRender: checkpointed forward + segmented backward on frames of few tiles
 
 #define GS_CHECK_DEV(x) TORCH_CHECK((x).is_cuda(), #x " must be a GPU (HIP) tensor")
 #define GS_CHECK_F32(x) TORCH_CHECK((x).scalar_type() == torch::kFloat32, #x " must be float32")
@@ -142,6 +143,8 @@ Tensor cov2d_channel_lookup(const Tensor &conics, int64_t N) {
 
 void gsplatSetFastExp(bool enabled) { g_fast_exp.store(enabled); }
 bool gsplatGetFastExp() { return g_fast_exp.load(); }
+void gsplatSetSegmentedBackward(bool enabled) { g_segmented.store(enabled); }
+bool gsplatGetSegmentedBackward() { return g_segmented.load(); }
 
 // ---- spherical_harmonics.cpp:3-28 helpers ------------------------------------------------------
 int degFromSh(int numBases) {
@@ -600,21 +603,36 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     Tensor finalTs = torch::empty({H, W}, f32), finalIdx = torch::empty({H, W}, i32);
     Tensor bgHold;
     const float *bg = vec3_arg(background, bgHold);
+    // a frame of few tiles with long lists (the reduced resolutions a run starts with, model.cpp:85-92): the
+    // forward leaves checkpoints along the lists, the backward runs their pieces side by side — planned
+    // from the statistics of the last frame of this size (gsplat_hip.h: gs_rasterize_checkpoint_plan)
+    int32_t segLen = 0, maxSegments = 0;
+    size_t ckBytes = 0;
+    {
+        const BinState st = readBinState(means.get_device(), W, H);
+        if (g_segmented.load())
+            check_status(gs_rasterize_checkpoint_plan(W, H, st.listStats, &segLen, &maxSegments, &ckBytes),
+                         "gs_rasterize_checkpoint_plan");
+    }
+    Tensor checkpoints = ckBytes ? torch::empty({(int64_t)ckBytes}, f32.dtype(torch::kUInt8)) : Tensor();
     BinnedLists b;
     for (;;) {
         b = binPackedRecords(packedAll, depths, H, W);
-        check_status(gs_rasterize_forward(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
-                                          maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
-                                          fptr(b.packed), bg, fptr_mut(imgRaw), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), fptr_mut(img), nullptr,
-                                          b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
-                                          flags, s),
+        check_status(gs_rasterize_forward_ckpt(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
+                                               maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
+                                               fptr(b.packed), bg, fptr_mut(imgRaw), fptr_mut(finalTs),
+                                               finalIdx.data_ptr<int32_t>(), fptr_mut(img), nullptr,
+                                               b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
+                                               flags, ckBytes ? checkpoints.data_ptr() : nullptr, ckBytes,
+                                               segLen, maxSegments, s),
                      "gs_rasterize_forward");
         if (validateBinning(b)) break;
     }
     Tensor packed = b.packed, idsSorted = b.gaussianIdsSorted, tileBins = b.tileBins, tileOrder = b.tileOrder;
     ctx->saved_data["listM"] = (int64_t)b.listStats[0];
     ctx->saved_data["listLongest"] = (int64_t)b.listStats[1];
+    ctx->saved_data["segLen"] = (int64_t)segLen;
+    ctx->saved_data["maxSegments"] = (int64_t)maxSegments;
 
     ctx->saved_data["imgWidth"] = imgWidth; ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
@@ -629,7 +647,8 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
                             gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold,
-                            tileOrder, opacityLogits, b.blockMasks});
+                            tileOrder, opacityLogits, b.blockMasks,
+                            ckBytes ? checkpoints : torch::empty({0}, f32.dtype(torch::kUInt8))});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};
@@ -649,22 +668,26 @@ tensor_list SplatRender::backward(AutogradContext *ctx, tensor_list grad_outputs
     const float *bg = bgHold.data_ptr<float>();
     const float *cp = cpHold.data_ptr<float>();
     auto f32 = means.options();
-    Tensor opacityLogits = sv[17], blockMasks = sv[18];
+    Tensor opacityLogits = sv[17], blockMasks = sv[18], checkpoints = sv[19];
     const int32_t listStats[2] = {(int32_t)ctx->saved_data["listM"].toInt(),
                                   (int32_t)ctx->saved_data["listLongest"].toInt()};
     Tensor v_xy = (gradOut.numel() == 2 * N && N > 0) ? gradOut.view({N, 2}) : Tensor();
     const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
     Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
     const uint32_t flags = (uint32_t)ctx->saved_data["flags"].toInt();
+    const size_t ckBytes = (size_t)checkpoints.numel();
     // compositing backward: gradients stay in the 64-byte records of `ws` ...
-    check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
-                                       maskptr(blockMasks),
-                                       tileBins.data_ptr<int32_t>(), fptr(packed), bg, fptr(finalTs),
-                                       finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
-                                       fptr(imgRaw), nullptr, nullptr, nullptr, nullptr, ws.data_ptr(),
-                                       wsBytes, listStats,
-                                       tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
-                                       flags | GS_FLAG_KEEP_RECORDS, s),
+    check_status(gs_rasterize_backward_ckpt(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
+                                            maskptr(blockMasks),
+                                            tileBins.data_ptr<int32_t>(), fptr(packed), bg, fptr(finalTs),
+                                            finalIdx.data_ptr<int32_t>(), fptr(v_img), nullptr,
+                                            fptr(imgRaw), nullptr, nullptr, nullptr, nullptr, ws.data_ptr(),
+                                            wsBytes, listStats,
+                                            tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
+                                            flags | GS_FLAG_KEEP_RECORDS,
+                                            ckBytes ? checkpoints.data_ptr() : nullptr, ckBytes,
+                                            (int32_t)ctx->saved_data["segLen"].toInt(),
+                                            (int32_t)ctx->saved_data["maxSegments"].toInt(), s),
                  "gs_rasterize_backward");
     // ... and one fused stage turns them into the six parameter gradients (gs_gaussian_backward)
     GsCamera cam = make_camera(ctx->saved_data["fx"].toDouble(), ctx->saved_data["fy"].toDouble(),
@@ -902,6 +925,7 @@ std::vector<Tensor> op_splat_render(const Tensor &means, const Tensor &logScales
 }
 
 void op_set_fast_exp(bool enabled) { gsplatSetFastExp(enabled); }
+void op_set_segmented_backward(bool enabled) { gsplatSetSegmentedBackward(enabled); }
 
 // -> [params x6, exp_avg x6, exp_avg_sq x6 (moment lists empty when none were given), counts int32[4]
 //     = {nSplits, nDups, added, culled} on the host]
@@ -1110,6 +1134,7 @@ TORCH_LIBRARY(opensplat_amd, m) {
           "Tensor background, Tensor? xys_grad_out=None) -> Tensor[]",
           &op_splat_render);
     m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
+    m.def("set_segmented_backward(bool enabled) -> ()", &op_set_segmented_backward);
     m.def("main_loss(Tensor rgb, Tensor gt, float ssim_weight) -> Tensor", &op_main_loss);
     m.def("densify_stats(Tensor xys_grad, Tensor radii, int last_height, int last_width, "
           "Tensor xys_grad_norm, Tensor vis_counts, Tensor max_2d_size) -> Tensor[]",

@@ -54,6 +54,12 @@ def set_fast_exp(enabled: bool) -> None:
     _ops.set_fast_exp(bool(enabled))
 
 
+def set_segmented_backward(enabled: bool) -> None:
+    """splat_render on frames of few tiles: checkpointed forward + segmented compositing backward (default on;
+    scheduling only — gsplatSetSegmentedBackward)."""
+    _ops.set_segmented_backward(bool(enabled))
+
+
 def binning_reset() -> None:
     """Forget the id-list capacities of the speculative binning (gsplatResetBinningState)."""
     _ops.binning_reset()

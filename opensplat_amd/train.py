@@ -77,7 +77,8 @@ class Trainer:
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3].
         segmented: on frames of few tiles the compositing backward runs the pieces of a tile's list side by
-        side from checkpoints the forward leaves (cabi.Checkpoints; scheduling only)."""
+        side from checkpoints the forward leaves (cabi.Checkpoints; scheduling only).  The captured iteration
+        (graph=True) does not use it: its launch grid would follow every frame's longest list."""
         self.segmented, self._ckpt = segmented, cabi.Checkpoints()
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
                                       dtype=torch.float32).to(device)

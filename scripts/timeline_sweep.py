@@ -2,7 +2,7 @@
 """Compositing kernel durations of a small-frame training iteration against the list length: the same scene
 family as scripts/timeline_small.py at several Gaussian counts, with the binning's {M, longest list}.
 Separates what a frame costs whatever its lists (launch, table load, first gather) from what an entry of
-the longest list costs.   python scripts/timeline_sweep.py [W H]"""
+the longest list costs.   python scripts/timeline_sweep.py [W H [N,N,...]]"""
 import json
 import math
 import os
@@ -25,7 +25,8 @@ def main():
     dev = torch.device("cuda", 0)
     bg = np.zeros(3, np.float32)
     rows = []
-    for n_init in (50, 400, 1500, 6000, 20000):
+    counts = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else (50, 400, 1500, 6000, 20000)
+    for n_init in counts:
         rs = np.random.RandomState(0)
         cams = [make_camera((3.5 * math.cos(t), 0.4 * math.sin(2 * t), 3.5 * math.sin(t)), W, H)
                 for t in np.linspace(0.0, 2.0 * math.pi, 8, endpoint=False)]

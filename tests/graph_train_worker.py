@@ -22,7 +22,7 @@ def case_bit_for_bit():
               sh_degree_interval=9)
     order = [0, 1, 2, 3, 4, 2, 0]
     deg = lambda s: min(s // 9, 1)
-    ref = train.Trainer(*init, dev, **kw)
+    ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
     got = train.Trainer(*init, dev, graph=True, **kw)
     n_ref = _run(ref, cams, images, bg, 40, order, deg=deg)
     n_got = _run(got, cams, images, bg, 40, order, deg=deg)
@@ -45,7 +45,7 @@ def case_overflow():
     # a camera five times closer to the blob: many more (tile, Gaussian) pairs than the ring cameras
     near = make_camera((0.55, 0.05, 0.3), W, H)
     kw = dict(max_steps=100, deterministic=True)
-    ref = train.Trainer(*init, dev, **kw)
+    ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
     got = train.Trainer(*init, dev, graph=True, **kw)
     near_img = ref.render(near, bg, 1).clone() * 0.5
     seq = [(cams[0], images[0]), (cams[0], images[0]), (cams[1], images[1]), (near, near_img),
@@ -75,7 +75,7 @@ def case_resolution():
     half = [torch.nn.functional.avg_pool2d(im.permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).contiguous()
             for im in images]
     kw = dict(max_steps=100, deterministic=True)
-    ref = train.Trainer(*init, dev, **kw)
+    ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
     got = train.Trainer(*init, dev, graph=True, **kw)
     for T in (ref, got):
         for s in range(10):
@@ -97,7 +97,7 @@ def case_eager_renders():
 
     dev, cams, images, init, bg = _capture(K=16)
     kw = dict(max_steps=400, deterministic=True)
-    ref = train.Trainer(*init, dev, **kw)
+    ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
     got = train.Trainer(*init, dev, graph=True, **kw)
     for T in (ref, got):
         pcs = [T.prepare_camera(c) for c in cams] if T.graph else cams
