@@ -86,6 +86,15 @@ def parse_args():
 class Pipeline:
     """The hot path on one GPU with every buffer preallocated."""
 
+    def _pieces(self):
+        """-> (Checkpoints or None, backward flag bits) for the next forward / backward pair."""
+        ls = self.ws.list_stats
+        if not self.pieces or ls[1] <= 2 * self.pieces:
+            return None, 0
+        segs = (int(ls[1]) * 5 // 4 + self.pieces - 1) // self.pieces + 1
+        self.ckpt.plan(self.s.W, self.s.H, ls, self.dev, seg_len=self.pieces, max_segments=segs)
+        return self.ckpt, 3 << 21
+
     def __init__(self, scene, device, flags, stage_kernels=False, factored=False, cameras_per_rank=1):
         import torch
 
@@ -115,6 +124,10 @@ class Pipeline:
                          cov2d=torch.empty((N, 3), **f))
         self.sh_out = (torch.empty((N, 3), **f), torch.empty((N, 3), **f))  # colours, raw rgb
         self.ws = cabi.BinWorkspace()
+        # --pieces S (measurement): checkpointed forward + the backward in pieces of S list entries, four
+        # pixels per lane, planned from the previous step's list statistics like Trainer does on small frames
+        self.pieces = int(os.environ.get("GSPLAT_BENCH_PIECES", "0"))
+        self.ckpt = cabi.Checkpoints()
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i))
         # 2-D gradients (fully written by gs_rasterize_backward) + its record workspace
@@ -198,7 +211,8 @@ class Pipeline:
             mark()
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
-            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
+            ck, ckf = self._pieces()
+            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd, checkpoints=ck)
             mark()
             # was the id list large enough?  Waits for the scan kernel only (long finished while the
             # forward kernel runs): the stream never drains, the host keeps enqueuing.
@@ -208,8 +222,8 @@ class Pipeline:
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             g = cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"],
-                                        f["final_idx"], self.v_out, self.flags, out=self.rgrads,
-                                        workspace=self.bwd_ws)
+                                        f["final_idx"], self.v_out, self.flags | ckf, out=self.rgrads,
+                                        workspace=self.bwd_ws, checkpoints=ck)
             mark()
             cabi.sh_backward_fused(s.degrees_to_use, s.K, self.means, self.cam_pos, rgb_raw,
                                    g["v_colors"], out=(self.grads.v_dc, self.grads.v_rest))
@@ -265,7 +279,8 @@ class Pipeline:
             mark()
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
-            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd)
+            ck, ckf = self._pieces()
+            f = cabi.rasterize_forward(s.W, s.H, b, self.background, self.flags, out=self.fwd, checkpoints=ck)
             mark()
             if not cabi.validate_binning(b):
                 self.misses += 1
@@ -273,7 +288,7 @@ class Pipeline:
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"], f["final_idx"],
-                                    self.v_out, self.flags | KEEP, workspace=self.bwd_ws)
+                                    self.v_out, self.flags | KEEP | ckf, workspace=self.bwd_ws, checkpoints=ck)
             mark()
             ACC = cabi.GS_FLAG_ACCUMULATE_GRADS if accumulate else 0
             gout = self.gout

@@ -302,11 +302,12 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
                           const int32_t *tile_order /*device [tiles], nullable*/, uint32_t flags,
                           gs_stream_t stream);
 
-/* Frames of few tiles (at most 2560: the reduced resolutions OpenSplat's resolution schedule starts a run
- * with, model.cpp:85-92; small captures): four waves per tile cannot fill the chip, the launch lasts as long
- * as one wave needs for the LONGEST list.  No counterpart in the reference, which gives a tile's list to
- * one workgroup (forward.cu:256-378, backward.cu:161-355).  Two things help, both scheduling only:
- *  - the forward takes two list entries per step on such frames (same bits; chosen by itself);
+/* Frames that do not fill the chip with one wave per tile, and frames whose longest tile lists lie far beyond
+ * the mean (the reduced resolutions OpenSplat's resolution schedule starts a run with, model.cpp:85-92; small
+ * and mid-size captures — up to 6144 tiles, 1.5 Mpixel): the compositing launches last as long as one wave
+ * needs for the LONGEST list.  No counterpart in the reference, which gives a tile's list to one workgroup
+ * (forward.cu:256-378, backward.cu:161-355).  Two things help, both scheduling only:
+ *  - the forward takes two list entries per step on frames of at most 2560 tiles (same bits; chosen by itself);
  *  - the backward can start anywhere in a list if it is handed the state in front of that entry.  With a
  *    checkpoint buffer the forward stores four floats per pixel every `seg_len` entries of a tile's list
  *    (and at its end) — the state of the BACKWARD's recurrence there: transmittance and colour buffer as
@@ -317,9 +318,10 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
  *    transmittance product instead of the product of reciprocals the one-pass backward (and
  *    gsplat_cpu.cpp:337-345) unwinds to there: the two differ by the rounding of that unwinding.
  * gs_rasterize_checkpoint_plan: from the scan's {M, longest list} of the previous frame (host, nullable)
- *   -> seg_len (a power of two >= 64), max_segments, bytes of the buffer; bytes = 0: not worthwhile (frame
- *   of many tiles, no statistics yet, short lists) — call the plain entry points.  A list that outgrows
- *   the plan is finished by its last piece.
+ *   -> seg_len (a power of two >= 64), max_segments, bytes of the buffer; bytes = 0: not worthwhile (more than
+ *   6144 tiles, no statistics yet, short lists, or — beyond 2560 tiles — no list four times the mean) — call
+ *   the plain entry points.  A list that outgrows the plan is finished by its last piece.  The pieces' waves
+ *   hold 1 / 2 / 4 pixels per lane up to 128 / 1024 / more tiles.
  * gs_rasterize_forward_ckpt / gs_rasterize_backward_ckpt: the entry points above + the buffer (16-byte
  *   aligned, >= tiles * max_segments * 4096 bytes; NULL: exactly the plain call).  The backward must be
  *   given the buffer, seg_len and max_segments its forward wrote with. */

@@ -363,6 +363,7 @@ class Checkpoints:
 
 _NO_CHECKPOINTS = (None, C.c_size_t(0), C.c_int32(0), C.c_int32(0))
 _FWD_FLAGS_ENV = int(os.environ.get("GSPLAT_FWD_FLAGS", "0"), 0)   # measurements (e.g. bits 23..24: entries per step)
+_BWD_FLAGS_ENV = int(os.environ.get("GSPLAT_BWD_FLAGS", "0"), 0)   # measurements (bits 21..22: pixels per lane)
 
 
 def rasterize_forward(W, H, binned: Binned, background, flags=0, out=None, checkpoints=None):
@@ -399,6 +400,7 @@ def rasterize_backward(W, H, N, binned: Binned, background, final_Ts, final_idx,
         workspace = torch.empty((max(ws_bytes, 64),), device=dev, dtype=torch.uint8)
     bg = _vec3(background)
     ck = checkpoints.args() if checkpoints is not None else _NO_CHECKPOINTS
+    flags |= _BWD_FLAGS_ENV
     _check(lib().gs_rasterize_backward_ckpt(C.c_int(W), C.c_int(H), C.c_int(N),
                                        _p(binned.gaussian_ids_sorted), _p(binned.block_masks),
                                        _p(binned.tile_bins),

@@ -243,10 +243,12 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     // NaN once the pixel is finished (or outside the image): a NaN row makes sigma NaN
     float pyf = inimg ? (float)py : qnan();
     float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    // (CK) the backward's view of the state, see above.  (Kept up on every step: behind a wave-level "some lane
-    // has a hot entry, or one composited behind a hot one" branch with the image's own colour sum + a
-    // correction the forward took 115 us instead of 98 on the 6000-Gaussian training frame — 87 without
-    // checkpoints.)
+    // (CK) the backward's view of the state, see above.  Until the wave meets its first hot entry invG is 1 and
+    // S is the image's own colour sum: nothing is kept beside it (`hotw`, wave-uniform: one compare and a
+    // scalar branch per step).  From then on S and invG are kept up on every step of the wave (13 VALU per
+    // entry: 98 against 87 us on the 6000-Gaussian training frame if it is done from the start; a per-step
+    // "some lane has a hot entry or one behind a hot one" test in front of a correction term took 115).
+    bool hotw = false;
     float invG = 1.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     // one composited entry's share of it (alpha: 0 where the entry does not contribute; Tf: T in front of it)
     auto track = [&](float alpha, float Tf, const float4 &c) {
@@ -255,6 +257,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         s1 = s1 + ws * c.y;
         s2 = s2 + ws * c.z;
         if (alpha > 0.99f) invG = invG * ((1.0f - 0.99f) * __builtin_amdgcn_rcpf(1.0f - alpha));
+    };
+    // called with the entry's (entries') alpha BEFORE the colour sum takes it in
+    auto first_hot = [&](bool lane_hot) {
+        if (!hotw && __builtin_amdgcn_ballot_w64(lane_hot) != 0ull) {
+            asm volatile("; first hot entry");
+            hotw = true;
+            s0 = a0; s1 = a1; s2 = a2;
+        }
     };
     int last = -1;   // list index of the last composited entry
     int le = -1;     // ... as a slot of the current chunk (turned into an index once per chunk)
@@ -282,7 +292,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         if (CK && c0 != range.x && ((c0 - range.x) & ((1 << seg_shift) - 1)) == 0) {
             const int k = (c0 - range.x) >> seg_shift;
             if (k < max_seg && inimg)
-                ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T * invG, s0, s1, s2);
+                ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T * invG, hotw ? s0 : a0, hotw ? s1 : a1, hotw ? s2 : a2);
         }
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
         const uint32_t touch = ntouch;
@@ -297,6 +307,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         constexpr bool kChunkBinds = false;
         const bool chunk_binds = !kChunkBinds ||
             __builtin_amdgcn_ballot_w64(touch != 0u && (__float_as_uint(n1.z) & 1u) != 0u) != 0ull;
+        static_assert(!kChunkBinds, "the walks below are instantiated for the general case only");
+        (void)chunk_binds;
+        const bool chunk_hot = CK && (hotw || __builtin_amdgcn_ballot_w64(touch != 0u && n1.y > 0.99f) != 0ull);
         // a block whose 16 pixels are all finished walks nothing
         uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
         uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
@@ -313,8 +326,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
             }
         }
-        auto walk = [&](auto binds_tag) {
+        auto walk = [&](auto binds_tag, auto hot_tag) {
           constexpr bool BINDS = decltype(binds_tag)::value;
+          constexpr bool HOT = CK && decltype(hot_tag)::value;
           uint32_t ep_next;
           { GS_WALK_PACK(ep0_) ep_next = ep0_; }
           while (ep_next != kWalkDone) {
@@ -363,11 +377,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 asm volatile("; pixel saturates");
                 if (nT <= 1e-4f) { pyf = qnan(); alpha = 0.0f; nT = T; ok = false; }
             }
+            if (HOT) {
+                first_hot(alpha > 0.99f);
+                if (hotw) track(alpha, T, q2);
+            }
             const float w = alpha * T;
             a0 = a0 + w * q2.x;
             a1 = a1 + w * q2.y;
             a2 = a2 + w * q2.z;
-            if (CK) track(alpha, T, q2);
             T = nT;
             le = ok ? e : le;
           }
@@ -378,8 +395,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         // hundred tiles, where a lone wave pays the full latency of every dependent step (measured 170 ns
         // per step against 40 ns of issue, profiles/timeline_sweep_*_r04.json).  The compositing itself
         // stays in list order (a, then b with the transmittance a leaves), so the bits are the same.
-        auto walk2 = [&](auto binds_tag) {
+        auto walk2 = [&](auto binds_tag, auto hot_tag) {
           constexpr bool BINDS = decltype(binds_tag)::value;
+          constexpr bool HOT = CK && decltype(hot_tag)::value;
           uint32_t epa_next, epb_next;
           { GS_WALK_PACK(wa0_) epa_next = wa0_; }
           { GS_WALK_PACK(wb0_) epb_next = wb0_; }
@@ -440,6 +458,13 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                     pyf = qnan(); ab = 0.0f; nTb = nTa; okb = false;
                 }
             }
+            if (HOT) {
+                first_hot(aa > 0.99f || ab > 0.99f);
+                if (hotw) {
+                    track(aa, T, qa2);
+                    track(ab, nTa, qb2);
+                }
+            }
             const float wa = aa * T;
             a0 = a0 + wa * qa2.x;
             a1 = a1 + wa * qa2.y;
@@ -448,18 +473,16 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a0 = a0 + wb * qb2.x;
             a1 = a1 + wb * qb2.y;
             a2 = a2 + wb * qb2.z;
-            if (CK) {
-                track(aa, T, qa2);
-                track(ab, nTa, qb2);
-            }
             T = nTb;
             le = okb ? eb : (oka ? ea : le);
           }
         };
+        // (kChunkBinds is off: the general walk)  A chunk none of whose entries has an opacity above 0.99 cannot
+        // hold a hot entry (alpha <= opacity): until the wave has met one, such chunks walk without looking
         if constexpr (ILP == 2) {
-            if (chunk_binds) walk2(std::true_type{}); else walk2(std::false_type{});
+            if (chunk_hot) walk2(std::true_type{}, std::true_type{}); else walk2(std::true_type{}, std::false_type{});
         } else {
-            if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
+            if (chunk_hot) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
         }
         last = le >= 0 ? c0 + le : last;
         le = -1;
@@ -477,7 +500,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         }
         final_Ts[pix] = T;
         final_idx[pix] = last;
-        if (CK) ckpt[0] = make_float4(invG, s0, s1, s2);
+        if (CK) ckpt[0] = make_float4(invG, hotw ? s0 : a0, hotw ? s1 : a1, hotw ? s2 : a2);
     }
 }
 
@@ -1073,7 +1096,7 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
 // tile-major (the pieces of a tile on one XCD), longest list first.  The pieces of a Gaussian's gradient meet
 // in its record like the tiles' always did.  (The reference walks a tile's list in one workgroup,
 // backward.cu:217-353; its transmittance recurrence is the one of backward_wave.)
-template <bool EXACT, bool DET>
+template <bool EXACT, bool DET, int PX>
 __global__ void __launch_bounds__(64, GS_BWD_WAVES)
 k_rasterize_backward_seg(int W, int H, int tiles_x, int num_tiles, int seg_shift, int max_seg,
                          const float4 *__restrict__ ckpt, const int32_t *__restrict__ order,
@@ -1087,24 +1110,28 @@ k_rasterize_backward_seg(int W, int H, int tiles_x, int num_tiles, int seg_shift
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
     __shared__ float acc[kAcc * kAccStride];
-    // block -> (XCD x, k): k = (slot / 8, piece, quadrant), like decode_wave<1> with 4 * max_seg parts
+    // block -> (XCD x, k): k = (slot / 8, piece, part of the tile), like decode_wave<PX> with PER_TILE * max_seg
+    // parts per tile
+    using G = WaveGeom<PX>;
     const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int per_tile = 4 * max_seg;
+    const int per_tile = G::PER_TILE * max_seg;
     const int part = k % per_tile, slot = ((k / per_tile) << 3) + x;
     if (slot >= num_tiles) return;
     const int tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
-    const int seg = part >> 2, quad = part & 3;
+    const int seg = part / G::PER_TILE, sub = part % G::PER_TILE;
     const int2 r = bins[tile];
     const int lo = r.x + (seg << seg_shift);
     if (lo >= r.y) return;
     // (the last piece the buffer has a record for takes whatever is left of a list that outgrew the plan)
     const bool tail = seg == max_seg - 1 || lo + (1 << seg_shift) >= r.y;
     const int hi = tail ? r.y : lo + (1 << seg_shift);
-    const int wx0 = (tile % tiles_x) * GS_TILE + 8 * (quad & 1), wy0 = (tile / tiles_x) * GS_TILE + 8 * (quad >> 1);
+    constexpr int PX_COLS = GS_TILE / G::WW;
+    const int wx0 = (tile % tiles_x) * GS_TILE + G::WW * (sub % PX_COLS);
+    const int wy0 = (tile / tiles_x) * GS_TILE + G::WH * (sub / PX_COLS);
     if (wx0 >= W || wy0 >= H) return;
     const float4 *rec = ckpt + (size_t)tile * max_seg * (GS_TILE * GS_TILE);
     const ListPiece piece{lo, hi, tail ? nullptr : rec + (size_t)(seg + 1) * (GS_TILE * GS_TILE), rec};
-    backward_wave<EXACT, DET, 1, true>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1,
+    backward_wave<EXACT, DET, PX, true>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1,
                                        bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
                                        gfix, piece);
 }
@@ -1289,21 +1316,36 @@ static bool checkpoint_args_ok(const void *checkpoints, size_t checkpoint_bytes,
     return checkpoint_bytes >= (size_t)tiles * (size_t)max_segments * GS_TILE * GS_TILE * sizeof(float4);
 }
 
+// Pixels per lane of the pieces' waves, by the frame's tile count (measured, 64-entry pieces, SfM-like scenes:
+// 30 tiles 25 / 31 / 44 us with 1 / 2 / 4; 432 tiles 48 / 45 / 54 at 6000 and 68 / 55 / 63 at 20 000 Gaussians;
+// 1200 tiles 133 / 94 / 82; 1504 tiles 171 / 113 / 99; 3024 tiles 282 / 170 / 128).
+static int piece_pixels_per_lane(int tiles) { return tiles <= 128 ? 1 : tiles <= 1024 ? 2 : 4; }
+
 extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_stats, int32_t *seg_len,
                                             int32_t *max_segments, size_t *bytes) {
     if (W <= 0 || H <= 0 || !seg_len || !max_segments || !bytes) return GS_ERR_INVALID_ARGUMENT;
     *seg_len = 0; *max_segments = 0; *bytes = 0;
     const int tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
-    if (2 * tiles > kWaveSlots || !list_stats || list_stats[0] <= 0) return GS_OK;
+    // Where pieces pay (SfM-like scenes, one-pass -> pieces, backward kernel alone): 432 tiles 141 -> 45 us,
+    // 1504 tiles 234 -> 99, 3024 tiles 288 -> 128, 5922 tiles 402 -> 315; a full 1080p frame (8160 tiles) gains
+    // 10 % on a scene with a long tail of lists and loses 5 % on BASELINE config 2's even one (no tail to cut,
+    // and its opaque Gaussians make the forward keep the backward's state: 170 -> 186 us).
+    constexpr int kMaxTiles = 6144;
+    if (tiles > kMaxTiles || !list_stats || list_stats[0] <= 0) return GS_OK;
+    const int64_t longest = list_stats[1], mean = ((int64_t)list_stats[0] + tiles - 1) / tiles;
     // pieces of one chunk (64 entries): 6000 Gaussians at 384x288 47.6 us, against 58.9 / 75.3 / 126.8 us with
     // 128 / 256 / 512 and 141 us in one pass; 96x72: 25 / 40 / 65 / 107 / 263 us (profiles/HISTORY.md)
-    const int32_t len = 64;
-    const int64_t longest = list_stats[1];
+    int64_t len = 64;
     if (longest <= 2 * len) return GS_OK;   // nothing worth cutting
+    // a frame that fills the chip one wave per tile gains only by its tail: lists far beyond the mean
+    if (2 * tiles > kWaveSlots && longest < 4 * mean) return GS_OK;
     // the longest list of the frame the statistics come from + a quarter: a list that outgrows it is
-    // finished by its last piece (slower, correct)
-    const int64_t segs = std::min<int64_t>((longest + longest / 4 + len - 1) / len + 1, 4096);
-    *seg_len = len;
+    // finished by its last piece (slower, correct).  Every (tile, piece) is a workgroup, most of which look at
+    // their tile's list and leave: longer pieces before the launch exceeds a quarter of a million of them.
+    auto pieces = [&](int64_t l) { return (longest + longest / 4 + l - 1) / l + 1; };
+    while (len < 1024 && (int64_t)tiles * pieces(len) > (1 << 18)) len *= 2;
+    const int64_t segs = std::min<int64_t>(pieces(len), 4096);
+    *seg_len = (int32_t)len;
     *max_segments = (int32_t)segs;
     *bytes = (size_t)tiles * (size_t)segs * GS_TILE * GS_TILE * sizeof(float4);
     return GS_OK;
@@ -1444,7 +1486,9 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
         return GS_ERR_INVALID_ARGUMENT;
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
-    const int units = ck ? 4 * max_segments * 8 * ((tiles + 7) / 8)
+    // pieces: pixels per lane by the tile count unless the flag bits say otherwise
+    const int seg_px = ((flags >> 21) & 3u) != 0u ? px_per_lane : piece_pixels_per_lane(tiles);
+    const int units = ck ? (4 / seg_px) * max_segments * 8 * ((tiles + 7) / 8)
                     : px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
                                        : (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // PER_TILE waves per tile
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
@@ -1455,13 +1499,15 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     GS_LAUNCH((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
                        tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
                        bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+#define GS_SEG_LAUNCH3(EX, DT, PXN)                                                                       \
+    GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x,     \
+              tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted, block_masks, bins, \
+              pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (ck)                                                                                            \
-            GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x,   \
-                      tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted,            \
-                      block_masks, bins, pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out,            \
-                      v_out_alpha, img_raw, gacc, gfix);                                                   \
+        if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                                  \
+        else if (ck && seg_px == 2) GS_SEG_LAUNCH3(EX, DT, 2);                                             \
+        else if (ck) GS_SEG_LAUNCH3(EX, DT, 4);                                                            \
         else if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);                                              \
         else if (px_per_lane == 2) GS_BWD_LAUNCH3(EX, DT, 2);                                              \
         else if (px_per_lane == 4) GS_BWD_LAUNCH3(EX, DT, 4);                                              \
@@ -1477,6 +1523,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, false); else GS_BWD_LAUNCH(true, false);
     }
 #undef GS_BWD_LAUNCH3
+#undef GS_SEG_LAUNCH3
 #undef GS_BWD_LAUNCH
     gs::ev_after(s);
     GS_LAUNCH_CHECK();

@@ -33,7 +33,8 @@ def main():
         gt = ground_truth(max(n_init, 8000), K, rs)
         G = train.Trainer(*gt, dev)
         images = [G.render(c, bg, 3).clone() for c in cams]
-        T = train.Trainer(*sfm_like_init(gt, n_init, K, rs), dev, max_steps=10000)
+        T = train.Trainer(*sfm_like_init(gt, n_init, K, rs), dev, max_steps=10000,
+                          segmented=os.environ.get("GSPLAT_SEGMENTED", "1") != "0")
         for s in range(1, 30):
             T.train_step(cams[s % 8], images[s % 8], bg, 3)
         torch.cuda.synchronize()
