@@ -319,7 +319,7 @@ int gs_rasterize_backward(int W, int H, int N, const int32_t *gaussian_ids_sorte
  *    gsplat_cpu.cpp:337-345) unwinds to there: the two differ by the rounding of that unwinding.
  * gs_rasterize_checkpoint_plan: from the scan's {M, longest list} of the previous frame (host, nullable)
  *   -> seg_len (a power of two >= 64), max_segments, bytes of the buffer; bytes = 0: not worthwhile (more than
- *   6144 tiles, no statistics yet, short lists, or — beyond 2560 tiles — no list four times the mean) — call
+ *   6144 tiles, no statistics yet, short lists, or — beyond 960 tiles — no list four times the mean) — call
  *   the plain entry points.  A list that outgrows the plan is finished by its last piece.  The pieces' waves
  *   hold 1 / 2 / 4 pixels per lane up to 128 / 1024 / more tiles.
  * gs_rasterize_forward_ckpt / gs_rasterize_backward_ckpt: the entry points above + the buffer (16-byte

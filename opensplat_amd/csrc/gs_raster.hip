@@ -1337,8 +1337,11 @@ extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_st
     // 128 / 256 / 512 and 141 us in one pass; 96x72: 25 / 40 / 65 / 107 / 263 us (profiles/HISTORY.md)
     int64_t len = 64;
     if (longest <= 2 * len) return GS_OK;   // nothing worth cutting
-    // a frame that fills the chip one wave per tile gains only by its tail: lists far beyond the mean
-    if (2 * tiles > kWaveSlots && longest < 4 * mean) return GS_OK;
+    // a frame whose one-pass launch (four / two / one wave per tile) comes near the chip's wave slots gains only by
+    // its tail — lists far beyond the mean.  Even lists (uniform synthetic scenes, opaque Gaussians), one pass ->
+    // pieces: 752x500 5659 -> 5525 /s, 1008x756 3713 -> 3678 and 1295 -> 1318 /s, 1504x1000 2473 -> 2310 /s.
+    constexpr int kAlwaysTiles = 960;
+    if (tiles > kAlwaysTiles && longest < 4 * mean) return GS_OK;
     // the longest list of the frame the statistics come from + a quarter: a list that outgrows it is
     // finished by its last piece (slower, correct).  Every (tile, piece) is a workgroup, most of which look at
     // their tile's list and leave: longer pieces before the launch exceeds a quarter of a million of them.

@@ -183,7 +183,8 @@ def test_checkpoint_plan_and_argument_checks():
     assert not ck.plan(1920, 1080, stats, "cuda:0")                         # a full frame: many tiles
     assert ck.plan(1008, 756, (C.c_int32 * 2)(600000, 2000), "cuda:0")      # mid-size, lists far beyond the mean
     assert not ck.plan(1008, 756, (C.c_int32 * 2)(1500000, 1200), "cuda:0") # mid-size, no tail
-    assert ck.plan(640, 480, (C.c_int32 * 2)(1500000, 1400), "cuda:0")      # does not fill the chip: always
+    assert ck.plan(384, 288, (C.c_int32 * 2)(400000, 1400), "cuda:0")       # far from filling the chip: always
+    assert not ck.plan(752, 500, (C.c_int32 * 2)(1500000, 1400), "cuda:0")  # 1504 tiles, even lists
     assert not ck.plan(384, 288, None, "cuda:0")                            # no statistics yet
     assert not ck.plan(384, 288, (C.c_int32 * 2)(5000, 100), "cuda:0")      # nothing worth cutting
     # a buffer that is too small, or a segment length that is not a power of two, is refused
