@@ -36,10 +36,6 @@ k_gaussian_forward(CamArgs cam, const float *__restrict__ vm_dev, const float *_
     load_device_matrices(cam, vm_dev, pm_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *slab = smem + wave * (64 * ROWP);
-    // GS_FLAG_ACCUMULATE_GRADS: the six parameter gradients are ADDED to what the output tensors
-    // hold (several cameras per optimiser step on one rank, one all-reduce for all of them)
-    const bool accum = (flags & GS_FLAG_ACCUMULATE_GRADS) != 0u;
-    auto put = [accum](float *p, float v) { *p = accum ? *p + v : v; };
     const int64_t g0 = ((int64_t)blockIdx.x * (ShSplit<K>::kBlock / 64) + wave) * 64;
     const int cnt = g0 < N ? min(64, (int)(N - g0)) : 0;
     // The wave's slab of higher-band coefficients is fetched into registers FIRST (coalesced 16-byte

@@ -33,7 +33,6 @@ namespace gs {
 constexpr int kWin = GS_SSIM_WINDOW, kRad = kWin / 2;
 constexpr int kTW = 32, kTH = 22;                        // output tile
 constexpr int kHW = kTW + 2 * kRad, kHH = kTH + 2 * kRad;  // halo: 42 x 32
-constexpr int kRawPitch = 3 * kHW + 1;                   // 127 floats: odd -> conflict-free columns
 constexpr int kHPitch = kTW + 1;                         // 33
 constexpr int kMapPitch = kHW + 1;                       // 43
 constexpr int kOutPitch = 3 * kTW + 1;                   // 97

@@ -243,28 +243,28 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     // NaN once the pixel is finished (or outside the image): a NaN row makes sigma NaN
     float pyf = inimg ? (float)py : qnan();
     float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    // (CK) the backward's view of the state, see above.  Until the wave meets its first hot entry invG is 1 and
-    // S is the image's own colour sum: nothing is kept beside it (`hotw`, wave-uniform: one compare and a
-    // scalar branch per step).  From then on S and invG are kept up on every step of the wave (13 VALU per
-    // entry: 98 against 87 us on the 6000-Gaussian training frame if it is done from the start; a per-step
-    // "some lane has a hot entry or one behind a hot one" test in front of a correction term took 115).
-    bool hotw = false;
-    float invG = 1.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    // one composited entry's share of it (alpha: 0 where the entry does not contribute; Tf: T in front of it)
-    auto track = [&](float alpha, float Tf, const float4 &c) {
-        const float ws = (fminf(alpha, 0.99f) * Tf) * invG;
-        s0 = s0 + ws * c.x;
-        s1 = s1 + ws * c.y;
-        s2 = s2 + ws * c.z;
-        if (alpha > 0.99f) invG = invG * ((1.0f - 0.99f) * __builtin_amdgcn_rcpf(1.0f - alpha));
-    };
-    // called with the entry's (entries') alpha BEFORE the colour sum takes it in
-    auto first_hot = [&](bool lane_hot) {
-        if (!hotw && __builtin_amdgcn_ballot_w64(lane_hot) != 0ull) {
-            asm volatile("; first hot entry");
-            hotw = true;
-            s0 = a0; s1 = a1; s2 = a2;
+    // (CK) the backward's view of the state, see above.  invG only changes at a hot entry, so between two of them
+    // S grows by invG times what the image's colour sum grows by:  S = sb + invG * (a - cb), rebased at every hot
+    // entry (sb <- S, cb <- a, invG <- invG / g) — nothing to do on any other step, and without a hot entry
+    // S = 0 + 1 * (a - 0): the image's own sums, bit for bit.  (Kept as a second set of sums on every step it cost
+    // the forward 87 -> 98 us on the 6000-Gaussian training frame, from a wave's first hot entry on still 170 ->
+    // 186 us on config 2's opaque Gaussians; profiles/HISTORY.md.)
+    float invG = 1.0f, sb0 = 0.0f, sb1 = 0.0f, sb2 = 0.0f, cb0 = 0.0f, cb1 = 0.0f, cb2 = 0.0f;
+    // called right AFTER the colour sums took the entry in (alpha > 0.99 in some lane; Tf: T in front of it):
+    // S_after = S_before + c min(alpha, 0.99) Tf invG, with a_before = a - alpha Tf c
+    auto rebase = [&](float alpha, float Tf, const float4 &c) {
+        asm volatile("; hot entry");
+        if (alpha > 0.99f) {
+            const float dT = (0.99f - alpha) * Tf;
+            sb0 = sb0 + invG * ((a0 - cb0) + dT * c.x);
+            sb1 = sb1 + invG * ((a1 - cb1) + dT * c.y);
+            sb2 = sb2 + invG * ((a2 - cb2) + dT * c.z);
+            cb0 = a0; cb1 = a1; cb2 = a2;
+            invG = invG * ((1.0f - 0.99f) * __builtin_amdgcn_rcpf(1.0f - alpha));
         }
+    };
+    auto record = [&](float first) {
+        return make_float4(first, sb0 + invG * (a0 - cb0), sb1 + invG * (a1 - cb1), sb2 + invG * (a2 - cb2));
     };
     int last = -1;   // list index of the last composited entry
     int le = -1;     // ... as a slot of the current chunk (turned into an index once per chunk)
@@ -292,7 +292,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         if (CK && c0 != range.x && ((c0 - range.x) & ((1 << seg_shift) - 1)) == 0) {
             const int k = (c0 - range.x) >> seg_shift;
             if (k < max_seg && inimg)
-                ckpt[(size_t)k * (GS_TILE * GS_TILE)] = make_float4(T * invG, hotw ? s0 : a0, hotw ? s1 : a1, hotw ? s2 : a2);
+                ckpt[(size_t)k * (GS_TILE * GS_TILE)] = record(T * invG);
         }
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
         const uint32_t touch = ntouch;
@@ -309,7 +309,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             __builtin_amdgcn_ballot_w64(touch != 0u && (__float_as_uint(n1.z) & 1u) != 0u) != 0ull;
         static_assert(!kChunkBinds, "the walks below are instantiated for the general case only");
         (void)chunk_binds;
-        const bool chunk_hot = CK && (hotw || __builtin_amdgcn_ballot_w64(touch != 0u && n1.y > 0.99f) != 0ull);
+        const bool chunk_hot = CK && __builtin_amdgcn_ballot_w64(touch != 0u && n1.y > 0.99f) != 0ull;
         // a block whose 16 pixels are all finished walks nothing
         uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
         uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
@@ -377,14 +377,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 asm volatile("; pixel saturates");
                 if (nT <= 1e-4f) { pyf = qnan(); alpha = 0.0f; nT = T; ok = false; }
             }
-            if (HOT) {
-                first_hot(alpha > 0.99f);
-                if (hotw) track(alpha, T, q2);
-            }
             const float w = alpha * T;
             a0 = a0 + w * q2.x;
             a1 = a1 + w * q2.y;
             a2 = a2 + w * q2.z;
+            if (HOT && __builtin_amdgcn_ballot_w64(alpha > 0.99f) != 0ull) rebase(alpha, T, q2);
             T = nT;
             le = ok ? e : le;
           }
@@ -458,27 +455,22 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                     pyf = qnan(); ab = 0.0f; nTb = nTa; okb = false;
                 }
             }
-            if (HOT) {
-                first_hot(aa > 0.99f || ab > 0.99f);
-                if (hotw) {
-                    track(aa, T, qa2);
-                    track(ab, nTa, qb2);
-                }
-            }
             const float wa = aa * T;
             a0 = a0 + wa * qa2.x;
             a1 = a1 + wa * qa2.y;
             a2 = a2 + wa * qa2.z;
+            if (HOT && __builtin_amdgcn_ballot_w64(aa > 0.99f) != 0ull) rebase(aa, T, qa2);
             const float wb = ab * nTa;
             a0 = a0 + wb * qb2.x;
             a1 = a1 + wb * qb2.y;
             a2 = a2 + wb * qb2.z;
+            if (HOT && __builtin_amdgcn_ballot_w64(ab > 0.99f) != 0ull) rebase(ab, nTa, qb2);
             T = nTb;
             le = okb ? eb : (oka ? ea : le);
           }
         };
         // (kChunkBinds is off: the general walk)  A chunk none of whose entries has an opacity above 0.99 cannot
-        // hold a hot entry (alpha <= opacity): until the wave has met one, such chunks walk without looking
+        // hold a hot entry (alpha <= opacity): such chunks walk without looking
         if constexpr (ILP == 2) {
             if (chunk_hot) walk2(std::true_type{}, std::true_type{}); else walk2(std::true_type{}, std::false_type{});
         } else {
@@ -500,7 +492,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         }
         final_Ts[pix] = T;
         final_idx[pix] = last;
-        if (CK) ckpt[0] = make_float4(invG, hotw ? s0 : a0, hotw ? s1 : a1, hotw ? s2 : a2);
+        if (CK) ckpt[0] = record(invG);
     }
 }
 
@@ -1329,7 +1321,7 @@ extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_st
     // Where pieces pay (SfM-like scenes, one-pass -> pieces, backward kernel alone): 432 tiles 141 -> 45 us,
     // 1504 tiles 234 -> 99, 3024 tiles 288 -> 128, 5922 tiles 402 -> 315; a full 1080p frame (8160 tiles) gains
     // 10 % on a scene with a long tail of lists and loses 5 % on BASELINE config 2's even one (no tail to cut,
-    // and its opaque Gaussians make the forward keep the backward's state: 170 -> 186 us).
+    // and its opaque Gaussians make the forward look for hot entries in most chunks: 170 -> 178 us).
     constexpr int kMaxTiles = 6144;
     if (tiles > kMaxTiles || !list_stats || list_stats[0] <= 0) return GS_OK;
     const int64_t longest = list_stats[1], mean = ((int64_t)list_stats[0] + tiles - 1) / tiles;
