@@ -573,17 +573,18 @@ def test_stale_list_statistics_only_cost_time():
     assert np.array_equal(np_(f["img"]), np_(ref["img"]))
 
 
-def test_sort_class_launch_policy_every_branch_and_every_stale_transition():
+@pytest.mark.parametrize("W,H,dense", [(160, 96, 1), (512, 520, 18)])
+def test_sort_class_launch_policy_every_branch_and_every_stale_transition(W, H, dense):
     """gs_bin_sort launches its classes after the PREVIOUS frame's {M, longest list}: the 512 class alone
     (longest <= 400), the 1024 class alone (longest <= 900, mean list > 300), the 512 + 1024 classes
-    (longest <= 900), all three otherwise.  Frames of each kind follow each other on ONE workspace, so that
-    every policy meets every kind of frame — also the ones it did not expect; ids and image must equal a
-    fresh run's (which launches everything) each time."""
+    (longest <= 900), all three otherwise; on a frame of at most 1024 tiles (launch-bound: the first case here,
+    60 tiles; the second has 1056) the 1024 class alone up to 900 and the 8192 + 1024 classes beyond.  Frames of
+    each kind follow each other on ONE workspace, so that every policy meets every kind of frame — also the
+    ones it did not expect; ids and image must equal a fresh run's (which launches everything) each time."""
     import torch
 
     from opensplat_amd import cabi
 
-    W, H = 160, 96
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
 
     def find(cond, candidates):
@@ -594,12 +595,14 @@ def test_sort_class_launch_policy_every_branch_and_every_stale_transition():
                 return sc, out
         pytest.fail("no candidate scene had the wanted list statistics")
 
-    short = find(lambda st: st[1] <= 400, [dict(N=1500, seed=73)])
+    # (`dense`: the frame's area in units of the small one — what an even scene needs more of for the same lists;
+    # the scenes whose long lists come from a hot spot keep their size)
+    short = find(lambda st: st[1] <= 400, [dict(N=1500 * dense, seed=73)])
     mid_dense = find(lambda st: 400 < st[1] <= 900 and st[0] > 300 * tiles,
-                     [dict(N=n, seed=75, sigma_px=(2.0, 5.0)) for n in range(8000, 30000, 1000)])
+                     [dict(N=n * dense, seed=75, sigma_px=(2.0, 5.0)) for n in range(8000, 30000, 1000)])
     mid_sparse = find(lambda st: 400 < st[1] <= 900 and st[0] <= 300 * tiles,
                       [dict(N=n, seed=76, sigma_px=(0.5, 2.0), hot=(0.3, 24)) for n in range(3000, 20000, 500)])
-    long_ = find(lambda st: st[1] > 1024, [dict(N=40000, seed=74, sigma_px=(2.0, 5.0))])
+    long_ = find(lambda st: st[1] > 1024, [dict(N=40000 * dense, seed=74, sigma_px=(2.0, 5.0))])
     ws = cabi.BinWorkspace()
     order = [mid_dense, mid_dense, long_, long_, mid_sparse, mid_sparse, long_, short, short, mid_dense,
              mid_sparse, short, long_, mid_dense, short, mid_sparse, mid_dense]
