@@ -1364,6 +1364,8 @@ extern "C" int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_i
     if ((uintptr_t)packed & 15u) return GS_ERR_INVALID_ARGUMENT;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
+    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
+        return GS_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
@@ -1371,8 +1373,6 @@ extern "C" int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_i
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
-    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
-        return GS_ERR_INVALID_ARGUMENT;
     float4 *ck = static_cast<float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
     // entries per step: two on a frame of lone waves (flag bits 23..24 force 1 / 2: measurements, tests)
@@ -1440,6 +1440,8 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
         return GS_ERR_WORKSPACE;
     const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
     const int tiles = tiles_x * tiles_y;
+    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
+        return GS_ERR_INVALID_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     const int2 *bins = reinterpret_cast<const int2 *>(tile_bins);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
@@ -1477,8 +1479,6 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    if (!checkpoint_args_ok(checkpoints, checkpoint_bytes, seg_len, max_segments, tiles))
-        return GS_ERR_INVALID_ARGUMENT;
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
     // pieces: pixels per lane by the tile count unless the flag bits say otherwise

@@ -194,3 +194,46 @@ def test_cpp_example_maps_one_hip_runtime_and_one_rccl():
     for stem in ("libamdhip64", "librccl", "libhsa-runtime64"):
         found = sorted({m.group(1) for m in re.finditer(r"=> (\S*%s\.so\S*)" % re.escape(stem), out)})
         assert len(found) == 1, (stem, found)
+
+
+def test_checkpoint_plan_rules_without_gpu():
+    """gs_rasterize_checkpoint_plan is host code: which frames get the backward in pieces, the
+    piece length, the record count and the buffer size; the checkpointed entry points refuse a buffer that
+    does not fit before touching the device."""
+    l = cabi.lib()
+
+    def plan(W, H, stats):
+        sl, ms, nb = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_size_t(1)
+        arr = (ctypes.c_int32 * 2)(*stats) if stats is not None else None
+        assert l.gs_rasterize_checkpoint_plan(W, H, arr, ctypes.byref(sl), ctypes.byref(ms), ctypes.byref(nb)) == 0
+        return sl.value, ms.value, nb.value
+
+    tiles = lambda W, H: ((W + 15) // 16) * ((H + 15) // 16)
+    # far from filling the chip: always, pieces of one chunk, records for the longest list + a quarter
+    sl, ms, nb = plan(384, 288, (60000, 900))
+    assert sl == 64 and ms * sl >= 900 * 5 // 4 and nb == tiles(384, 288) * ms * 4096
+    assert plan(96, 72, (20000, 2000))[2] > 0
+    # nothing worth cutting / no statistics yet / too many tiles
+    assert plan(384, 288, (5000, 100)) == (0, 0, 0)
+    assert plan(384, 288, None) == (0, 0, 0)
+    assert plan(384, 288, (0, 0)) == (0, 0, 0)
+    assert plan(1920, 1080, (2000000, 5000)) == (0, 0, 0)
+    # beyond 960 tiles only with a tail: a list four times the mean
+    assert plan(1008, 756, (600000, 2000))[2] > 0          # mean 199
+    assert plan(1008, 756, (1500000, 1200)) == (0, 0, 0)   # mean 497
+    assert plan(1504, 1000, (2300000, 1800))[2] > 0        # 5922 tiles, mean 389
+    # very long lists on many tiles: longer pieces keep tiles x records below 2^18 workgroups
+    sl, ms, nb = plan(1504, 1000, (3000000, 20000))
+    assert sl > 64 and sl & (sl - 1) == 0 and tiles(1504, 1000) * ms <= (1 << 18)
+    # invalid arguments
+    assert l.gs_rasterize_checkpoint_plan(0, 10, None, None, None, None) == -1
+    # a buffer that is too small / a piece length that is not a power of two: refused before any launch
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    bg = (ctypes.c_float * 3)(0.0, 0.0, 0.0)
+    fwd = (64, 64, one, one, one, one, bg, one, one, one, null, null, null, 0)
+    assert l.gs_rasterize_forward_ckpt(*fwd, one, ctypes.c_size_t(4096), 64, 4, null) == -1
+    assert l.gs_rasterize_forward_ckpt(*fwd, one, ctypes.c_size_t(16 * 4 * 4096), 96, 4, null) == -1
+    bwd = (64, 64, 10, one, one, one, one, bg, one, one, one, null, null, one, one, one, one, ctypes.c_void_p(64),
+           ctypes.c_size_t(1 << 20), null, null, 0)
+    assert l.gs_rasterize_backward_ckpt(*bwd, one, ctypes.c_size_t(4096), 64, 4, null) == -1
+    assert l.gs_rasterize_backward_ckpt(*bwd, ctypes.c_void_p(24), ctypes.c_size_t(1 << 20), 64, 4, null) == -1   # unaligned
