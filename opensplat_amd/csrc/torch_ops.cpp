@@ -375,6 +375,28 @@ bool validateBinning(BinnedLists &b) {
     return ok;
 }
 
+// The checkpoint buffer of one forward / backward pair of the compositing kernels, planned from the statistics of
+// the last validated frame of this (device, size) — gsplat_hip.h: gs_rasterize_checkpoint_plan; bytes = 0: the
+// plain schedule (a full frame, short lists, no statistics yet, or gsplatSetSegmentedBackward(false)).
+struct CheckpointPlan {
+    Tensor buffer;
+    size_t bytes = 0;
+    int32_t segLen = 0, maxSegments = 0;
+    void *ptr() const { return bytes ? buffer.data_ptr() : nullptr; }
+    Tensor saved(const torch::TensorOptions &f32) const {
+        return bytes ? buffer : torch::empty({0}, f32.dtype(torch::kUInt8));
+    }
+};
+static CheckpointPlan planCheckpoints(int device, int W, int H, const torch::TensorOptions &f32) {
+    CheckpointPlan cp;
+    if (!g_segmented.load()) return cp;
+    const BinState st = readBinState(device, W, H);
+    check_status(gs_rasterize_checkpoint_plan(W, H, st.listStats, &cp.segLen, &cp.maxSegments, &cp.bytes),
+                 "gs_rasterize_checkpoint_plan");
+    if (cp.bytes) cp.buffer = torch::empty({(int64_t)cp.bytes}, f32.dtype(torch::kUInt8));
+    return cp;
+}
+
 std::tuple<int64_t, int64_t> gsplatCov2dChannelCounters(bool reset) {
     auto r = std::make_tuple(g_cov2dHits.load(), g_cov2dMisses.load());
     if (reset) { g_cov2dHits = 0; g_cov2dMisses = 0; }
@@ -445,15 +467,19 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     auto f32 = xys.options();
     Tensor outImg = torch::empty({H, W, 3}, f32), finalTs = torch::empty({H, W}, f32);
     Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
+    // a frame that does not fill the chip, or with a tail of long lists (gsplat_hip.h:
+    // gs_rasterize_checkpoint_plan; planned from the last frame of this size): checkpoints for the backward
+    CheckpointPlan cp = planCheckpoints(xys.get_device(), W, H, f32);
     BinnedLists b;
     for (;;) {
         b = binAndSortPacked(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
-        check_status(gs_rasterize_forward(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
-                                          maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
-                                          fptr(b.packed), bg, fptr_mut(outImg), fptr_mut(finalTs),
-                                          finalIdx.data_ptr<int32_t>(), nullptr, nullptr,
-                                          b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
-                                          flags, current_stream()),
+        check_status(gs_rasterize_forward_ckpt(W, H, b.gaussianIdsSorted.data_ptr<int32_t>(),
+                                               maskptr(b.blockMasks), b.tileBins.data_ptr<int32_t>(),
+                                               fptr(b.packed), bg, fptr_mut(outImg), fptr_mut(finalTs),
+                                               finalIdx.data_ptr<int32_t>(), nullptr, nullptr,
+                                               b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
+                                               flags, cp.ptr(), cp.bytes, cp.segLen, cp.maxSegments,
+                                               current_stream()),
                      "gs_rasterize_forward");
         if (validateBinning(b)) break;
     }
@@ -462,12 +488,14 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     // this frame's own list statistics steer the backward's wave geometry
     ctx->saved_data["listM"] = (int64_t)b.listStats[0];
     ctx->saved_data["listLongest"] = (int64_t)b.listStats[1];
+    ctx->saved_data["segLen"] = (int64_t)cp.segLen;
+    ctx->saved_data["maxSegments"] = (int64_t)cp.maxSegments;
     ctx->saved_data["imgWidth"] = imgWidth;
     ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["flags"] = (int64_t)flags;
     ctx->saved_data["numPoints"] = N;
     ctx->save_for_backward({idsSorted, tileBins, packed, finalTs, finalIdx, bgHold, tileOrder,
-                            b.blockMasks});
+                            b.blockMasks, cp.saved(f32)});
     return outImg;
 }
 
@@ -477,7 +505,8 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     variable_list saved = ctx->get_saved_variables();
     Tensor idsSorted = saved[0], tileBins = saved[1], packed = saved[2];
     Tensor finalTs = saved[3], finalIdx = saved[4], bgHold = saved[5], tileOrder = saved[6];
-    Tensor blockMasks = saved[7];
+    Tensor blockMasks = saved[7], checkpoints = saved[8];
+    const size_t ckBytes = (size_t)checkpoints.numel();
     const int32_t listStats[2] = {(int32_t)ctx->saved_data["listM"].toInt(),
                                   (int32_t)ctx->saved_data["listLongest"].toInt()};
     c10::DeviceGuard guard(packed.device());
@@ -489,15 +518,18 @@ tensor_list RasterizeGaussians::backward(AutogradContext *ctx, tensor_list grad_
     Tensor v_colors = torch::empty({N, 3}, f32), v_opacity = torch::empty({N, 1}, f32);
     const size_t wsBytes = gs_rasterize_backward_workspace_bytes((int)N);
     Tensor ws = torch::empty({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
-    check_status(gs_rasterize_backward(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
-                                       maskptr(blockMasks),
-                                       tileBins.data_ptr<int32_t>(), fptr(packed), bg,
-                                       fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
-                                       nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
-                                       nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
-                                       fptr_mut(v_opacity), ws.data_ptr(), wsBytes, listStats,
-                                       tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
-                                       (uint32_t)ctx->saved_data["flags"].toInt(), current_stream()),
+    check_status(gs_rasterize_backward_ckpt(W, H, (int)N, idsSorted.data_ptr<int32_t>(),
+                                            maskptr(blockMasks),
+                                            tileBins.data_ptr<int32_t>(), fptr(packed), bg,
+                                            fptr(finalTs), finalIdx.data_ptr<int32_t>(), fptr(v_outImg),
+                                            nullptr /* v_out_alpha: zeros, rasterize_gaussians.cpp:108 */,
+                                            nullptr, fptr_mut(v_xy), fptr_mut(v_conic), fptr_mut(v_colors),
+                                            fptr_mut(v_opacity), ws.data_ptr(), wsBytes, listStats,
+                                            tileOrder.numel() ? tileOrder.data_ptr<int32_t>() : nullptr,
+                                            (uint32_t)ctx->saved_data["flags"].toInt(),
+                                            ckBytes ? checkpoints.data_ptr() : nullptr, ckBytes,
+                                            (int32_t)ctx->saved_data["segLen"].toInt(),
+                                            (int32_t)ctx->saved_data["maxSegments"].toInt(), current_stream()),
                  "gs_rasterize_backward");
     Tensor none;
     return {v_xy, none, none, v_conic, none, v_colors, v_opacity, none, none, none, none};
@@ -606,15 +638,7 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     // a frame of few tiles with long lists (the reduced resolutions a run starts with, model.cpp:85-92): the
     // forward leaves checkpoints along the lists, the backward runs their pieces side by side — planned
     // from the statistics of the last frame of this size (gsplat_hip.h: gs_rasterize_checkpoint_plan)
-    int32_t segLen = 0, maxSegments = 0;
-    size_t ckBytes = 0;
-    {
-        const BinState st = readBinState(means.get_device(), W, H);
-        if (g_segmented.load())
-            check_status(gs_rasterize_checkpoint_plan(W, H, st.listStats, &segLen, &maxSegments, &ckBytes),
-                         "gs_rasterize_checkpoint_plan");
-    }
-    Tensor checkpoints = ckBytes ? torch::empty({(int64_t)ckBytes}, f32.dtype(torch::kUInt8)) : Tensor();
+    CheckpointPlan ckp = planCheckpoints(means.get_device(), W, H, f32);
     BinnedLists b;
     for (;;) {
         b = binPackedRecords(packedAll, depths, H, W);
@@ -623,16 +647,15 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
                                                fptr(b.packed), bg, fptr_mut(imgRaw), fptr_mut(finalTs),
                                                finalIdx.data_ptr<int32_t>(), fptr_mut(img), nullptr,
                                                b.tileOrder.numel() ? b.tileOrder.data_ptr<int32_t>() : nullptr,
-                                               flags, ckBytes ? checkpoints.data_ptr() : nullptr, ckBytes,
-                                               segLen, maxSegments, s),
+                                               flags, ckp.ptr(), ckp.bytes, ckp.segLen, ckp.maxSegments, s),
                      "gs_rasterize_forward");
         if (validateBinning(b)) break;
     }
     Tensor packed = b.packed, idsSorted = b.gaussianIdsSorted, tileBins = b.tileBins, tileOrder = b.tileOrder;
     ctx->saved_data["listM"] = (int64_t)b.listStats[0];
     ctx->saved_data["listLongest"] = (int64_t)b.listStats[1];
-    ctx->saved_data["segLen"] = (int64_t)segLen;
-    ctx->saved_data["maxSegments"] = (int64_t)maxSegments;
+    ctx->saved_data["segLen"] = (int64_t)ckp.segLen;
+    ctx->saved_data["maxSegments"] = (int64_t)ckp.maxSegments;
 
     ctx->saved_data["imgWidth"] = imgWidth; ctx->saved_data["imgHeight"] = imgHeight;
     ctx->saved_data["fx"] = fx; ctx->saved_data["fy"] = fy;
@@ -647,8 +670,7 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     ctx->save_for_backward({means, logScales, quats, vmHold, pmHold, radii, rgbRaw, idsSorted,
                             tileBins, packed, finalTs, finalIdx, imgRaw,
                             gradOut.defined() ? gradOut : torch::empty({0}, f32), bgHold, cpHold,
-                            tileOrder, opacityLogits, b.blockMasks,
-                            ckBytes ? checkpoints : torch::empty({0}, f32.dtype(torch::kUInt8))});
+                            tileOrder, opacityLogits, b.blockMasks, ckp.saved(f32)});
     Tensor xysOut = xys.detach();
     ctx->mark_non_differentiable({xysOut, radii});
     return {img, xysOut, radii};

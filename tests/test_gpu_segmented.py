@@ -285,3 +285,41 @@ def test_splat_render_uses_the_pieces_from_its_second_frame_on():
         tol = 2e-5 if n in ("opacity_logits", "features_dc", "features_rest", "xys") else 2e-3
         assert rel_err(np_(b), np_(a)) < tol, n
     assert not all(torch.equal(a, b) for a, b in zip(g0, g1)), "the segmented backward did not run"
+
+
+def test_rasterize_gaussians_operator_uses_the_pieces_from_its_second_frame_on():
+    """The drop-in operator an unmodified model.cpp calls (rasterize_gaussians.hpp:23-37, ten arguments): from the
+    second frame of a size on its backward runs in pieces; image the same bits, the four compositing-level
+    gradients within summation order of the one-pass backward."""
+    import torch
+
+    from opensplat_amd import ops
+
+    s = _deep_scene()    # random opacities up to 1: hot entries included
+    v_img = to_dev(np.random.RandomState(5).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32))
+
+    def run():
+        t = lambda a, rg=False: to_dev(a).requires_grad_(rg)
+        p = ops.project_gaussians(t(s.means), t(s.scales), 1.0, t(s.quats), t(s.viewmat), t(s.projmat),
+                                  s.fx, s.fy, s.cx, s.cy, s.H, s.W)
+        xys, conics = p[0].detach().requires_grad_(True), p[3].detach().requires_grad_(True)
+        colors, opac = t(s.colors, True), t(s.opacities, True)
+        img = ops.rasterize_gaussians(xys, p[1], p[2], conics, p[4], colors, opac, s.H, s.W, t(s.background),
+                                      p[6])
+        img.backward(v_img)
+        torch.cuda.synchronize()
+        return img.detach().clone(), [x.grad.clone() for x in (xys, conics, colors, opac)]
+
+    try:
+        ops.binning_reset()
+        ops.set_segmented_backward(False)
+        img0, g0 = run()
+        ops.set_segmented_backward(True)
+        img1, g1 = run()      # statistics of the frame above: planned
+    finally:
+        ops.set_segmented_backward(True)
+    assert torch.equal(img0, img1)
+    for n, a, b in zip(("xys", "conics", "colors", "opacity"), g0, g1):
+        assert torch.isfinite(b).all(), n
+        assert rel_err(np_(b), np_(a)) < 2e-5, n
+    assert not all(torch.equal(a, b) for a, b in zip(g0, g1)), "the segmented backward did not run"
