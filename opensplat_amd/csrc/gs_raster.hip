@@ -515,6 +515,34 @@ __device__ __forceinline__ int reduce9_component(int li) {
     const int bank_value = ((b & 1) << 1) | (b >> 1);   // banks hold values 0, 2, 1, 3 (+4 for s1)
     return j == 0 ? bank_value : (j == 1 ? 4 + bank_value : (li == 2 ? 8 : -1));
 }
+// Stages A and B alone: they sum over the ORBIT of a lane under {row_mirror, row_half_mirror} — the four lanes
+// {l, 7 - l, 8 + l, 15 - l}, l = 0..3, one in each bank of the row.  Afterwards the lane in bank b holds the
+// orbit's total of value {0, 2, 1, 3}[b] in s0, of value 4 + {0, 2, 1, 3}[b] in s1 and of value 8 in s2: a
+// complete nine-value reduction over FOUR-lane groups in 14 VALU — sixteen groups per wave (backward_wave_q).
+__device__ __forceinline__ void orbit_reduce9(float v0, float v1, float v2, float v3, float v4, float v5,
+                                              float v6, float v7, float v8, float &s0, float &s1,
+                                              float &s2) {
+    float r01 = v0 + dpp_f<0x140>(v0);  // row_mirror
+    float r23 = v2 + dpp_f<0x140>(v2);
+    float r45 = v4 + dpp_f<0x140>(v4);
+    float r67 = v6 + dpp_f<0x140>(v6);
+    const float r8 = v8 + dpp_f<0x140>(v8);
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %2, %6, %6 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %3, %7, %7 row_mirror row_mask:0xf bank_mask:0xc"
+                 : "+v"(r01), "+v"(r23), "+v"(r45), "+v"(r67)
+                 : "v"(v1), "v"(v3), "v"(v5), "v"(v7));
+    s0 = r01 + dpp_f<0x141>(r01);  // row_half_mirror
+    s1 = r45 + dpp_f<0x141>(r45);
+    s2 = r8 + dpp_f<0x141>(r8);
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
+                 : "+v"(s0), "+v"(s1)
+                 : "v"(r23), "v"(r67));
+}
 __device__ __forceinline__ float row_reduce9(float v0, float v1, float v2, float v3, float v4,
                                              float v5, float v6, float v7, float v8, bool odd,
                                              bool bit1) {
@@ -1010,6 +1038,350 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: SIXTEEN GROUPS OF FOUR LANES ("Q geometry").  A wave is still one tile with four pixels per
+// lane, but a group is FOUR lanes that own one 4 x 4-pixel block (a lane = one column of the block, its four
+// pixels the block's rows), and every one of the sixteen groups walks ITS OWN list — the entries of the staged
+// chunk whose coverage-mask bit for that block is set: sixteen different Gaussians per instruction stream.
+//   * why: with 8 x 8 blocks a Gaussian covers 16 - 17 of the 64 pixel slots of a pass (26 % live lanes,
+//     profiles/work_stats_r04_c2.json); a 4 x 4 block it reaches it covers to 52 %, and all four passes of a
+//     step are always needed.  scripts/sim_bwd_geometry.py (the same lists rebuilt on the host, checked against
+//     the instrumented kernel's counters): 0.30 steps per list entry at 71 % group fill against 0.47 steps at
+//     3.65 passes — 0.68 x the VALU instructions at 64-entry chunks, 0.62 x at 128.
+//   * the walk cannot be scalar any more (sixteen s_ff1 chains per step): per chunk the wave builds sixteen
+//     QUEUES of slot numbers in LDS — one ballot per block bit, trimmed by the block's last contributor, ranks by
+//     v_mbcnt, a byte store per (block, entry) pair — and a step is one ds_read_u8 with a per-group address;
+//     the queues are pre-filled with the sentinel slot, so an exhausted group reads the NaN record by itself.
+//     The step count of a chunk is the longest queue (scalar: sixteen s_bcnt1 + s_max).
+//   * the nine sums of a step are reduced over the group's four lanes by the first two stages of the row
+//     butterfly alone (orbit_reduce9, 14 VALU: the groups are the orbits {l, 7-l, 8+l, 15-l} of row_mirror and
+//     row_half_mirror, one lane in each DPP bank) and go to the per-entry LDS accumulators with three ds_add_f32
+//     (every lane two components, the bank-0 lane the ninth).
+// Everything per pixel — thresholds, the exact re-evaluation inside the band, the recurrences — is
+// backward_wave's, statement for statement; flush and gradient records are unchanged.
+struct __attribute__((aligned(16))) SRecQ {
+    float4 p0, p1, p2;   // {x y A' B' | C' o s_hi s_lo | r g b C}   (A' = A log2 e ...; C unscaled for the rare paths)
+};
+template <int CH>
+struct QLds {
+    SRecQ stage[CH + 1];
+    float4 rare[CH + 1];                 // {rx, ry, A, B}: rectangle words and the unscaled conic (rare paths, flush)
+    alignas(16) uint8_t queue[16 * CH + 16];   // [block][rank] -> slot; (+16: the read one step ahead)
+    float acc[kAcc * (CH + 1)];          // component-major, odd stride
+    int sid[CH];
+};
+
+template <bool EXACT, bool DET, int CH>
+__device__ __forceinline__ void
+backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const int32_t *__restrict__ ids,
+                const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
+                const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    static_assert(CH == 64 || CH == 128, "one or two staged entries per lane");
+    static_assert((GS_BWD_LOG2E & GS_BWD_SIGMA_THRESH) != 0, "the Q walk is written for the sigma' thresholds");
+    constexpr int NS = CH / 64;          // staged entries per lane
+    constexpr int AS = CH + 1;           // accumulator stride
+    constexpr int PX = 4;
+    const int lane = threadIdx.x;
+    if (bg_dev) {
+        bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
+    }
+    // lane -> (block, column): row of lanes = block row; the orbit index q = block column; DPP bank = column
+    const int brow = lane >> 4, l16 = lane & 15, bank = l16 >> 2;
+    const int bcol = (bank & 1) ? 3 - (l16 & 3) : (l16 & 3);
+    const int grp = 4 * brow + bcol;                    // == the block's bit in the coverage mask
+    const int c0 = ((bank & 1) << 1) | (bank >> 1);     // the component orbit_reduce9 leaves in s0 (s1: 4 + c0)
+    const int fj = (lane * 7282) >> 16;                 // flush: lane = 9 * fj + fcomp (lane 63: no work)
+    const int fcomp = lane == 63 ? kAcc : lane - 9 * fj;
+    const int px = tx0 + 4 * bcol + bank;
+    const int py0 = ty0 + 4 * brow;                     // pixel p of the lane: row py0 + p
+    const float pxf = (float)px;
+    float pyf[PX], T[PX], D[PX], vo0[PX], vo1[PX], vo2[PX];
+    int last[PX];
+    int gl = -1;
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+        const int py = py0 + p;
+        float Tfin = 1.0f, oa = 0.0f;
+        vo0[p] = vo1[p] = vo2[p] = 0.0f;
+        last[p] = -1;
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px;
+            Tfin = final_Ts[pix];
+            last[p] = final_idx[pix];
+            vo0[p] = v_out[3 * pix + 0];
+            vo1[p] = v_out[3 * pix + 1];
+            vo2[p] = v_out[3 * pix + 2];
+            if (img_raw) {  // backward of the fused clamp_max(rgb, 1)
+                if (!(img_raw[3 * pix + 0] <= 1.0f)) vo0[p] = 0.0f;
+                if (!(img_raw[3 * pix + 1] <= 1.0f)) vo1[p] = 0.0f;
+                if (!(img_raw[3 * pix + 2] <= 1.0f)) vo2[p] = 0.0f;
+            }
+            oa = v_out_alpha ? v_out_alpha[pix] : 0.0f;
+        }
+        pyf[p] = (float)py;
+        T[p] = Tfin;
+        D[p] = Tfin * (oa - (bg0 * vo0[p] + bg1 * vo1[p] + bg2 * vo2[p]));
+        gl = max(gl, last[p]);
+    }
+    // last contributor of each block (its four lanes: the orbit) and of the wave
+    gl = max(gl, dpp_i<0x140>(gl));
+    gl = max(gl, dpp_i<0x141>(gl));
+    int sgl[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) sgl[g] = __builtin_amdgcn_readlane(gl, 16 * (g >> 2) + (g & 3));
+    int wave_last = sgl[0];
+#pragma unroll
+    for (int g = 1; g < 16; g++) wave_last = max(wave_last, sgl[g]);
+    const int2 range = bins[tile];
+    if (wave_last < range.x) return;
+
+    if (lane == 0) {
+        stage_sentinel(&lds.stage[CH]);
+        lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < kAcc; i++)
+#pragma unroll
+        for (int j = 0; j < NS; j++) lds.acc[i * AS + lane + 64 * j] = 0.0f;
+
+    int ng[NS];
+    uint32_t nmask[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        ng[j] = 0; nmask[j] = 0u;
+        const int idx = wave_last - lane - 64 * j;
+        if (idx >= range.x) { ng[j] = ids[idx]; nmask[j] = masks[idx]; }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p] + CH;   // (no contributor: beyond any slot)
+    const uint8_t *myq = &lds.queue[grp * CH];
+    float *acc0 = &lds.acc[c0 * AS];
+    for (int hi = wave_last; hi >= range.x; hi -= CH) {
+#pragma unroll
+        for (int p = 0; p < PX; p++) last[p] -= CH;   // now relative to this chunk's first slot
+        __syncthreads();
+        uint32_t msk[NS];
+        bool binds_t = false;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            msk[j] = nmask[j];
+            const int t = lane + 64 * j;
+            if (msk[j]) {
+                const float4 n0 = packed[3 * (size_t)ng[j] + 0], n1 = packed[3 * (size_t)ng[j] + 1],
+                             n2 = packed[3 * (size_t)ng[j] + 2];
+                const uint32_t sb = __float_as_uint(n1.z);
+                // L' -+ band; an opacity that cannot reach 1/255 at all gets the empty interval [0, 0]
+                float s_hi = 0.0f, s_lo = -1.0f;
+                if (n1.y > 0.0f) {
+                    const float Lp = __builtin_amdgcn_logf(255.0f * n1.y);   // v_log_f32: log2
+                    if (Lp + kSigBand >= 0.0f) { s_hi = Lp + kSigBand; s_lo = Lp - kSigBand; }
+                }
+                const float sm = __uint_as_float((__float_as_uint(s_hi) & ~1u) | (sb & 1u));
+                lds.stage[t].p0 = make_float4(n0.x, n0.y, n0.z * kLog2e, n0.w * kLog2e);
+                lds.stage[t].p1 = make_float4(n1.x * kLog2e, n1.y, sm, s_lo);
+                lds.stage[t].p2 = make_float4(n2.x, n2.y, n2.z, n1.x);
+                lds.rare[t] = make_float4(n1.w, n2.w, n0.z, n0.w);
+                binds_t = binds_t || (sb & 1u) != 0u;
+            }
+            if (hi - t >= range.x) lds.sid[t] = ng[j];
+        }
+        const bool chunk_binds = __builtin_amdgcn_ballot_w64(binds_t) != 0ull;
+        // ---- the sixteen queues ----
+        {
+            const uint32_t fill = CH * 0x01010101u;   // the sentinel slot in every byte
+            uint4 *qf = reinterpret_cast<uint4 *>(lds.queue);
+#pragma unroll
+            for (int j = 0; j < NS; j++) qf[lane + 64 * j] = make_uint4(fill, fill, fill, fill);
+            if (lane == 0) qf[64 * NS] = make_uint4(fill, fill, fill, fill);
+        }
+        int nsteps = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                uint64_t m = __builtin_amdgcn_ballot_w64((msk[j] & (1u << g)) != 0u);
+                // slot t has list index hi - t: needed by the block only if hi - t <= its last contributor
+                const int d = hi - sgl[g] - 64 * j;
+                if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    lds.queue[g * CH + base + rank] = (uint8_t)(lane + 64 * j);
+                }
+                base += __builtin_popcountll(m);
+            }
+            GS_STAT(11, base);
+            nsteps = max(nsteps, base);
+        }
+        GS_STAT(12, 1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            nmask[j] = 0u;
+            const int idx = hi - CH - lane - 64 * j;
+            if (idx >= range.x) { ng[j] = ids[idx]; nmask[j] = masks[idx]; }
+        }
+        if (nsteps == 0) continue;
+        bool flushed_any = false;  // wave-uniform
+        auto walk = [&](auto binds_tag) {
+            constexpr bool BINDS = decltype(binds_tag)::value;
+            int e_next = myq[0];
+            for (int k = 0; k < nsteps; k++) {
+                const int e = e_next;
+                const float4 q0 = lds.stage[e].p0, q1 = lds.stage[e].p1, q2 = lds.stage[e].p2;
+                e_next = myq[k + 1];
+                const uint32_t sbits = __float_as_uint(q1.z);
+                GS_STAT(8, 1);
+                const float dx = q0.x - pxf;
+                const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
+                const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
+                const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
+                float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
+                uint64_t anym = 0ull;
+#pragma unroll
+                for (int p = 0; p < PX; p++) {
+                    const float dy = q0.y - pyf[p];
+                    float sg = fmaf(hC * dy, dy, hAdxdx);
+                    sg = fmaf(Bdx, dy, sg);
+                    if (any_binds) {
+                        asm volatile("; rectangle binds");
+                        if (sbits & 1u) {
+                            // decide exactly like the forward: its op order for sigma, rectangle applied
+                            const float4 q3 = lds.rare[e];
+                            float se = ((q3.z * dx) * dx) + (q2.w * dy) * dy;
+                            se = 0.5f * se;
+                            se = se + (q3.w * dx) * dy;
+                            const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y);
+                            const uint32_t pyu = (uint32_t)(py0 + p);
+                            const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                            pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
+                            sg = in ? (se + 0.0f) * kLog2e : qnan();
+                        }
+                    }
+                    const uint64_t mneed = __builtin_amdgcn_ballot_w64(e >= last[p]) &
+                                           __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
+                    if (mneed == 0ull) continue;
+                    anym |= mneed;
+                    GS_STAT(9, 1);
+                    GS_STAT(10, __builtin_popcountll(mneed));
+                    float vis = __builtin_amdgcn_exp2f(-sg);   // sg = sigma log2(e)
+                    uint64_t mok;
+                    if (EXACT) {
+                        const uint64_t bhi = __builtin_amdgcn_ballot_w64(sg <= q1.w);
+                        mok = mneed & bhi;
+                        if (mok != mneed) {   // some lane sits in the band
+                            asm volatile("; threshold ambiguous");
+                            bool in = false;
+                            if (__builtin_amdgcn_inverse_ballot_w64(mneed & ~bhi)) {
+                                const float4 q3 = lds.rare[e];
+                                float se = ((q3.z * dx) * dx) + (q2.w * dy) * dy;
+                                se = 0.5f * se;
+                                se = se + (q3.w * dx) * dy;
+                                vis = expf_glibc_cmem(-se);
+                                in = q1.y * vis >= (1.0f / 255.0f);
+                            }
+                            mok |= __builtin_amdgcn_ballot_w64(in);
+                        }
+                    } else {
+                        mok = mneed & __builtin_amdgcn_ballot_w64(q1.y * vis >= (1.0f / 255.0f));
+                    }
+                    vis = __builtin_amdgcn_inverse_ballot_w64(mok) ? vis : 0.0f;
+                    const float alpha = fminf(q1.y * vis, 0.99f);
+                    const float om = 1.0f - alpha;
+                    const float ra = __builtin_amdgcn_rcpf(om);
+                    T[p] = T[p] * ra;
+                    const float fac = alpha * T[p];
+                    gr = fmaf(fac, vo0[p], gr);
+                    gg = fmaf(fac, vo1[p], gg);
+                    gb = fmaf(fac, vo2[p], gb);
+                    const float cv = fmaf(q2.z, vo2[p], fmaf(q2.y, vo1[p], q2.x * vo0[p]));
+                    const float v_alpha = fmaf(T[p], cv, ra * D[p]);
+                    D[p] = fmaf(-fac, cv, D[p]);
+                    const float u = vis * v_alpha;
+                    const float uy = u * dy;
+                    su += u;
+                    suy += uy;
+                    suyy = fmaf(uy, dy, suyy);
+                }
+                if (anym == 0ull) continue;
+                const float ux = su * dx;
+                float s0, s1, s2;
+                orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
+                if (e < CH) {   // (an exhausted group has nothing to add; its dx is NaN)
+                    __hip_atomic_fetch_add(&acc0[e], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&acc0[4 * AS + e], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (bank == 0)
+                        __hip_atomic_fetch_add(&lds.acc[8 * AS + e], s2, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                flushed_any = true;
+            }
+        };
+        if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
+        if (!flushed_any) continue;
+        // ---- flush: as backward_wave ----
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int t = lane + 64 * j;
+            if (msk[j] != 0u) {   // (only slots staged THIS chunk, see backward_wave)
+                const float Ux = lds.acc[0 * AS + t], Uy = lds.acc[1 * AS + t];
+                const float Uxx = lds.acc[2 * AS + t], Uxy = lds.acc[3 * AS + t];
+                const float Uyy = lds.acc[4 * AS + t];
+                const float mo = -lds.stage[t].p1.y;          // v_sigma = -opacity * u
+                const float A = lds.rare[t].z, B = lds.rare[t].w, C = lds.stage[t].p2.w;
+                lds.acc[0 * AS + t] = mo * fmaf(A, Ux, B * Uy);
+                lds.acc[1 * AS + t] = mo * fmaf(B, Ux, C * Uy);
+                lds.acc[2 * AS + t] = 0.5f * mo * Uxx;
+                lds.acc[3 * AS + t] = 0.5f * mo * Uxy;
+                lds.acc[4 * AS + t] = 0.5f * mo * Uyy;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < (CH + 6) / 7; i++) {
+            const int ent = 7 * i + fj;
+            if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
+                const float v = lds.acc[fcomp * AS + ent];
+                if (v != 0.0f) {
+                    const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
+                    if (DET)
+                        atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
+                                                fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
+                    else
+                        atomicAdd(gacc + o, v);
+                }
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < kAcc; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) lds.acc[i * AS + lane + 64 * j] = 0.0f;
+    }
+}
+
+template <bool EXACT, bool DET, int CH>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                       const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
+                       const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
+                       float bg2, const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                       const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                       const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                       float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    __shared__ QLds<CH> lds;
+    int tile, wx0, wy0;
+    if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
+    backward_wave_q<EXACT, DET, CH>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
+                                    final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+}
+
 // One geometry for every tile (flag bits 21..22: measurements, the wave-geometry tests).
 template <bool EXACT, bool DET, int PX>
 // (four pixels per lane at 96 VGPRs keep eight values in scratch, touched once per CHUNK, not per step:
@@ -1479,6 +1851,8 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
+    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q), 64- / 128-entry chunks
+    const int qgeom = (int)((flags >> 25) & 3u);
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
     // pieces: pixels per lane by the tile count unless the flag bits say otherwise
@@ -1498,9 +1872,15 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x,     \
               tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted, block_masks, bins, \
               pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+#define GS_Q_LAUNCH3(EX, DT, CHN)                                                                         \
+    GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT, CHN>), dim3(8 * ((tiles + 7) / 8)), dim3(64), 0, s, W, H, \
+              tiles_x, tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
+              bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                                  \
+        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 64);                                                   \
+        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 128);                                             \
+        else if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                             \
         else if (ck && seg_px == 2) GS_SEG_LAUNCH3(EX, DT, 2);                                             \
         else if (ck) GS_SEG_LAUNCH3(EX, DT, 4);                                                            \
         else if (px_per_lane == 1) GS_BWD_LAUNCH3(EX, DT, 1);                                              \
@@ -1518,6 +1898,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, false); else GS_BWD_LAUNCH(true, false);
     }
 #undef GS_BWD_LAUNCH3
+#undef GS_Q_LAUNCH3
 #undef GS_SEG_LAUNCH3
 #undef GS_BWD_LAUNCH
     gs::ev_after(s);

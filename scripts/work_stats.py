@@ -32,8 +32,11 @@ v = list(buf)
 fwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[0:5]))
 bwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[8:13]))
 M = pipe.num_isects
+# flag bits 25..26 of GSPLAT_BWD_FLAGS: the backward with sixteen four-lane groups per wave
+bwd_groups = 16 if (int(os.environ.get("GSPLAT_BWD_FLAGS", "0"), 0) >> 25) & 3 else 4
 for d in (fwd, bwd):
     d["steps_per_list_entry"] = d["steps"] / max(M, 1)
-    d["ideal_steps_if_groups_balanced"] = d["block_entries"] / 4.0
+    d["groups_per_wave"] = bwd_groups if d is bwd else 4
+    d["ideal_steps_if_groups_balanced"] = d["block_entries"] / float(d["groups_per_wave"])
     d["live_lanes_per_needing_step"] = d["needing_lanes"] / max(d["steps_with_a_needing_lane"], 1)
 print(json.dumps({"M": M, "forward": fwd, "backward": bwd}))
