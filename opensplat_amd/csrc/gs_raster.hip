@@ -1047,7 +1047,7 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 //     profiles/work_stats_r04_c2.json); a 4 x 4 block it reaches it covers to 52 %, and all four passes of a
 //     step are always needed.  scripts/sim_bwd_geometry.py (the same lists rebuilt on the host, checked against
 //     the instrumented kernel's counters): 0.30 steps per list entry at 71 % group fill against 0.47 steps at
-//     3.65 passes — 0.68 x the VALU instructions at 64-entry chunks, 0.62 x at 128.
+//     3.65 passes — 0.68 x the VALU instructions; measured 1.53e8 -> 1.04e8 (profiles/r05/).
 //   * the walk cannot be scalar any more (sixteen s_ff1 chains per step): per chunk the wave builds sixteen
 //     QUEUES of slot numbers in LDS — one ballot per block bit, trimmed by the block's last contributor, ranks by
 //     v_mbcnt, a byte store per (block, entry) pair — and a step is one ds_read_u8 with a per-group address;
@@ -1055,41 +1055,52 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 //     The step count of a chunk is the longest queue (scalar: sixteen s_bcnt1 + s_max).
 //   * the nine sums of a step are reduced over the group's four lanes by the first two stages of the row
 //     butterfly alone (orbit_reduce9, 14 VALU: the groups are the orbits {l, 7-l, 8+l, 15-l} of row_mirror and
-//     row_half_mirror, one lane in each DPP bank) and go to the per-entry LDS accumulators with three ds_add_f32
-//     (every lane two components, the bank-0 lane the ninth).
+//     row_half_mirror, one lane in each DPP bank).
+//   * NO LDS ATOMICS.  The first version added the group's sums to per-entry accumulators with ds_add_f32 like
+//     backward_wave does: 144 atomic lanes per step, and an LDS float atomic costs ~2.2 LDS cycles PER LANE
+//     (SQ_LDS_IDX_ACTIVE 1.2e8 -> 2.3e8, SQ_WAIT_INST_LDS 2.2e7 -> 4.5e8: 442 us against 294, LDS-bound,
+//     profiles/r05/q64_ldsatomic_*).  A (block, entry) pair is visited exactly once, so its nine sums are now
+//     PLAIN stores into the pair's own 40-byte record (pair slots are handed out group by group while the queues
+//     are built: slot = first slot of the group + rank), and after the walk lane t adds up the records of entry
+//     t's pairs (sixteen exec-masked rounds, one per block bit, in a fixed order: the per-wave sum is
+//     deterministic), converts moments to gradient components and hands them to the record-major global flush.
+//     The pair buffer bounds a chunk (PMAX pairs): a chunk whose entries make more pairs is cut short and the
+//     following chunks stage fewer entries (big Gaussians: BASELINE config 3).
 // Everything per pixel — thresholds, the exact re-evaluation inside the band, the recurrences — is
-// backward_wave's, statement for statement; flush and gradient records are unchanged.
+// backward_wave's, statement for statement; the gradient records are unchanged.
 struct __attribute__((aligned(16))) SRecQ {
     float4 p0, p1, p2;   // {x y A' B' | C' o s_hi s_lo | r g b C}   (A' = A log2 e ...; C unscaled for the rare paths)
 };
-template <int CH>
+constexpr int kQChunk = 64;
+constexpr int kPairRec = 10;   // floats per pair record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
+template <int PMAX>
 struct QLds {
-    SRecQ stage[CH + 1];
-    float4 rare[CH + 1];                 // {rx, ry, A, B}: rectangle words and the unscaled conic (rare paths, flush)
-    alignas(16) uint8_t queue[16 * CH + 16];   // [block][rank] -> slot; (+16: the read one step ahead)
-    float acc[kAcc * (CH + 1)];          // component-major, odd stride
-    int sid[CH];
+    static_assert(PMAX >= 128 && PMAX * kPairRec >= kAcc * (kQChunk + 1), "pair buffer also holds the flush's accumulators");
+    SRecQ stage[kQChunk + 1];
+    float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
+    alignas(16) uint8_t queue[16 * kQChunk + 16];      // [block][rank] -> slot; (+16: the read one step ahead)
+    alignas(16) float pairs[PMAX * kPairRec];          // pair records; after the gather: acc[component][slot]
+    int sid[kQChunk];
 };
 
-template <bool EXACT, bool DET, int CH>
+template <bool EXACT, bool DET, int PMAX>
 __device__ __forceinline__ void
-backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const int32_t *__restrict__ ids,
+backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const int32_t *__restrict__ ids,
                 const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
                 const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
                 const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                 const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                 const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                 float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
-    static_assert(CH == 64 || CH == 128, "one or two staged entries per lane");
     static_assert((GS_BWD_LOG2E & GS_BWD_SIGMA_THRESH) != 0, "the Q walk is written for the sigma' thresholds");
-    constexpr int NS = CH / 64;          // staged entries per lane
-    constexpr int AS = CH + 1;           // accumulator stride
+    constexpr int CH = kQChunk;
+    constexpr int AS = CH + 1;           // accumulator stride of the flush
     constexpr int PX = 4;
     const int lane = threadIdx.x;
     if (bg_dev) {
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
-    // lane -> (block, column): row of lanes = block row; the orbit index q = block column; DPP bank = column
+    // lane -> (block, column): row of lanes = block row; the orbit index = block column; DPP bank = column
     const int brow = lane >> 4, l16 = lane & 15, bank = l16 >> 2;
     const int bcol = (bank & 1) ? 3 - (l16 & 3) : (l16 & 3);
     const int grp = 4 * brow + bcol;                    // == the block's bit in the coverage mask
@@ -1143,91 +1154,84 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const i
         stage_sentinel(&lds.stage[CH]);
         lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    int ng = 0;
+    uint32_t nmask = 0u;
+    if (wave_last - lane >= range.x) { ng = ids[wave_last - lane]; nmask = masks[wave_last - lane]; }
 #pragma unroll
-    for (int i = 0; i < kAcc; i++)
-#pragma unroll
-        for (int j = 0; j < NS; j++) lds.acc[i * AS + lane + 64 * j] = 0.0f;
-
-    int ng[NS];
-    uint32_t nmask[NS];
-#pragma unroll
-    for (int j = 0; j < NS; j++) {
-        ng[j] = 0; nmask[j] = 0u;
-        const int idx = wave_last - lane - 64 * j;
-        if (idx >= range.x) { ng[j] = ids[idx]; nmask[j] = masks[idx]; }
-    }
-#pragma unroll
-    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p] + CH;   // (no contributor: beyond any slot)
+    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p];   // relative to the chunk's first slot (-1: beyond)
     const uint8_t *myq = &lds.queue[grp * CH];
-    float *acc0 = &lds.acc[c0 * AS];
-    for (int hi = wave_last; hi >= range.x; hi -= CH) {
-#pragma unroll
-        for (int p = 0; p < PX; p++) last[p] -= CH;   // now relative to this chunk's first slot
+    int n_nom = CH;   // entries staged per chunk: fewer once a chunk overflowed the pair buffer
+    int adv = 0;
+    for (int hi = wave_last; hi >= range.x; hi -= adv) {
         __syncthreads();
-        uint32_t msk[NS];
-        bool binds_t = false;
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            msk[j] = nmask[j];
-            const int t = lane + 64 * j;
-            if (msk[j]) {
-                const float4 n0 = packed[3 * (size_t)ng[j] + 0], n1 = packed[3 * (size_t)ng[j] + 1],
-                             n2 = packed[3 * (size_t)ng[j] + 2];
-                const uint32_t sb = __float_as_uint(n1.z);
-                // L' -+ band; an opacity that cannot reach 1/255 at all gets the empty interval [0, 0]
-                float s_hi = 0.0f, s_lo = -1.0f;
-                if (n1.y > 0.0f) {
-                    const float Lp = __builtin_amdgcn_logf(255.0f * n1.y);   // v_log_f32: log2
-                    if (Lp + kSigBand >= 0.0f) { s_hi = Lp + kSigBand; s_lo = Lp - kSigBand; }
-                }
-                const float sm = __uint_as_float((__float_as_uint(s_hi) & ~1u) | (sb & 1u));
-                lds.stage[t].p0 = make_float4(n0.x, n0.y, n0.z * kLog2e, n0.w * kLog2e);
-                lds.stage[t].p1 = make_float4(n1.x * kLog2e, n1.y, sm, s_lo);
-                lds.stage[t].p2 = make_float4(n2.x, n2.y, n2.z, n1.x);
-                lds.rare[t] = make_float4(n1.w, n2.w, n0.z, n0.w);
-                binds_t = binds_t || (sb & 1u) != 0u;
+        // ---- the sixteen queues, pair slots group by group; cut the chunk if its pairs exceed the buffer ----
+        int nsteps, npairs, n_ent = n_nom;
+        int startv = 0;   // lane g (< 16): first pair slot of block g
+        for (;;) {
+            const uint32_t mskb = lane < n_ent ? nmask : 0u;
+            {
+                const uint32_t fill = CH * 0x01010101u;   // the sentinel slot in every byte
+                uint4 *qf = reinterpret_cast<uint4 *>(lds.queue);
+                qf[lane] = make_uint4(fill, fill, fill, fill);
+                if (lane == 0) qf[64] = make_uint4(fill, fill, fill, fill);
             }
-            if (hi - t >= range.x) lds.sid[t] = ng[j];
-        }
-        const bool chunk_binds = __builtin_amdgcn_ballot_w64(binds_t) != 0ull;
-        // ---- the sixteen queues ----
-        {
-            const uint32_t fill = CH * 0x01010101u;   // the sentinel slot in every byte
-            uint4 *qf = reinterpret_cast<uint4 *>(lds.queue);
+            nsteps = 0; npairs = 0;
 #pragma unroll
-            for (int j = 0; j < NS; j++) qf[lane + 64 * j] = make_uint4(fill, fill, fill, fill);
-            if (lane == 0) qf[64 * NS] = make_uint4(fill, fill, fill, fill);
-        }
-        int nsteps = 0;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            int base = 0;
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                uint64_t m = __builtin_amdgcn_ballot_w64((msk[j] & (1u << g)) != 0u);
+            for (int g = 0; g < 16; g++) {
+                uint64_t m = __builtin_amdgcn_ballot_w64((mskb & (1u << g)) != 0u);
                 // slot t has list index hi - t: needed by the block only if hi - t <= its last contributor
-                const int d = hi - sgl[g] - 64 * j;
+                const int d = hi - sgl[g];
                 if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
                 if (__builtin_amdgcn_inverse_ballot_w64(m)) {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    lds.queue[g * CH + base + rank] = (uint8_t)(lane + 64 * j);
+                    lds.queue[g * CH + rank] = (uint8_t)lane;
                 }
-                base += __builtin_popcountll(m);
+                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(startv) : "s"(npairs), "s"(g) : "m0");
+                const int cnt = __builtin_popcountll(m);
+                npairs += cnt;
+                nsteps = max(nsteps, cnt);
             }
-            GS_STAT(11, base);
-            nsteps = max(nsteps, base);
+            if (npairs <= PMAX) break;
+            // (sixteen pairs per entry at most, PMAX >= 128: eight entries always fit)
+            asm volatile("; pair buffer overflow");
+            n_ent = max(8, min(n_ent - 4, (n_ent * PMAX) / npairs));
+            n_nom = n_ent;
         }
+        if (n_nom < CH && 4 * npairs < 3 * PMAX) n_nom = min(CH, n_nom + 4);
+        adv = n_ent;
+        const uint32_t msk = lane < n_ent ? nmask : 0u;
+        // first pair slot of the lane's own group
+        const int mystart = __builtin_amdgcn_ds_bpermute(4 * grp, startv);
+        // ---- stage the records ----
+        bool binds_t = false;
+        if (msk) {
+            const float4 n0 = packed[3 * (size_t)ng + 0], n1 = packed[3 * (size_t)ng + 1],
+                         n2 = packed[3 * (size_t)ng + 2];
+            const uint32_t sb = __float_as_uint(n1.z);
+            // L' -+ band; an opacity that cannot reach 1/255 at all gets the empty interval [0, 0]
+            float s_hi = 0.0f, s_lo = -1.0f;
+            if (n1.y > 0.0f) {
+                const float Lp = __builtin_amdgcn_logf(255.0f * n1.y);   // v_log_f32: log2
+                if (Lp + kSigBand >= 0.0f) { s_hi = Lp + kSigBand; s_lo = Lp - kSigBand; }
+            }
+            const float sm = __uint_as_float((__float_as_uint(s_hi) & ~1u) | (sb & 1u));
+            lds.stage[lane].p0 = make_float4(n0.x, n0.y, n0.z * kLog2e, n0.w * kLog2e);
+            lds.stage[lane].p1 = make_float4(n1.x * kLog2e, n1.y, sm, s_lo);
+            lds.stage[lane].p2 = make_float4(n2.x, n2.y, n2.z, n1.x);
+            lds.rare[lane] = make_float4(n1.w, n2.w, n0.z, n0.w);
+            binds_t = (sb & 1u) != 0u;
+        }
+        if (hi - lane >= range.x) lds.sid[lane] = ng;
+        const bool chunk_binds = __builtin_amdgcn_ballot_w64(binds_t) != 0ull;
+        GS_STAT(11, npairs);
         GS_STAT(12, 1);
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NS; j++) {
-            nmask[j] = 0u;
-            const int idx = hi - CH - lane - 64 * j;
-            if (idx >= range.x) { ng[j] = ids[idx]; nmask[j] = masks[idx]; }
-        }
-        if (nsteps == 0) continue;
-        bool flushed_any = false;  // wave-uniform
+        // the next chunk's ids and masks (its first slot is list index hi - n_ent)
+        nmask = 0u;
+        if (hi - n_ent - lane >= range.x) { ng = ids[hi - n_ent - lane]; nmask = masks[hi - n_ent - lane]; }
+        if (nsteps != 0) {
+        float *mypair = &lds.pairs[mystart * kPairRec + 2 * c0];
         auto walk = [&](auto binds_tag) {
             constexpr bool BINDS = decltype(binds_tag)::value;
             int e_next = myq[0];
@@ -1242,7 +1246,6 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const i
                 const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
-                uint64_t anym = 0ull;
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
@@ -1266,7 +1269,6 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const i
                     const uint64_t mneed = __builtin_amdgcn_ballot_w64(e >= last[p]) &
                                            __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
                     if (mneed == 0ull) continue;
-                    anym |= mneed;
                     GS_STAT(9, 1);
                     GS_STAT(10, __builtin_popcountll(mneed));
                     float vis = __builtin_amdgcn_exp2f(-sg);   // sg = sigma log2(e)
@@ -1308,66 +1310,81 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<CH> &lds, int W, int H, const i
                     suy += uy;
                     suyy = fmaf(uy, dy, suyy);
                 }
-                if (anym == 0ull) continue;
                 const float ux = su * dx;
                 float s0, s1, s2;
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
-                if (e < CH) {   // (an exhausted group has nothing to add; its dx is NaN)
-                    __hip_atomic_fetch_add(&acc0[e], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&acc0[4 * AS + e], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (bank == 0)
-                        __hip_atomic_fetch_add(&lds.acc[8 * AS + e], s2, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (e < CH) {   // (an exhausted group has no pair; its dx is NaN)
+                    *reinterpret_cast<float2 *>(mypair + k * kPairRec) = make_float2(s0, s1);
+                    mypair[k * kPairRec + 8 - 2 * c0] = s2;   // (the group's four lanes store the same total)
                 }
-                flushed_any = true;
             }
         };
         if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
-        if (!flushed_any) continue;
-        // ---- flush: as backward_wave ----
+        }
+        // ---- gather: lane t adds up the records of entry t's pairs, block by block ----
         wave_sync();
+        float S0 = 0.0f, S1 = 0.0f, S2 = 0.0f, S3 = 0.0f, S4 = 0.0f, S5 = 0.0f, S6 = 0.0f, S7 = 0.0f, S8 = 0.0f;
+        {
+            int first = 0;   // (the queues' masks again: sixteen SGPR pairs kept across the walk spill)
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
-            const int t = lane + 64 * j;
-            if (msk[j] != 0u) {   // (only slots staged THIS chunk, see backward_wave)
-                const float Ux = lds.acc[0 * AS + t], Uy = lds.acc[1 * AS + t];
-                const float Uxx = lds.acc[2 * AS + t], Uxy = lds.acc[3 * AS + t];
-                const float Uyy = lds.acc[4 * AS + t];
-                const float mo = -lds.stage[t].p1.y;          // v_sigma = -opacity * u
-                const float A = lds.rare[t].z, B = lds.rare[t].w, C = lds.stage[t].p2.w;
-                lds.acc[0 * AS + t] = mo * fmaf(A, Ux, B * Uy);
-                lds.acc[1 * AS + t] = mo * fmaf(B, Ux, C * Uy);
-                lds.acc[2 * AS + t] = 0.5f * mo * Uxx;
-                lds.acc[3 * AS + t] = 0.5f * mo * Uxy;
-                lds.acc[4 * AS + t] = 0.5f * mo * Uyy;
+            for (int g = 0; g < 16; g++) {
+                uint64_t m = __builtin_amdgcn_ballot_w64((msk & (1u << g)) != 0u);
+                const int d = hi - sgl[g];
+                if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const float *r = &lds.pairs[(first + rank) * kPairRec];
+                    const float2 a = *reinterpret_cast<const float2 *>(r), b = *reinterpret_cast<const float2 *>(r + 2);
+                    const float2 c = *reinterpret_cast<const float2 *>(r + 4), d2 = *reinterpret_cast<const float2 *>(r + 6);
+                    S0 += a.x; S4 += a.y; S1 += b.x; S5 += b.y; S2 += c.x; S6 += c.y; S3 += d2.x; S7 += d2.y;
+                    S8 += r[8];
+                }
+                first += __builtin_popcountll(m);
             }
         }
         wave_sync();
+        // ---- moments -> gradient components (once per entry), into acc[component][slot] (over the pair records) ----
+        {
+            float *acc = lds.pairs;
+            float A = 0.0f, B = 0.0f, C = 0.0f, mo = 0.0f;
+            if (msk != 0u) {   // (only slots staged THIS chunk hold a record, see backward_wave)
+                mo = -lds.stage[lane].p1.y;          // v_sigma = -opacity * u
+                A = lds.rare[lane].z; B = lds.rare[lane].w; C = lds.stage[lane].p2.w;
+            }
+            acc[0 * AS + lane] = mo * fmaf(A, S0, B * S1);   // v_x: v_sigma * (A dx + B dy)
+            acc[1 * AS + lane] = mo * fmaf(B, S0, C * S1);   // v_y
+            acc[2 * AS + lane] = 0.5f * mo * S2;             // v_A  (gsplat_cpu.cpp:361-363)
+            acc[3 * AS + lane] = 0.5f * mo * S3;             // v_B
+            acc[4 * AS + lane] = 0.5f * mo * S4;             // v_C
+            acc[5 * AS + lane] = S5;
+            acc[6 * AS + lane] = S6;
+            acc[7 * AS + lane] = S7;
+            acc[8 * AS + lane] = S8;
+            wave_sync();
 #pragma unroll
-        for (int i = 0; i < (CH + 6) / 7; i++) {
-            const int ent = 7 * i + fj;
-            if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
-                const float v = lds.acc[fcomp * AS + ent];
-                if (v != 0.0f) {
-                    const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
-                    if (DET)
-                        atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
-                                                fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
-                    else
-                        atomicAdd(gacc + o, v);
+            for (int i = 0; i < (CH + 6) / 7; i++) {
+                const int ent = 7 * i + fj;
+                if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
+                    const float v = acc[fcomp * AS + ent];
+                    if (v != 0.0f) {
+                        const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
+                        if (DET)
+                            atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
+                                                    fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
+                        else
+                            atomicAdd(gacc + o, v);
+                    }
                 }
             }
         }
-        wave_sync();
 #pragma unroll
-        for (int i = 0; i < kAcc; i++)
-#pragma unroll
-            for (int j = 0; j < NS; j++) lds.acc[i * AS + lane + 64 * j] = 0.0f;
+        for (int p = 0; p < PX; p++) last[p] -= adv;   // relative to the next chunk's first slot
     }
 }
 
-template <bool EXACT, bool DET, int CH>
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+template <bool EXACT, bool DET, int PMAX>
+__global__ void __launch_bounds__(64, 3)
 k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                        const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
                        const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
@@ -1375,11 +1392,11 @@ k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *
                        const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                        const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                        float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
-    __shared__ QLds<CH> lds;
+    __shared__ QLds<PMAX> lds;
     int tile, wx0, wy0;
     if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
-    backward_wave_q<EXACT, DET, CH>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
-                                    final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+    backward_wave_q<EXACT, DET, PMAX>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
+                                      final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
 }
 
 // One geometry for every tile (flag bits 21..22: measurements, the wave-geometry tests).
@@ -1851,7 +1868,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q), 64- / 128-entry chunks
+    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q), pair buffer of 192 / 256 / 128 records (128: every chunk of an ordinary scene overflows — tests)
     const int qgeom = (int)((flags >> 25) & 3u);
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
@@ -1878,8 +1895,9 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
               bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 64);                                                   \
-        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 128);                                             \
+        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 192);                                                  \
+        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 256);                                             \
+        else if (!ck && qgeom == 3) GS_Q_LAUNCH3(EX, DT, 128);                                             \
         else if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                             \
         else if (ck && seg_px == 2) GS_SEG_LAUNCH3(EX, DT, 2);                                             \
         else if (ck) GS_SEG_LAUNCH3(EX, DT, 4);                                                            \
