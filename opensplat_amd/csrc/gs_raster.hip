@@ -1059,33 +1059,40 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 //   * NO LDS ATOMICS.  The first version added the group's sums to per-entry accumulators with ds_add_f32 like
 //     backward_wave does: 144 atomic lanes per step, and an LDS float atomic costs ~2.2 LDS cycles PER LANE
 //     (SQ_LDS_IDX_ACTIVE 1.2e8 -> 2.3e8, SQ_WAIT_INST_LDS 2.2e7 -> 4.5e8: 442 us against 294, LDS-bound,
-//     profiles/r05/q64_ldsatomic_*).  A (block, entry) pair is visited exactly once, so its nine sums are now
-//     PLAIN stores into the pair's own 40-byte record (pair slots are handed out group by group while the queues
-//     are built: slot = first slot of the group + rank), and after the walk lane t adds up the records of entry
-//     t's pairs (sixteen exec-masked rounds, one per block bit, in a fixed order: the per-wave sum is
-//     deterministic), converts moments to gradient components and hands them to the record-major global flush.
-//     The pair buffer bounds a chunk (PMAX pairs): a chunk whose entries make more pairs is cut short and the
-//     following chunks stage fewer entries (big Gaussians: BASELINE config 3).
+//     profiles/r05/q64_ldsatomic_*).  The second stored every (block, entry) pair's sums in a record of its own
+//     and let lane t add up entry t's records after the walk: no LDS wait any more, but 600 VALU per chunk of
+//     queue / gather bookkeeping and 13 KB of LDS (three waves per SIMD): 298 us (profiles/r05/q192_pairstore_*).
+//     Now: PLAIN read-add-write on the entry's accumulator record, made safe by a CLAIM — two groups collide
+//     only if they take the same entry in the same step; every group writes its number to tag[entry] (one byte
+//     store), reads it back, and the group whose number stuck does its read-add-write; the others go round
+//     again (LDS operations of a wave execute in order, the lanes in lockstep: exactly one winner per entry
+//     and round).  One round almost always.
 // Everything per pixel — thresholds, the exact re-evaluation inside the band, the recurrences — is
-// backward_wave's, statement for statement; the gradient records are unchanged.
+// backward_wave's, statement for statement; flush and gradient records are unchanged.
 struct __attribute__((aligned(16))) SRecQ {
     float4 p0, p1, p2;   // {x y A' B' | C' o s_hi s_lo | r g b C}   (A' = A log2 e ...; C unscaled for the rare paths)
 };
 constexpr int kQChunk = 64;
-constexpr int kPairRec = 10;   // floats per pair record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
-template <int PMAX>
+constexpr int kAccRec = 10;   // floats per accumulator record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
+// dword of component c in an accumulator record
+__device__ __forceinline__ int acc_dword(int c) { return c < 8 ? 2 * (c & 3) + (c >> 2) : 8; }
+// MODE (measurement variants, flag bits 25..26): 1 claim loop; 2 one claim round, the losers add with LDS
+// atomics; 3 two copies of the accumulators (checkerboard of blocks: horizontal / vertical neighbours never
+// meet) + claim loop
+template <int MODE>
 struct QLds {
-    static_assert(PMAX >= 128 && PMAX * kPairRec >= kAcc * (kQChunk + 1), "pair buffer also holds the flush's accumulators");
+    static constexpr int COPIES = MODE == 3 ? 2 : 1;
     SRecQ stage[kQChunk + 1];
     float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
     alignas(16) uint8_t queue[16 * kQChunk + 16];      // [block][rank] -> slot; (+16: the read one step ahead)
-    alignas(16) float pairs[PMAX * kPairRec];          // pair records; after the gather: acc[component][slot]
+    alignas(16) float acc[COPIES * (kQChunk + 1) * kAccRec];   // per-entry sums (entry-major)
     int sid[kQChunk];
+    unsigned int tag[COPIES * (kQChunk + 1)];          // the claim: which block adds to an entry this round
 };
 
-template <bool EXACT, bool DET, int PMAX>
+template <bool EXACT, bool DET, int MODE>
 __device__ __forceinline__ void
-backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const int32_t *__restrict__ ids,
+backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const int32_t *__restrict__ ids,
                 const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
                 const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
                 const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
@@ -1094,7 +1101,6 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
                 float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
     static_assert((GS_BWD_LOG2E & GS_BWD_SIGMA_THRESH) != 0, "the Q walk is written for the sigma' thresholds");
     constexpr int CH = kQChunk;
-    constexpr int AS = CH + 1;           // accumulator stride of the flush
     constexpr int PX = 4;
     const int lane = threadIdx.x;
     if (bg_dev) {
@@ -1107,6 +1113,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
     const int c0 = ((bank & 1) << 1) | (bank >> 1);     // the component orbit_reduce9 leaves in s0 (s1: 4 + c0)
     const int fj = (lane * 7282) >> 16;                 // flush: lane = 9 * fj + fcomp (lane 63: no work)
     const int fcomp = lane == 63 ? kAcc : lane - 9 * fj;
+    const int fdw = acc_dword(fcomp < kAcc ? fcomp : 0);
     const int px = tx0 + 4 * bcol + bank;
     const int py0 = ty0 + 4 * brow;                     // pixel p of the lane: row py0 + p
     const float pxf = (float)px;
@@ -1154,56 +1161,26 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
         stage_sentinel(&lds.stage[CH]);
         lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    constexpr int COPIES = QLds<MODE>::COPIES;
+    constexpr int kCopy = (kQChunk + 1) * kAccRec;       // floats per accumulator copy
+    const int mycopy = COPIES == 2 ? ((brow + bcol) & 1) : 0;
+    float2 *myrec = reinterpret_cast<float2 *>(&lds.acc[lane * kAccRec]);   // (8-byte aligned: 40-byte records)
+#pragma unroll
+    for (int c = 0; c < COPIES; c++)
+#pragma unroll
+        for (int i = 0; i < kAccRec / 2; i++) myrec[c * (kCopy / 2) + i] = make_float2(0.0f, 0.0f);
+
     int ng = 0;
     uint32_t nmask = 0u;
     if (wave_last - lane >= range.x) { ng = ids[wave_last - lane]; nmask = masks[wave_last - lane]; }
 #pragma unroll
-    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p];   // relative to the chunk's first slot (-1: beyond)
+    for (int p = 0; p < PX; p++) last[p] = wave_last - last[p] + CH;   // (no contributor: beyond any slot)
     const uint8_t *myq = &lds.queue[grp * CH];
-    int n_nom = CH;   // entries staged per chunk: fewer once a chunk overflowed the pair buffer
-    int adv = 0;
-    for (int hi = wave_last; hi >= range.x; hi -= adv) {
-        __syncthreads();
-        // ---- the sixteen queues, pair slots group by group; cut the chunk if its pairs exceed the buffer ----
-        int nsteps, npairs, n_ent = n_nom;
-        int startv = 0;   // lane g (< 16): first pair slot of block g
-        for (;;) {
-            const uint32_t mskb = lane < n_ent ? nmask : 0u;
-            {
-                const uint32_t fill = CH * 0x01010101u;   // the sentinel slot in every byte
-                uint4 *qf = reinterpret_cast<uint4 *>(lds.queue);
-                qf[lane] = make_uint4(fill, fill, fill, fill);
-                if (lane == 0) qf[64] = make_uint4(fill, fill, fill, fill);
-            }
-            nsteps = 0; npairs = 0;
+    for (int hi = wave_last; hi >= range.x; hi -= CH) {
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                uint64_t m = __builtin_amdgcn_ballot_w64((mskb & (1u << g)) != 0u);
-                // slot t has list index hi - t: needed by the block only if hi - t <= its last contributor
-                const int d = hi - sgl[g];
-                if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
-                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    lds.queue[g * CH + rank] = (uint8_t)lane;
-                }
-                asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(startv) : "s"(npairs), "s"(g) : "m0");
-                const int cnt = __builtin_popcountll(m);
-                npairs += cnt;
-                nsteps = max(nsteps, cnt);
-            }
-            if (npairs <= PMAX) break;
-            // (sixteen pairs per entry at most, PMAX >= 128: eight entries always fit)
-            asm volatile("; pair buffer overflow");
-            n_ent = max(8, min(n_ent - 4, (n_ent * PMAX) / npairs));
-            n_nom = n_ent;
-        }
-        if (n_nom < CH && 4 * npairs < 3 * PMAX) n_nom = min(CH, n_nom + 4);
-        adv = n_ent;
-        const uint32_t msk = lane < n_ent ? nmask : 0u;
-        // first pair slot of the lane's own group
-        const int mystart = __builtin_amdgcn_ds_bpermute(4 * grp, startv);
-        // ---- stage the records ----
+        for (int p = 0; p < PX; p++) last[p] -= CH;   // now relative to this chunk's first slot
+        __syncthreads();
+        const uint32_t msk = nmask;
         bool binds_t = false;
         if (msk) {
             const float4 n0 = packed[3 * (size_t)ng + 0], n1 = packed[3 * (size_t)ng + 1],
@@ -1224,14 +1201,34 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
         }
         if (hi - lane >= range.x) lds.sid[lane] = ng;
         const bool chunk_binds = __builtin_amdgcn_ballot_w64(binds_t) != 0ull;
-        GS_STAT(11, npairs);
+        // ---- the sixteen queues ----
+        {
+            const uint32_t fill = CH * 0x01010101u;   // the sentinel slot in every byte
+            uint4 *qf = reinterpret_cast<uint4 *>(lds.queue);
+            qf[lane] = make_uint4(fill, fill, fill, fill);
+            if (lane == 0) qf[64] = make_uint4(fill, fill, fill, fill);
+        }
+        int nsteps = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            uint64_t m = __builtin_amdgcn_ballot_w64((msk & (1u << g)) != 0u);
+            // slot t has list index hi - t: needed by the block only if hi - t <= its last contributor
+            const int d = hi - sgl[g];
+            if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                lds.queue[g * CH + rank] = (uint8_t)lane;
+            }
+            const int cnt = __builtin_popcountll(m);
+            GS_STAT(11, cnt);
+            nsteps = max(nsteps, cnt);
+        }
         GS_STAT(12, 1);
         __syncthreads();
-        // the next chunk's ids and masks (its first slot is list index hi - n_ent)
         nmask = 0u;
-        if (hi - n_ent - lane >= range.x) { ng = ids[hi - n_ent - lane]; nmask = masks[hi - n_ent - lane]; }
-        if (nsteps != 0) {
-        float *mypair = &lds.pairs[mystart * kPairRec + 2 * c0];
+        if (hi - CH - lane >= range.x) { ng = ids[hi - CH - lane]; nmask = masks[hi - CH - lane]; }
+        if (nsteps == 0) continue;
         auto walk = [&](auto binds_tag) {
             constexpr bool BINDS = decltype(binds_tag)::value;
             int e_next = myq[0];
@@ -1239,6 +1236,10 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
                 const int e = e_next;
                 const float4 q0 = lds.stage[e].p0, q1 = lds.stage[e].p1, q2 = lds.stage[e].p2;
                 e_next = myq[k + 1];
+                // the claim's first round: issued here, looked at after the passes
+                const bool active = e < CH;   // (an exhausted group has nothing to add; its dx is NaN)
+                unsigned int *mytag = &lds.tag[mycopy * (kQChunk + 1) + e];
+                if (active) __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
@@ -1246,6 +1247,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
                 const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
+                const int won = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
@@ -1313,78 +1315,91 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<PMAX> &lds, int W, int H, const
                 const float ux = su * dx;
                 float s0, s1, s2;
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
-                if (e < CH) {   // (an exhausted group has no pair; its dx is NaN)
-                    *reinterpret_cast<float2 *>(mypair + k * kPairRec) = make_float2(s0, s1);
-                    mypair[k * kPairRec + 8 - 2 * c0] = s2;   // (the group's four lanes store the same total)
+                // ---- add to the entry's record: plain read-add-write by the group that holds the claim ----
+                float *rec = &lds.acc[mycopy * kCopy + e * kAccRec];
+                // (lane masks as scalars: the loop's exit test is one s_cmp)
+                const uint64_t actm = __builtin_amdgcn_ballot_w64(active);
+                uint64_t winm = actm & __builtin_amdgcn_ballot_w64(won == grp);
+                uint64_t pendm = actm & ~winm;
+                for (;;) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(winm)) {
+                        float2 *r2 = reinterpret_cast<float2 *>(rec + 2 * c0);
+                        float2 a = *r2;
+                        float c8 = rec[8];
+                        a.x += s0; a.y += s1; c8 += s2;   // (the group's four lanes hold the same s2: same store)
+                        *r2 = a;
+                        rec[8] = c8;
+                    }
+                    if (pendm == 0ull) break;
+                    if (MODE == 2) {
+                        // the groups that lost the claim add with atomics, behind the winners' stores (the
+                        // LDS operations of a wave execute in order)
+                        asm volatile("; claim lost: atomics");
+                        if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
+                            __hip_atomic_fetch_add(rec + 2 * c0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(rec + 2 * c0 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (bank == 0)
+                                __hip_atomic_fetch_add(rec + 8, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        break;
+                    }
+                    asm volatile("; claim lost: another round");
+                    bool w = false;
+                    if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
+                        __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        w = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == grp;
+                    }
+                    winm = __builtin_amdgcn_ballot_w64(w);
+                    pendm &= ~winm;
                 }
             }
         };
         if (chunk_binds) walk(std::true_type{}); else walk(std::false_type{});
-        }
-        // ---- gather: lane t adds up the records of entry t's pairs, block by block ----
+        // ---- flush: moments -> gradient components (once per entry), then one atomic lane per
+        //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
         wave_sync();
-        float S0 = 0.0f, S1 = 0.0f, S2 = 0.0f, S3 = 0.0f, S4 = 0.0f, S5 = 0.0f, S6 = 0.0f, S7 = 0.0f, S8 = 0.0f;
-        {
-            int first = 0;   // (the queues' masks again: sixteen SGPR pairs kept across the walk spill)
-#pragma unroll
-            for (int g = 0; g < 16; g++) {
-                uint64_t m = __builtin_amdgcn_ballot_w64((msk & (1u << g)) != 0u);
-                const int d = hi - sgl[g];
-                if (d > 0) m = d >= 64 ? 0ull : (m & ~((1ull << d) - 1ull));
-                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const float *r = &lds.pairs[(first + rank) * kPairRec];
-                    const float2 a = *reinterpret_cast<const float2 *>(r), b = *reinterpret_cast<const float2 *>(r + 2);
-                    const float2 c = *reinterpret_cast<const float2 *>(r + 4), d2 = *reinterpret_cast<const float2 *>(r + 6);
-                    S0 += a.x; S4 += a.y; S1 += b.x; S5 += b.y; S2 += c.x; S6 += c.y; S3 += d2.x; S7 += d2.y;
-                    S8 += r[8];
-                }
-                first += __builtin_popcountll(m);
+        if (msk != 0u) {   // (only slots staged THIS chunk, see backward_wave)
+            float *r = &lds.acc[lane * kAccRec];
+            float Ux = r[0], Uy = r[2], Uxx = r[4], Uxy = r[6], Uyy = r[1];
+            if (COPIES == 2) {
+                Ux += r[kCopy + 0]; Uy += r[kCopy + 2]; Uxx += r[kCopy + 4]; Uxy += r[kCopy + 6]; Uyy += r[kCopy + 1];
             }
+            const float mo = -lds.stage[lane].p1.y;          // v_sigma = -opacity * u
+            const float A = lds.rare[lane].z, B = lds.rare[lane].w, C = lds.stage[lane].p2.w;
+            r[0] = mo * fmaf(A, Ux, B * Uy);   // v_x: v_sigma * (A dx + B dy)
+            r[2] = mo * fmaf(B, Ux, C * Uy);   // v_y
+            r[4] = 0.5f * mo * Uxx;            // v_A  (gsplat_cpu.cpp:361-363)
+            r[6] = 0.5f * mo * Uxy;            // v_B
+            r[1] = 0.5f * mo * Uyy;            // v_C
         }
         wave_sync();
-        // ---- moments -> gradient components (once per entry), into acc[component][slot] (over the pair records) ----
-        {
-            float *acc = lds.pairs;
-            float A = 0.0f, B = 0.0f, C = 0.0f, mo = 0.0f;
-            if (msk != 0u) {   // (only slots staged THIS chunk hold a record, see backward_wave)
-                mo = -lds.stage[lane].p1.y;          // v_sigma = -opacity * u
-                A = lds.rare[lane].z; B = lds.rare[lane].w; C = lds.stage[lane].p2.w;
-            }
-            acc[0 * AS + lane] = mo * fmaf(A, S0, B * S1);   // v_x: v_sigma * (A dx + B dy)
-            acc[1 * AS + lane] = mo * fmaf(B, S0, C * S1);   // v_y
-            acc[2 * AS + lane] = 0.5f * mo * S2;             // v_A  (gsplat_cpu.cpp:361-363)
-            acc[3 * AS + lane] = 0.5f * mo * S3;             // v_B
-            acc[4 * AS + lane] = 0.5f * mo * S4;             // v_C
-            acc[5 * AS + lane] = S5;
-            acc[6 * AS + lane] = S6;
-            acc[7 * AS + lane] = S7;
-            acc[8 * AS + lane] = S8;
-            wave_sync();
 #pragma unroll
-            for (int i = 0; i < (CH + 6) / 7; i++) {
-                const int ent = 7 * i + fj;
-                if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
-                    const float v = acc[fcomp * AS + ent];
-                    if (v != 0.0f) {
-                        const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
-                        if (DET)
-                            atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
-                                                    fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
-                        else
-                            atomicAdd(gacc + o, v);
-                    }
+        for (int i = 0; i < (CH + 6) / 7; i++) {
+            const int ent = 7 * i + fj;
+            if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
+                float v = lds.acc[ent * kAccRec + fdw];
+                // (the moments' second copy went into the first above; colours and sum(u) are added here)
+                if (COPIES == 2 && fcomp >= 5) v += lds.acc[kCopy + ent * kAccRec + fdw];
+                if (v != 0.0f) {
+                    const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
+                    if (DET)
+                        atomicAdd(gfix + o, (unsigned long long)__float2ll_rn(
+                                                fminf(fmaxf(v * kFixScale, -4.6e18f), 4.6e18f)));
+                    else
+                        atomicAdd(gacc + o, v);
                 }
             }
         }
+        wave_sync();
 #pragma unroll
-        for (int p = 0; p < PX; p++) last[p] -= adv;   // relative to the next chunk's first slot
+        for (int c = 0; c < COPIES; c++)
+#pragma unroll
+            for (int i = 0; i < kAccRec / 2; i++) myrec[c * (kCopy / 2) + i] = make_float2(0.0f, 0.0f);
     }
 }
 
-template <bool EXACT, bool DET, int PMAX>
-__global__ void __launch_bounds__(64, 3)
+template <bool EXACT, bool DET, int MODE>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
 k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                        const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
                        const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
@@ -1392,11 +1407,11 @@ k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *
                        const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                        const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
                        float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
-    __shared__ QLds<PMAX> lds;
+    __shared__ QLds<MODE> lds;
     int tile, wx0, wy0;
     if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
-    backward_wave_q<EXACT, DET, PMAX>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
-                                      final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+    backward_wave_q<EXACT, DET, MODE>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
+                                final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
 }
 
 // One geometry for every tile (flag bits 21..22: measurements, the wave-geometry tests).
@@ -1868,7 +1883,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q), pair buffer of 192 / 256 / 128 records (128: every chunk of an ordinary scene overflows — tests)
+    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q)
     const int qgeom = (int)((flags >> 25) & 3u);
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
@@ -1889,15 +1904,15 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x,     \
               tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted, block_masks, bins, \
               pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
-#define GS_Q_LAUNCH3(EX, DT, CHN)                                                                         \
-    GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT, CHN>), dim3(8 * ((tiles + 7) / 8)), dim3(64), 0, s, W, H, \
+#define GS_Q_LAUNCH3(EX, DT, MD)                                                                          \
+    GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT, MD>), dim3(8 * ((tiles + 7) / 8)), dim3(64), 0, s, W, H, \
               tiles_x, tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
               bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 192);                                                  \
-        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 256);                                             \
-        else if (!ck && qgeom == 3) GS_Q_LAUNCH3(EX, DT, 128);                                             \
+        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 1);                                                    \
+        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 2);                                               \
+        else if (!ck && qgeom == 3) GS_Q_LAUNCH3(EX, DT, 3);                                               \
         else if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                             \
         else if (ck && seg_px == 2) GS_SEG_LAUNCH3(EX, DT, 2);                                             \
         else if (ck) GS_SEG_LAUNCH3(EX, DT, 4);                                                            \

@@ -231,3 +231,44 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def claim_rounds(config="c2", tiles="12x8"):
+    """Rounds of the claim (read-add-write by the group that holds the entry) per step, for one accumulator
+    copy, two (checkerboard of blocks) and four (2 x 2 parity of the block coordinates)."""
+    s = scenes.config_c2() if config == "c2" else scenes.config_c3()
+    ntx, nty = (int(v) for v in tiles.split("x"))
+    TX, TY = (s.W + 15) // 16, (s.H + 15) // 16
+    tx0, ty0 = (TX - ntx) // 2, (TY - nty) // 2
+    g = build_window(s, tx0, ty0, ntx, nty)
+    tot = {1: 0, 2: 0, 4: 0}
+    steps = 0
+    for ty in range(ty0, ty0 + nty):
+        for tx in range(tx0, tx0 + ntx):
+            r = tile_work(g, tx, ty)
+            if r is None:
+                continue
+            need0, last = r
+            L = need0.shape[0]
+            b16 = block16(need0)
+            wave_last = int(last.max())
+            if wave_last < 0:
+                continue
+            gl4 = last.reshape(4, 4, 4, 4).max(axis=(1, 3)).reshape(16)
+            for hi in range(wave_last, -1, -64):
+                lo = max(hi - 63, 0)
+                ent = np.arange(hi, lo - 1, -1)
+                qs = [ent[b16[ent, gi] & (ent <= gl4[gi])] for gi in range(16)]
+                n = max(len(q) for q in qs)
+                for k in range(n):
+                    steps += 1
+                    for banks in (1, 2, 4):
+                        cl = {}
+                        for gi in range(16):
+                            if k < len(qs[gi]):
+                                br, bc = gi >> 2, gi & 3
+                                bank = 0 if banks == 1 else ((br + bc) & 1) if banks == 2 else ((br & 1) * 2 + (bc & 1))
+                                key = (bank, int(qs[gi][k]))
+                                cl[key] = cl.get(key, 0) + 1
+                        tot[banks] += max(cl.values()) if cl else 0
+    return {b: tot[b] / max(steps, 1) for b in tot}
