@@ -1076,23 +1076,18 @@ constexpr int kQChunk = 64;
 constexpr int kAccRec = 10;   // floats per accumulator record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
 // dword of component c in an accumulator record
 __device__ __forceinline__ int acc_dword(int c) { return c < 8 ? 2 * (c & 3) + (c >> 2) : 8; }
-// MODE (measurement variants, flag bits 25..26): 1 claim loop; 2 one claim round, the losers add with LDS
-// atomics; 3 two copies of the accumulators (checkerboard of blocks: horizontal / vertical neighbours never
-// meet) + claim loop
-template <int MODE>
 struct QLds {
-    static constexpr int COPIES = MODE == 3 ? 2 : 1;
     SRecQ stage[kQChunk + 1];
     float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
     alignas(16) uint8_t queue[16 * kQChunk + 16];      // [block][rank] -> slot; (+16: the read one step ahead)
-    alignas(16) float acc[COPIES * (kQChunk + 1) * kAccRec];   // per-entry sums (entry-major)
+    alignas(16) float acc[(kQChunk + 1) * kAccRec];    // per-entry sums (entry-major)
     int sid[kQChunk];
-    unsigned int tag[COPIES * (kQChunk + 1)];          // the claim: which block adds to an entry this round
+    unsigned int tag[kQChunk + 1];                     // the claim: which block adds to an entry this round
 };
 
-template <bool EXACT, bool DET, int MODE>
+template <bool EXACT, bool DET>
 __device__ __forceinline__ void
-backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const int32_t *__restrict__ ids,
+backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32_t *__restrict__ ids,
                 const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
                 const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
                 const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
@@ -1161,14 +1156,9 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
         stage_sentinel(&lds.stage[CH]);
         lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    constexpr int COPIES = QLds<MODE>::COPIES;
-    constexpr int kCopy = (kQChunk + 1) * kAccRec;       // floats per accumulator copy
-    const int mycopy = COPIES == 2 ? ((brow + bcol) & 1) : 0;
     float2 *myrec = reinterpret_cast<float2 *>(&lds.acc[lane * kAccRec]);   // (8-byte aligned: 40-byte records)
 #pragma unroll
-    for (int c = 0; c < COPIES; c++)
-#pragma unroll
-        for (int i = 0; i < kAccRec / 2; i++) myrec[c * (kCopy / 2) + i] = make_float2(0.0f, 0.0f);
+    for (int i = 0; i < kAccRec / 2; i++) myrec[i] = make_float2(0.0f, 0.0f);
 
     int ng = 0;
     uint32_t nmask = 0u;
@@ -1238,7 +1228,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
                 e_next = myq[k + 1];
                 // the claim's first round: issued here, looked at after the passes
                 const bool active = e < CH;   // (an exhausted group has nothing to add; its dx is NaN)
-                unsigned int *mytag = &lds.tag[mycopy * (kQChunk + 1) + e];
+                unsigned int *mytag = &lds.tag[e];
                 if (active) __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
@@ -1316,7 +1306,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
                 float s0, s1, s2;
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
                 // ---- add to the entry's record: plain read-add-write by the group that holds the claim ----
-                float *rec = &lds.acc[mycopy * kCopy + e * kAccRec];
+                float *rec = &lds.acc[e * kAccRec];
                 // (lane masks as scalars: the loop's exit test is one s_cmp)
                 const uint64_t actm = __builtin_amdgcn_ballot_w64(active);
                 uint64_t winm = actm & __builtin_amdgcn_ballot_w64(won == grp);
@@ -1331,18 +1321,6 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
                         rec[8] = c8;
                     }
                     if (pendm == 0ull) break;
-                    if (MODE == 2) {
-                        // the groups that lost the claim add with atomics, behind the winners' stores (the
-                        // LDS operations of a wave execute in order)
-                        asm volatile("; claim lost: atomics");
-                        if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
-                            __hip_atomic_fetch_add(rec + 2 * c0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(rec + 2 * c0 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (bank == 0)
-                                __hip_atomic_fetch_add(rec + 8, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        break;
-                    }
                     asm volatile("; claim lost: another round");
                     bool w = false;
                     if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
@@ -1360,10 +1338,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
         wave_sync();
         if (msk != 0u) {   // (only slots staged THIS chunk, see backward_wave)
             float *r = &lds.acc[lane * kAccRec];
-            float Ux = r[0], Uy = r[2], Uxx = r[4], Uxy = r[6], Uyy = r[1];
-            if (COPIES == 2) {
-                Ux += r[kCopy + 0]; Uy += r[kCopy + 2]; Uxx += r[kCopy + 4]; Uxy += r[kCopy + 6]; Uyy += r[kCopy + 1];
-            }
+            const float Ux = r[0], Uy = r[2], Uxx = r[4], Uxy = r[6], Uyy = r[1];
             const float mo = -lds.stage[lane].p1.y;          // v_sigma = -opacity * u
             const float A = lds.rare[lane].z, B = lds.rare[lane].w, C = lds.stage[lane].p2.w;
             r[0] = mo * fmaf(A, Ux, B * Uy);   // v_x: v_sigma * (A dx + B dy)
@@ -1377,9 +1352,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
         for (int i = 0; i < (CH + 6) / 7; i++) {
             const int ent = 7 * i + fj;
             if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
-                float v = lds.acc[ent * kAccRec + fdw];
-                // (the moments' second copy went into the first above; colours and sum(u) are added here)
-                if (COPIES == 2 && fcomp >= 5) v += lds.acc[kCopy + ent * kAccRec + fdw];
+                const float v = lds.acc[ent * kAccRec + fdw];
                 if (v != 0.0f) {
                     const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
                     if (DET)
@@ -1392,26 +1365,8 @@ backward_wave_q(int tile, int tx0, int ty0, QLds<MODE> &lds, int W, int H, const
         }
         wave_sync();
 #pragma unroll
-        for (int c = 0; c < COPIES; c++)
-#pragma unroll
-            for (int i = 0; i < kAccRec / 2; i++) myrec[c * (kCopy / 2) + i] = make_float2(0.0f, 0.0f);
+        for (int i = 0; i < kAccRec / 2; i++) myrec[i] = make_float2(0.0f, 0.0f);
     }
-}
-
-template <bool EXACT, bool DET, int MODE>
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
-k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
-                       const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
-                       const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
-                       float bg2, const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
-                       const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
-                       const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                       float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
-    __shared__ QLds<MODE> lds;
-    int tile, wx0, wy0;
-    if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
-    backward_wave_q<EXACT, DET, MODE>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
-                                final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
 }
 
 // One geometry for every tile (flag bits 21..22: measurements, the wave-geometry tests).
@@ -1482,6 +1437,69 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
     const int wx0 = (tile % tiles_x) * GS_TILE, wy0 = (tile / tiles_x) * GS_TILE;
     backward_wave<EXACT, DET, 4>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
                                  bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+}
+// The full-frame default since round 5: every tile one wave of sixteen four-lane groups (backward_wave_q).
+template <bool EXACT, bool DET>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                       const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
+                       const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
+                       float bg2, const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                       const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                       const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                       float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    __shared__ QLds lds;
+    int tile, wx0, wy0;
+    if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
+    backward_wave_q<EXACT, DET>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
+                                final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+}
+// ... and with the few outlying lists of a frame taken by four waves of one pixel per lane each, exactly as in
+// k_rasterize_backward_mixed (one LDS allocation serves either layout).
+struct ClassicLds {
+    SRecB stage[kChunk + 1];
+    int sid[kChunk];
+    float acc[kAcc * kAccStride];
+};
+template <bool EXACT, bool DET>
+__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+k_rasterize_backward_q_mixed(int W, int H, int tiles_x, int num_tiles, int long_len,
+                             const int32_t *__restrict__ order, const int32_t *__restrict__ ids,
+                             const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
+                             const float4 *__restrict__ packed, float bg0, float bg1, float bg2,
+                             const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
+                             const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
+                             const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
+                             float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+    constexpr size_t kBytes = sizeof(QLds) > sizeof(ClassicLds) ? sizeof(QLds) : sizeof(ClassicLds);
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
+    const int b = blockIdx.x;
+    if (b < 4 * kLongSlots) {
+        const int slot = b >> 2, part = b & 3;
+        if (slot >= num_tiles || !order) return;   // (without the longest-first order: no long path)
+        const int tile = order[slot];
+        const int2 r = bins[tile];
+        if (r.y - r.x <= long_len) return;
+        const int wx0 = (tile % tiles_x) * GS_TILE + 8 * (part & 1), wy0 = (tile / tiles_x) * GS_TILE + 8 * (part >> 1);
+        if (wx0 >= W || wy0 >= H) return;
+        ClassicLds &c = *reinterpret_cast<ClassicLds *>(raw);
+        backward_wave<EXACT, DET, 1>(tile, wx0, wy0, c.stage, c.sid, c.acc, W, H, ids, masks, bins, packed, bg0,
+                                     bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
+                                     gfix);
+        return;
+    }
+    const int bb = b - 4 * kLongSlots;
+    const int slot = ((bb >> 3) << 3) + (bb & 7);
+    if (slot >= num_tiles) return;
+    const int tile = order ? order[slot] : xcd_swizzle(slot, num_tiles);
+    if (slot < kLongSlots && order) {
+        const int2 r = bins[tile];
+        if (r.y - r.x > long_len) return;
+    }
+    const int wx0 = (tile % tiles_x) * GS_TILE, wy0 = (tile / tiles_x) * GS_TILE;
+    backward_wave_q<EXACT, DET>(tile, wx0, wy0, *reinterpret_cast<QLds *>(raw), W, H, ids, masks, bins, packed,
+                                bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
+                                gfix);
 }
 // Frames of few tiles (the reduced resolutions a training run starts with, small captures): four waves per
 // tile leave most of the chip's wave slots empty, and a lone wave issues one instruction every four cycles
@@ -1883,13 +1901,19 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     if (4 * tiles <= kWaveSlots) px_per_lane = 1;
     else if (2 * tiles <= kWaveSlots) px_per_lane = 2;
     if (((flags >> 21) & 3u) != 0u) px_per_lane = 1 << (((flags >> 21) & 3u) - 1u);
-    // flag bits 25..26: sixteen four-lane groups per wave (backward_wave_q)
-    const int qgeom = (int)((flags >> 25) & 3u);
+    // Every tile one wave with four pixels per lane: since round 5 that wave is sixteen four-lane groups
+    // (backward_wave_q: 286 -> 244 us at BASELINE config 2, level at config 3).  Flag bits 25..26: 1 = that
+    // geometry for every frame (tests), 2 = the four-group kernels of rounds 2 - 4 (measurements).
+    const int qsel = (int)((flags >> 25) & 3u);
+    const bool use_q = !checkpoints && ((flags >> 21) & 3u) == 0u && qsel != 2 &&
+                       (qsel == 1 || px_per_lane == 4 || px_per_lane == 0);
+    const bool q_mixed = use_q && px_per_lane == 0;
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
     // pieces: pixels per lane by the tile count unless the flag bits say otherwise
     const int seg_px = ((flags >> 21) & 3u) != 0u ? px_per_lane : piece_pixels_per_lane(tiles);
     const int units = ck ? (4 / seg_px) * max_segments * 8 * ((tiles + 7) / 8)
+                    : use_q ? (q_mixed ? 4 * gs::kLongSlots : 0) + 8 * ((tiles + 7) / 8)
                     : px_per_lane == 0 ? 4 * gs::kLongSlots + 8 * ((tiles + 7) / 8)
                                        : (4 / px_per_lane) * 8 * ((tiles + 7) / 8);  // PER_TILE waves per tile
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
@@ -1904,15 +1928,21 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x,     \
               tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted, block_masks, bins, \
               pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
-#define GS_Q_LAUNCH3(EX, DT, MD)                                                                          \
-    GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT, MD>), dim3(8 * ((tiles + 7) / 8)), dim3(64), 0, s, W, H, \
-              tiles_x, tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
-              bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+#define GS_Q_LAUNCH3(EX, DT)                                                                              \
+    do {                                                                                                  \
+        if (q_mixed)                                                                                      \
+            GS_LAUNCH((gs::k_rasterize_backward_q_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H,      \
+                      tiles_x, tiles, long_len, tile_order, gaussian_ids_sorted, block_masks, bins, pk,   \
+                      bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,      \
+                      gfix);                                                                              \
+        else                                                                                              \
+            GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x,   \
+                      tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,       \
+                      bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);              \
+    } while (0)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
-        if (!ck && qgeom == 1) GS_Q_LAUNCH3(EX, DT, 1);                                                    \
-        else if (!ck && qgeom == 2) GS_Q_LAUNCH3(EX, DT, 2);                                               \
-        else if (!ck && qgeom == 3) GS_Q_LAUNCH3(EX, DT, 3);                                               \
+        if (use_q) GS_Q_LAUNCH3(EX, DT);                                                                   \
         else if (ck && seg_px == 1) GS_SEG_LAUNCH3(EX, DT, 1);                                             \
         else if (ck && seg_px == 2) GS_SEG_LAUNCH3(EX, DT, 2);                                             \
         else if (ck) GS_SEG_LAUNCH3(EX, DT, 4);                                                            \

@@ -32,8 +32,9 @@ v = list(buf)
 fwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[0:5]))
 bwd = dict(zip(["steps", "steps_with_a_needing_lane", "needing_lanes", "block_entries", "wave_chunks"], v[8:13]))
 M = pipe.num_isects
-# flag bits 25..26 of GSPLAT_BWD_FLAGS: the backward with sixteen four-lane groups per wave
-bwd_groups = 16 if (int(os.environ.get("GSPLAT_BWD_FLAGS", "0"), 0) >> 25) & 3 else 4
+# the full-frame backward has sixteen four-lane groups per wave since round 5; flag bits 25..26 of
+# GSPLAT_BWD_FLAGS = 2 select the four-group kernels of rounds 2 - 4
+bwd_groups = 4 if (int(os.environ.get("GSPLAT_BWD_FLAGS", "0"), 0) >> 25) & 3 == 2 else 16
 for d in (fwd, bwd):
     d["steps_per_list_entry"] = d["steps"] / max(M, 1)
     d["groups_per_wave"] = bwd_groups if d is bwd else 4

@@ -40,8 +40,10 @@ def main():
         ok = ok and np.array_equal(ids_sorted[fi[has]], f["contributors"][offs[has]])
         if not ok:
             bad.append((i, "forward"))
-        for px, extra in ((0, 0), (1, 0), (2, 0), (4, 0), (4, cabi.GS_FLAG_DETERMINISTIC), (2, cabi.GS_FLAG_DETERMINISTIC)):
-            flag = ({1: 1, 2: 2, 4: 3}[px] << 21 if px else 0) | extra
+        # (px 16: sixteen four-lane groups per wave, flag bit 25 — the full-frame default since round 5)
+        for px, extra in ((0, 0), (1, 0), (2, 0), (4, 0), (4, cabi.GS_FLAG_DETERMINISTIC), (2, cabi.GS_FLAG_DETERMINISTIC),
+                          (16, 0), (16, cabi.GS_FLAG_DETERMINISTIC)):
+            flag = ((1 << 25) if px == 16 else {1: 1, 2: 2, 4: 3}[px] << 21 if px else 0) | extra
             gr = cabi.rasterize_backward(s.W, s.H, s.N, out["binned"], s.background, out["final_Ts"],
                                          out["final_idx"], to_dev(s.v_out), flag)
             torch.cuda.synchronize()

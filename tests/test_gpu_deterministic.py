@@ -67,12 +67,16 @@ def test_deterministic_mode_needs_its_larger_workspace():
             cabi._stream()), "gs_rasterize_backward")
 
 
-@pytest.mark.parametrize("px", [1, 2, 4])
+QGEOM, CLASSIC = 1 << 25, 2 << 25   # flag bits 25..26: sixteen four-lane groups for every frame / the four-group kernels
+
+
+@pytest.mark.parametrize("px", [1, 2, 4, "q", "q+det"])
 @pytest.mark.parametrize("scene", ["camera", "ragged", "deep"])
 def test_backward_wave_geometries_match_oracle(px, scene, restated):
     """The compositing backward with 1, 2 and 4 pixels per lane (4x4 / 4x8 / 8x8 blocks per 16-lane
-    group; flag bits 21..22) — every geometry against the oracle, incl. image sizes that are not
-    multiples of the wave's footprint."""
+    group; flag bits 21..22) and with sixteen four-lane groups per wave (4x4 blocks, four pixels per lane:
+    the full-frame default since round 5, forced here by flag bit 25) — every geometry against the oracle,
+    incl. image sizes that are not multiples of the wave's footprint."""
     import torch
 
     from opensplat_amd import cabi
@@ -84,7 +88,8 @@ def test_backward_wave_geometries_match_oracle(px, scene, restated):
     else:
         s = scenes.camera_scene(30000, 96, 64, K=4, seed=8, sigma_px=(1.0, 8.0), znear=1.0, zfar=100.0)
     out = hip_pipeline(s, backward=False)
-    flag = {1: 1, 2: 2, 4: 3}[px] << 21
+    flag = ({1: 1, 2: 2, 4: 3}[px] << 21 if isinstance(px, int) else
+            QGEOM | (cabi.GS_FLAG_DETERMINISTIC if px == "q+det" else 0))
     g = cabi.rasterize_backward(s.W, s.H, s.N, out["binned"], s.background, out["final_Ts"],
                                 out["final_idx"], to_dev(s.v_out), flag)
     torch.cuda.synchronize()
@@ -92,3 +97,44 @@ def test_backward_wave_geometries_match_oracle(px, scene, restated):
                            np_(out["cov2d"]), np_(out["depths"]), s.v_out)
     for k in ("v_xy", "v_conic", "v_colors", "v_opacity"):
         assert rel_err(np_(g[k]), ref[k].reshape(np_(g[k]).shape)) < 2e-5, (k, px)
+    if px == "q+det":   # order-independent sums: a second run has the same bits
+        g2 = cabi.rasterize_backward(s.W, s.H, s.N, out["binned"], s.background, out["final_Ts"],
+                                     out["final_idx"], to_dev(s.v_out), flag)
+        torch.cuda.synchronize()
+        for k in ("v_xy", "v_conic", "v_colors", "v_opacity"):
+            assert np.array_equal(np_(g[k]), np_(g2[k])), k
+
+
+@pytest.mark.parametrize("hot", [False, True])
+def test_full_frame_default_backward_matches_oracle_and_the_classic_kernels(hot, restated):
+    """A frame of 2 665 tiles — beyond the 2 560 up to which tiles get two or four waves — takes the
+    full-frame default: one wave per tile with sixteen four-lane groups (k_rasterize_backward_q), and with a
+    few lists far beyond the others (hot: 30 % of the Gaussians in a 40-px window) the launch that hands those
+    tiles to four one-pixel-per-lane waves (k_rasterize_backward_q_mixed).  Both against the oracle and
+    against the four-group kernels of rounds 2 - 4 (flag bit 26), with fp32 and with fixed-point sums."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(60000, 1040, 656, K=0, seed=93, znear=1.0, zfar=100.0, sigma_px=(0.7, 5.0),
+                            hot=(0.3, 40) if hot else (0.0, 0))
+    out = hip_pipeline(s, backward=False)
+    lens = np_(out["binned"].tile_bins)
+    lens = lens[:, 1] - lens[:, 0]
+    assert lens.size == 65 * 41 and 2 * lens.size > 5120
+    if hot:   # the statistics the launch decides on: a list beyond 2 x the mean and 512 entries
+        assert lens.max() > max(512, 2 * lens.mean())
+        assert out["binned"].list_stats[1] == lens.max()
+    f, ref = oracle_raster(restated, s, np_(out["xys"]), np_(out["conics"]), np_(out["colors"]),
+                           np_(out["cov2d"]), np_(out["depths"]), s.v_out)
+    assert np.array_equal(np_(out["img"]), f["img"])
+    res = {}
+    for name, flag in (("default", 0), ("classic", CLASSIC), ("default+det", cabi.GS_FLAG_DETERMINISTIC)):
+        g = cabi.rasterize_backward(s.W, s.H, s.N, out["binned"], s.background, out["final_Ts"],
+                                    out["final_idx"], to_dev(s.v_out), flag)
+        torch.cuda.synchronize()
+        res[name] = {k: np_(v).copy() for k, v in g.items()}
+        for k in ("v_xy", "v_conic", "v_colors", "v_opacity"):
+            assert rel_err(res[name][k], ref[k].reshape(res[name][k].shape)) < 2e-5, (name, k)
+    for k in ("v_xy", "v_conic", "v_colors", "v_opacity"):
+        assert rel_err(res["default"][k], res["classic"][k]) < 2e-5, k
