@@ -1238,6 +1238,8 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
                 const int won = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                float *rec = &lds.acc[e * kAccRec];
+                float2 *r2 = reinterpret_cast<float2 *>(rec + 2 * c0);
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
@@ -1260,7 +1262,8 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                     }
                     const uint64_t mneed = __builtin_amdgcn_ballot_w64(e >= last[p]) &
                                            __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
-                    if (mneed == 0ull) continue;
+                    // (no "nobody needs this pass" branch: with sixteen Gaussians in flight it is never taken, and
+                    // without it the four passes schedule as one block: 243 -> 240 us)
                     GS_STAT(9, 1);
                     GS_STAT(10, __builtin_popcountll(mneed));
                     float vis = __builtin_amdgcn_exp2f(-sg);   // sg = sigma log2(e)
@@ -1306,27 +1309,34 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 float s0, s1, s2;
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
                 // ---- add to the entry's record: plain read-add-write by the group that holds the claim ----
-                float *rec = &lds.acc[e * kAccRec];
                 // (lane masks as scalars: the loop's exit test is one s_cmp)
                 const uint64_t actm = __builtin_amdgcn_ballot_w64(active);
                 uint64_t winm = actm & __builtin_amdgcn_ballot_w64(won == grp);
                 uint64_t pendm = actm & ~winm;
+                float2 a01 = make_float2(0.0f, 0.0f);
+                float a8 = 0.0f;
+                bool loaded = false;   // (wave-uniform)
                 for (;;) {
                     if (__builtin_amdgcn_inverse_ballot_w64(winm)) {
-                        float2 *r2 = reinterpret_cast<float2 *>(rec + 2 * c0);
-                        float2 a = *r2;
-                        float c8 = rec[8];
-                        a.x += s0; a.y += s1; c8 += s2;   // (the group's four lanes hold the same s2: same store)
-                        *r2 = a;
-                        rec[8] = c8;
+                        if (!loaded) { a01 = *r2; a8 = rec[8]; }
+                        a01.x += s0; a01.y += s1; a8 += s2;   // (the group's four lanes hold the same s2: same store)
+                        *r2 = a01;
+                        rec[8] = a8;
                     }
                     if (pendm == 0ull) break;
+                    // another round for the groups that lost: the claim and the record — behind the winners'
+                    // stores — in ONE LDS round trip (242 -> 236 us at C2; reading the record of the FIRST round
+                    // before the passes, to take its round trip off the end of the step, measured 252 us: every
+                    // active group then reads, not only the winners)
                     asm volatile("; claim lost: another round");
                     bool w = false;
                     if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
                         __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         w = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == grp;
+                        a01 = *r2;
+                        a8 = rec[8];
                     }
+                    loaded = true;
                     winm = __builtin_amdgcn_ballot_w64(w);
                     pendm &= ~winm;
                 }
