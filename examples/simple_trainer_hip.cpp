@@ -20,6 +20,7 @@
 static const double kPi = 3.14159265358979323846;
 
 int main(int argc, char **argv) {
+    gsplatCheckAbi();   // libgsplat_hip.so / libgsplat_torch.so built from the same header
     int64_t numPoints = 10000, width = 256, height = 256, iterations = 200;
     double lr = 0.01;
     bool fusedAdam = false;

@@ -788,8 +788,11 @@ int gs_jpeg_decode_rgb(const uint8_t *data, size_t size, uint8_t *out, size_t ou
             coefs[i] = (int16_t *)calloc((size_t)j.c[i].blocks_w * j.c[i].blocks_h * 64, sizeof(int16_t));
             if (!coefs[i]) rc = GS_IMG_ERR_INVALID_ARGUMENT;
         }
-        int more = 1;
+        int more = 1, scans = 0;
         while (rc == GS_IMG_OK && more) {
+            /* a progressive file has about ten scans; a crafted one with thousands of tiny scans would make
+             * the decoder walk the whole coefficient array once per scan: capped */
+            if (++scans > 1000) { rc = GS_IMG_ERR_CORRUPT; break; }
             rc = decode_scan_to_coefs(&j, coefs, &scan, end);
             if (rc) break;
             const int nx = next_scan(&j, &scan, end);

@@ -98,6 +98,9 @@ int64_t gsplatBinningCapacity(int device, int imgWidth, int imgHeight);
 // Reference-signature rasterize calls (ten arguments, no cov2d): {calls that found the frame's cov2d
 // behind ProjectGaussians' own conics tensor, calls that had to invert the conic} since the last reset.
 std::tuple<int64_t, int64_t> gsplatCov2dChannelCounters(bool reset = false);
+// throws (c10::Error) if libgsplat_hip.so is not the ABI version libgsplat_torch.so was built against; C++ callers
+// call it once at start-up (the Python side checks on import)
+void gsplatCheckAbi();
 
 class RasterizeGaussians : public torch::autograd::Function<RasterizeGaussians> {
 public:

@@ -456,7 +456,18 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
         // of ProjectGaussians::forward; only a `conics` that is not that operator's untouched output
         // falls back to conic^-1
         cov2d = cov2d_channel_lookup(conics, N);
-        if (cov2d.defined()) g_cov2dHits++; else g_cov2dMisses++;
+        if (cov2d.defined()) {
+            g_cov2dHits++;
+        } else {
+            g_cov2dMisses++;
+            TORCH_WARN_ONCE("RasterizeGaussians (ten-argument form): `conics` is not the untouched output of "
+                            "ProjectGaussians (a clone, an edited or a hand-made tensor), so the projection's "
+                            "cov2d cannot be found behind it; the pixel rectangles are re-derived from conic^-1 "
+                            "— close to, not identical with, rasterizer/gsplat-cpu.  Pass cov2d as the eleventh "
+                            "argument, or hand over ProjectGaussians' conics as returned (.detach() / "
+                            ".contiguous() of it are fine).  Further misses are only counted "
+                            "(gsplatCov2dChannelCounters).");
+        }
     }
     conics = conics.contiguous(); colors = colors.contiguous(); opacity = opacity.contiguous();
     const int W = (int)imgWidth, H = (int)imgHeight;
@@ -1127,10 +1138,18 @@ static std::vector<Tensor> op_bin_and_sort_gaussians(int64_t numPoints, int64_t 
     return {std::get<0>(t), std::get<1>(t), std::get<2>(t), std::get<3>(t), std::get<4>(t)};
 }
 
-TORCH_LIBRARY(opensplat_amd, m) {
-    // libgsplat_hip.so must be the one this file's header describes (shifted arguments otherwise)
+// libgsplat_hip.so must be the one this file's header describes (shifted arguments otherwise).  Checked by
+// ops.py right after load_library (a readable Python error) and by C++ callers through gsplatCheckAbi();
+// NOT inside the static initialiser below: an exception thrown while dlopen runs ends in std::terminate
+// (ADVICE r04).
+static std::vector<int64_t> op_abi_versions() { return {(int64_t)gs_version(), (int64_t)GS_ABI_VERSION}; }
+void gsplatCheckAbi() {
     TORCH_CHECK(gs_version() == GS_ABI_VERSION, "libgsplat_hip.so has ABI version ", gs_version(),
                 ", libgsplat_torch.so was built against ", GS_ABI_VERSION, ": rebuild both");
+}
+
+TORCH_LIBRARY(opensplat_amd, m) {
+    m.def("abi_versions() -> int[]", &op_abi_versions);
     m.def("bin_and_sort_gaussians(int num_points, int num_intersects, Tensor xys, Tensor depths, Tensor radii, "
           "Tensor cum_tiles_hit, int tiles_x, int tiles_y) -> Tensor[]", &op_bin_and_sort_gaussians);
     m.def("binning_reset() -> ()", &op_binning_reset);

@@ -22,6 +22,10 @@ if not os.path.exists(_LIB) or not os.path.exists(_build.HIP_LIB):
         "there is no CPU/PyTorch fallback." % _LIB)
 torch.ops.load_library(_LIB)
 _ops = torch.ops.opensplat_amd
+_abi = list(_ops.abi_versions())
+if _abi[0] != _abi[1]:   # (arguments would be shifted: refuse before the first call)
+    raise ImportError("libgsplat_hip.so has ABI version %d, libgsplat_torch.so was built against %d: rebuild both "
+                      "(python -m opensplat_amd._build --force)" % (_abi[0], _abi[1]))
 
 BLOCK_X = BLOCK_Y = 16  # rasterizer/gsplat/config.h:1-2
 

@@ -369,7 +369,7 @@ def test_c3_windows_match_oracle(restated):
 
 # ---- (d) C4 cameras ---------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("cam", [0, 7])
+@pytest.mark.parametrize("cam", list(range(8)))   # every yaw of BASELINE config 4
 def test_c4_camera_full_frame_matches_oracle(cam, restated):
     s = scenes.config_c4(cam)
     pipe = run_timed_path(s)

@@ -174,6 +174,24 @@ def test_foreign_conics_take_the_counted_fallback():
         assert (d > 1e-6).mean() < 1e-3
 
 
+def test_detached_or_contiguous_conics_still_find_their_cov2d():
+    """What a careless caller does to the projection's output before rasterizing — .detach(), .contiguous()
+    (a no-op on the operator's contiguous output), a reshape that is a view from offset 0 — keeps storage and
+    version counter: the ten-argument call still gets the exact rectangles."""
+    import torch
+
+    from opensplat_amd import ops
+
+    s = scenes.camera_scene(5000, 200, 120, K=0, seed=13, znear=1.0, zfar=100.0)
+    _, _, _, exact = _chain(s, ten_arguments=False)
+    for hook in (lambda c: c.detach(), lambda c: c.contiguous(), lambda c: c.detach().contiguous(),
+                 lambda c: c.view(-1, 3)):
+        ops.cov2d_channel_counters(reset=True)
+        _, _, _, img = _chain(s, ten_arguments=True, conics_hook=hook)
+        assert ops.cov2d_channel_counters() == (1, 0)
+        assert torch.equal(img, exact)
+
+
 def test_channel_survives_interleaved_frames_and_released_storages():
     """Two frames in flight (project A, project B, rasterize A, rasterize B) each find their OWN cov2d; a
     released frame's entry cannot be matched by a new tensor that reuses its memory."""

@@ -134,4 +134,4 @@ def test_model_forward_branches_agree_tightly_on_the_depth_ordered_scene():
     assert gpu["visible"] == cpu["visible"]
     assert abs(gpu["loss"] - cpu["loss"]) < 2e-5, (cpu, gpu)
     assert cmp_["mean_abs_diff_cpu_gpu"] < 2e-5, cmp_
-    assert cmp_["pixels_over_1e-5"] <= 0.02 * 96 * 64, cmp_
+    assert cmp_["pixels_over_1e-5"] <= max(4, 2e-5 * 96 * 64), cmp_   # (measured: 0)
