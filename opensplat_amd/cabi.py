@@ -360,6 +360,16 @@ class Checkpoints:
     def args(self):
         return _p(self.buf), C.c_size_t(self.buf.numel()), C.c_int32(self.seg_len), C.c_int32(self.max_segments)
 
+    def frozen(self):
+        """This plan as the forward used it (buffer reference, piece length, record count): what a frame keeps
+        for ITS backward — a later plan() on the shared object (another render in between, e.g. an evaluation
+        view) then changes neither.  The records themselves are only safe until the next forward
+        writes the shared buffer: a render() / backward() pair must not be interleaved with another render()
+        that plans pieces, which Trainer.backward checks."""
+        f = Checkpoints()
+        f.buf, f.seg_len, f.max_segments, f.bytes = self.buf, self.seg_len, self.max_segments, self.bytes
+        return f
+
 
 _NO_CHECKPOINTS = (None, C.c_size_t(0), C.c_int32(0), C.c_int32(0))
 _FWD_FLAGS_ENV = int(os.environ.get("GSPLAT_FWD_FLAGS", "0"), 0)   # measurements (e.g. bits 23..24: entries per step)

@@ -387,9 +387,11 @@ struct CheckpointPlan {
         return bytes ? buffer : torch::empty({0}, f32.dtype(torch::kUInt8));
     }
 };
-static CheckpointPlan planCheckpoints(int device, int W, int H, const torch::TensorOptions &f32) {
+// needGrad: a forward none of whose inputs requires a gradient (evaluation renders) has no backward: no plan, no
+// records written
+static CheckpointPlan planCheckpoints(int device, int W, int H, const torch::TensorOptions &f32, bool needGrad) {
     CheckpointPlan cp;
-    if (!g_segmented.load()) return cp;
+    if (!g_segmented.load() || !needGrad) return cp;
     const BinState st = readBinState(device, W, H);
     check_status(gs_rasterize_checkpoint_plan(W, H, st.listStats, &cp.segLen, &cp.maxSegments, &cp.bytes),
                  "gs_rasterize_checkpoint_plan");
@@ -480,7 +482,9 @@ Tensor RasterizeGaussians::forward(AutogradContext *ctx, Tensor xys, Tensor dept
     Tensor finalIdx = torch::empty({H, W}, f32.dtype(torch::kInt32));
     // a frame that does not fill the chip, or with a tail of long lists (gsplat_hip.h:
     // gs_rasterize_checkpoint_plan; planned from the last frame of this size): checkpoints for the backward
-    CheckpointPlan cp = planCheckpoints(xys.get_device(), W, H, f32);
+    const bool needGrad = xys.requires_grad() || conics.requires_grad() || colors.requires_grad() ||
+                          opacity.requires_grad();
+    CheckpointPlan cp = planCheckpoints(xys.get_device(), W, H, f32, needGrad);
     BinnedLists b;
     for (;;) {
         b = binAndSortPacked(xys, depths, radii, conics, colors, opacity, cov2d, H, W, false);
@@ -649,7 +653,10 @@ variable_list SplatRender::forward(AutogradContext *ctx, Tensor means, Tensor lo
     // a frame of few tiles with long lists (the reduced resolutions a run starts with, model.cpp:85-92): the
     // forward leaves checkpoints along the lists, the backward runs their pieces side by side — planned
     // from the statistics of the last frame of this size (gsplat_hip.h: gs_rasterize_checkpoint_plan)
-    CheckpointPlan ckp = planCheckpoints(means.get_device(), W, H, f32);
+    const bool needGrad = means.requires_grad() || logScales.requires_grad() || quats.requires_grad() ||
+                          opacityLogits.requires_grad() || featuresDc.requires_grad() ||
+                          (hasRest && featuresRest.requires_grad());
+    CheckpointPlan ckp = planCheckpoints(means.get_device(), W, H, f32, needGrad);
     BinnedLists b;
     for (;;) {
         b = binPackedRecords(packedAll, depths, H, W);

@@ -246,7 +246,11 @@ class Trainer:
             f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd, checkpoints=ck)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
-        f["checkpoints"] = ck
+        # the plan as THIS forward used it (a later render() re-plans the shared object); the generation counter
+        # tells backward() whether another forward has overwritten the shared record buffer since
+        self._ckpt_generation = getattr(self, "_ckpt_generation", 0) + (1 if ck is not None else 0)
+        f["checkpoints"] = ck.frozen() if ck is not None else None
+        f["checkpoints_generation"] = self._ckpt_generation
         # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
         # no gradient and afterTrain returns at once (model.cpp:315)
         self._visible = b.num_isects > 0
@@ -256,6 +260,9 @@ class Trainer:
     def backward(self, v_rgb):
         """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
+        if f.get("checkpoints") is not None and f["checkpoints_generation"] != self._ckpt_generation:
+            raise RuntimeError("Trainer.backward: another render() has overwritten the checkpoint records of the "
+                               "frame being differentiated; call backward() before the next render()")
         keep = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0)
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
                                 flags | keep, workspace=self.bwd_ws, img_raw=f["img"],
@@ -416,6 +423,12 @@ class Trainer:
         self._ensure_adam_rows()
         # (the previous iteration has completed — we waited for it below — so the pinned words are free)
         self._g_cam_np[:] = pc.block
+        # the captured copy kernel reads H * W * 3 floats through this raw pointer: the tensor must be exactly that
+        # (a uint8 or strided target would be read as garbage or out of bounds)
+        if not (isinstance(gt, torch.Tensor) and gt.is_cuda and gt.device == torch.device(self.dev)
+                and gt.dtype == torch.float32 and gt.is_contiguous() and gt.numel() == H * W * 3):
+            raise ValueError("Trainer(graph=True): gt must be a contiguous float32 [H, W, 3] tensor on %s, got %s"
+                             % (self.dev, (tuple(gt.shape), gt.dtype, gt.device) if isinstance(gt, torch.Tensor) else type(gt)))
         self._g_gt_ptr_np[0] = gt.data_ptr()
         self._g_gt_ref = gt          # (alive until the iteration that reads it has completed)
         bgk = background.tobytes() if isinstance(background, np.ndarray) else tuple(float(x) for x in background)
@@ -430,6 +443,7 @@ class Trainer:
                 self.graph_stats["eager"] += 1
                 self._g_done.record()
             else:
+                self._graphs[key] = self._graphs.pop(key)   # most recently used last
                 graph, (p, b, f, loss, flags) = hit
                 # The replays run on a stream of their own, behind whatever the caller's stream holds (a
                 # render for evaluation, afterTrain's statistics kernel, a refinement) — graphs replayed on
@@ -455,8 +469,9 @@ class Trainer:
                 continue
             break
         if hit is None and self.bin_ws.capacity == b.capacity:
-            if len(self._graphs) >= 8:
-                self._graphs.clear()
+            # (least recently used leaves: a data set with many distinct intrinsics keeps its hot keys)
+            while len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
             g = torch.cuda.CUDAGraph()
             self._g_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.graph(g, stream=self._g_stream):
