@@ -1771,11 +1771,12 @@ extern "C" int gs_rasterize_checkpoint_plan(int W, int H, const int32_t *list_st
     // their tile's list and leave: longer pieces before the launch exceeds a quarter of a million of them.
     auto pieces = [&](int64_t l) { return (longest + longest / 4 + l - 1) / l + 1; };
     // ... and before the records (4 KiB per (tile, piece), allocated per frame by the callers and held until the
-    // backward) exceed 256 MiB: a 1008 x 756 frame with a 2000-entry list would take 500 MB at 64-entry pieces
-    // (ADVICE r04).  A frame that needs more even at 1024-entry pieces is walked in one pass.
-    constexpr int64_t kMaxBytes = 256ll << 20;
+    // backward) exceed 512 MiB (64-entry pieces measured best wherever they fit: a 1008 x 756 frame
+    // with a 2000-entry list takes 508 MB).  A frame that needs more even at 8192-entry pieces is walked in one pass.
+    constexpr int64_t kMaxBytes = 512ll << 20;
     constexpr int64_t kRecord = GS_TILE * GS_TILE * sizeof(float4);
-    while (len < 1024 && ((int64_t)tiles * pieces(len) > (1 << 18) || (int64_t)tiles * pieces(len) * kRecord > kMaxBytes))
+    while ((len < 1024 && (int64_t)tiles * pieces(len) > (1 << 18)) ||
+           (len < 8192 && (int64_t)tiles * pieces(len) * kRecord > kMaxBytes))
         len *= 2;
     const int64_t segs = std::min<int64_t>(pieces(len), 4096);
     if ((int64_t)tiles * segs * kRecord > kMaxBytes) return GS_OK;

@@ -395,7 +395,12 @@ static CheckpointPlan planCheckpoints(int device, int W, int H, const torch::Ten
     const BinState st = readBinState(device, W, H);
     check_status(gs_rasterize_checkpoint_plan(W, H, st.listStats, &cp.segLen, &cp.maxSegments, &cp.bytes),
                  "gs_rasterize_checkpoint_plan");
-    if (cp.bytes) cp.buffer = torch::empty({(int64_t)cp.bytes}, f32.dtype(torch::kUInt8));
+    // (sizes follow the previous frame's longest list: rounded up to 32 MiB steps, so that the caching allocator
+    // re-uses a handful of block sizes instead of collecting one per frame)
+    if (cp.bytes) {
+        const int64_t step = 32ll << 20;
+        cp.buffer = torch::empty({((int64_t)cp.bytes + step - 1) / step * step}, f32.dtype(torch::kUInt8));
+    }
     return cp;
 }
 

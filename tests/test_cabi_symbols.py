@@ -225,6 +225,10 @@ def test_checkpoint_plan_rules_without_gpu():
     # very long lists on many tiles: longer pieces keep tiles x records below 2^18 workgroups
     sl, ms, nb = plan(1504, 1000, (3000000, 20000))
     assert sl > 64 and sl & (sl - 1) == 0 and tiles(1504, 1000) * ms <= (1 << 18)
+    # ... and the records below 512 MiB
+    assert nb <= (512 << 20)
+    sl, ms, nb = plan(1008, 756, (600000, 4000))   # 64-entry pieces would take 1 GB
+    assert sl > 64 and 0 < nb <= (512 << 20)
     # invalid arguments
     assert l.gs_rasterize_checkpoint_plan(0, 10, None, None, None, None) == -1
     # a buffer that is too small / a piece length that is not a power of two: refused before any launch
