@@ -60,9 +60,12 @@ def parse_args():
                          "gradients formed locally (opensplat_amd/dist.py FactoredExchange); auto = "
                          "factored while cameras_per_rank x ranks <= 32")
     ap.add_argument("--cameras-per-rank", type=int, default=1,
-                    help="N > 1 only: cameras each rank renders per gradient exchange (gradients "
-                         "accumulated in the flat buffer, ONE all-reduce per c rasterizations); "
-                         "1 = BASELINE config 4")
+                    help="cameras each rank renders per gradient exchange (gradients accumulated in the flat "
+                         "buffer, ONE all-reduce per c rasterizations); 1 = BASELINE config 4.  With --gpus 1 "
+                         "and c >= 2 the step keeps TWO cameras in flight (step_two_in_flight) and the line "
+                         "reports the serial loop beside it")
+    ap.add_argument("--serial-cameras", action="store_true",
+                    help="--gpus 1 --cameras-per-rank c: time the serial camera loop as the headline")
     ap.add_argument("--fast-exp", action="store_true",
                     help="hardware exp instead of the glibc-bit-exact one (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,8 +134,9 @@ class Pipeline:
         self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
                         final_idx=torch.empty((H, W), **i))
         # 2-D gradients (fully written by gs_rasterize_backward) + its record workspace
-        self.bwd_ws = torch.empty((cabi.lib().gs_rasterize_backward_workspace_bytes(N) + 64,),
-                                  device=dev, dtype=torch.uint8)
+        ws_bytes = (cabi.lib().gs_rasterize_backward_workspace_bytes_det(N) if flags & cabi.GS_FLAG_DETERMINISTIC
+                    else cabi.lib().gs_rasterize_backward_workspace_bytes(N))
+        self.bwd_ws = torch.empty((ws_bytes + 64,), device=dev, dtype=torch.uint8)
         self.g2d = torch.zeros(N * 9, **f)
         self.grads = dist.GradBuffer(N, K, dev)
         # the opacity gradient goes straight into the flat all-reduce buffer
@@ -319,6 +323,97 @@ class Pipeline:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             events.append(e)
+
+
+class CameraLane:
+    """What ONE camera in flight owns: per-Gaussian forward outputs, binning workspace, images, gradient
+    records, its camera block — and a HIP stream.  Two lanes let camera j + 1's per-Gaussian forward and
+    binning (HBM- / latency-bound, VALU mostly idle) run under camera j's compositing (VALU-bound)."""
+
+    def __init__(self, pipe):
+        torch, cabi, s = pipe.torch, pipe.cabi, pipe.s
+        N, W, H, dev = s.N, s.W, s.H, pipe.dev
+        f = dict(device=dev, dtype=torch.float32)
+        i = dict(device=dev, dtype=torch.int32)
+        self.gfwd = dict(packed=torch.empty((N, 12), **f), depths=torch.empty((N,), **f),
+                         radii=torch.empty((N,), **i), rgb_raw=torch.empty((N, 3), **f), xys=None)
+        self.ws = cabi.BinWorkspace()
+        self.fwd = dict(img=torch.empty((H, W, 3), **f), final_Ts=torch.empty((H, W), **f),
+                        final_idx=torch.empty((H, W), **i))
+        self.bwd_ws = torch.zeros((cabi.lib().gs_rasterize_backward_workspace_bytes_det(N) + 64,),
+                                  device=dev, dtype=torch.uint8)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.done = torch.cuda.Event()     # this lane's last gs_gaussian_backward
+        self.cam = self.vm_dev = self.pm_dev = self.cam_pos = None
+        self.g = self.b = self.f = None
+
+
+def _camera_block(pipe, viewmat, projmat, cache={}):
+    """(GsCamera, viewmat, projmat, camera centre) on the device, uploaded once per camera."""
+    key = (viewmat.tobytes(), projmat.tobytes(), str(pipe.dev))
+    hit = cache.get(key)
+    if hit is None:
+        s = pipe.s
+        t = lambda a: pipe.torch.from_numpy(np.ascontiguousarray(a)).to(pipe.dev)
+        R, tr = viewmat[:3, :3], viewmat[:3, 3]
+        hit = cache[key] = (pipe.cabi.make_camera(viewmat, projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H),
+                            t(viewmat), t(projmat), t((-R.T @ tr).astype(np.float32)))
+    return hit
+
+
+def step_two_in_flight(pipe, cameras, exchange=True, det=False):
+    """One step over `cameras` [(viewmat, projmat), ...] with TWO of them in flight: the front half of camera
+    j + 1 (gs_gaussian_forward, binning, compositing forward) is enqueued on the other lane's stream before
+    the back half of camera j (compositing backward, gs_gaussian_backward), so that the two overlap on the
+    GPU.  Gradients accumulate into pipe.grads in camera order (an event orders the gs_gaussian_backward
+    launches, which read-modify-write the flat buffer): the same sums, in the same order, as the serial loop.
+    Generalises the per-image loop of opensplat.cpp:151-170 to camera batches."""
+    torch, cabi, s = pipe.torch, pipe.cabi, pipe.s
+    assert pipe.fx is None and not pipe.stage_kernels
+    if not hasattr(pipe, "lanes"):
+        pipe.lanes = [CameraLane(pipe), CameraLane(pipe)]
+    main = torch.cuda.current_stream()
+    KEEP = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if det else 0)
+
+    def front(L, cam):
+        L.cam, L.vm_dev, L.pm_dev, L.cam_pos = _camera_block(pipe, *cam)
+        with torch.cuda.stream(L.stream):
+            L.g = cabi.gaussian_forward(L.cam, pipe.means, pipe.scales, pipe.quats, pipe.opac, pipe.features_dc,
+                                        pipe.features_rest, L.cam_pos, s.degrees_to_use, 0, out=L.gfwd,
+                                        viewmat_dev=L.vm_dev, projmat_dev=L.pm_dev)
+            L.b = cabi.bin_and_sort(s.W, s.H, None, L.g["depths"], None, None, None, None, None, L.ws,
+                                    speculative=True, packed=L.g["packed"])
+            L.f = cabi.rasterize_forward(s.W, s.H, L.b, pipe.background, pipe.flags, out=L.fwd)
+
+    def back(L, j, prev):
+        with torch.cuda.stream(L.stream):
+            cabi.rasterize_backward(s.W, s.H, s.N, L.b, pipe.background, L.f["final_Ts"], L.f["final_idx"],
+                                    pipe.v_out, pipe.flags | KEEP, workspace=L.bwd_ws)
+            if prev is not None:
+                L.stream.wait_event(prev.done)     # the flat gradient buffer: camera order
+            cabi.gaussian_backward(L.cam, pipe.means, pipe.scales, pipe.quats, pipe.opac, L.cam_pos, s.K,
+                                   s.degrees_to_use, L.g["radii"], L.g["rgb_raw"], L.bwd_ws, pipe.gout,
+                                   cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0, viewmat_dev=L.vm_dev,
+                                   projmat_dev=L.pm_dev)
+            L.done.record(L.stream)
+
+    for L in pipe.lanes:
+        L.stream.wait_stream(main)
+    front(pipe.lanes[0], cameras[0])
+    prev = None
+    for j in range(len(cameras)):
+        L = pipe.lanes[j % 2]
+        while not cabi.validate_binning(L.b):      # (the id list was too small: this camera's front again)
+            pipe.misses += 1
+            front(L, cameras[j])
+        if j + 1 < len(cameras):
+            front(pipe.lanes[(j + 1) % 2], cameras[j + 1])
+        back(L, j, prev)
+        prev = L
+    main.wait_event(prev.done)
+    pipe.num_isects = prev.b.num_isects
+    if exchange:
+        pipe.dist.wait_all(pipe.dist.allreduce_all_async(pipe.grads))
 
 
 def reorder_scene(s, how):
@@ -539,6 +634,41 @@ def exchange_probe(pipe, world, dev, iters=5):
     return out
 
 
+def cameras_probe(scene, dev, flags, factored, world, rank, cams, steps=6):
+    """N > 1: rasterizations/s with ONE and with TWO cameras per rank and exchange (gradients of a rank's cameras
+    accumulated locally, one exchange per step), measured back to back in THIS run on pipelines of their own:
+    the first multi-GPU record answers DESIGN.md §7's table (exchange exposed at c = 1, amortised at c >= 2) by
+    itself.  Collective: every rank takes part."""
+    import torch
+
+    out = {}
+    for c in (1, 2):
+        pipe = Pipeline(scene, dev, flags, factored=factored, cameras_per_rank=c)
+
+        def step():
+            for j in range(c):
+                pipe.set_camera(*cams[(rank * c + j) % 8])
+                pipe.step(accumulate=j > 0, exchange=j == c - 1, slot=j)
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        out["c%d_rasterizations_per_s" % c] = world * c * steps / float(t.item())
+        out["c%d_ms_per_step" % c] = float(t.item()) / steps * 1e3
+        del pipe
+        torch.cuda.empty_cache()
+    out["note"] = "%d steps each after 3 warm-up steps, host-timed between barriers, max over ranks" % steps
+    return out
+
+
 def operator_binning_probe(scene, dev, passes=3):
     """The speculative binning as the C++ OPERATORS run it (RasterizeGaussians::apply through
     torch.ops, torch_ops.cpp): the eight C4 cameras in shuffled order, `passes` times — forwards
@@ -688,7 +818,7 @@ def main():
 
     cfg = args.config
     if cfg == "auto":
-        cfg = "c2" if world == 1 else "c4"
+        cfg = "c2" if (world == 1 and args.cameras_per_rank == 1) else "c4"
     if cfg == "c2":
         scene = scenes.camera_scene(args.gaussians, args.width, args.height, K=16, seed=1,
                                     sigma_px=(0.5, 4.0), name="C2", hot=(args.hot, 48))
@@ -729,11 +859,18 @@ def main():
     sequence = cfg == "c4-sequence"
     step_no = [0]
 
-    def one_step(ev=None, kev=None):
+    # one GPU, several cameras per step: two of them in flight (the serial loop is timed beside it)
+    two_in_flight = world == 1 and cpr >= 2 and not args.stage_kernels and not args.serial_cameras
+    step_cams = [cams[(rank * cpr + j) % 8] for j in range(cpr)]
+
+    def one_step(ev=None, kev=None, serial=False):
         """One bench step: cpr cameras on this rank (gradients accumulated), then the exchange."""
         if sequence:
             pipe.set_camera(*cams[step_no[0] % 8])
         step_no[0] += 1
+        if two_in_flight and not serial and ev is None and kev is None:
+            step_two_in_flight(pipe, step_cams)
+            return
         for j in range(cpr):
             if cpr > 1:
                 pipe.set_camera(*cams[(rank * cpr + j) % 8])
@@ -761,7 +898,7 @@ def main():
     # ---- warm-up (untimed): the W steps asked for, then more until the clocks and caches have settled —
     # a 1080p step is 0.8 ms, five of them are over before the GPU has left its idle clock (the driver's
     # `--steps 20 --warmup W` line of round 3 read 6 % below a 50-step run for that reason alone)
-    def timed_block(n):
+    def timed_block(n, serial=False):
         """n plain steps (no events, no hooks) between barrier + synchronize on both sides; seconds (max
         over ranks)."""
         torch.cuda.synchronize()
@@ -769,7 +906,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
-            one_step()
+            one_step(serial=serial)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -805,6 +942,21 @@ def main():
     # driver's --steps 20 that was every other step) ----
     elapsed = timed_block(args.steps)
     misses_timed = pipe.misses - misses_warmup
+
+    # ---- one GPU, c >= 2 cameras per step: the serial camera loop timed beside the two-in-flight headline ----
+    cameras_ab = None
+    if two_in_flight:
+        for _ in range(4):
+            one_step(serial=True)
+        dt_serial = timed_block(args.steps, serial=True)
+        dt_pipe2 = timed_block(args.steps)       # (again, after the serial block: same clock state)
+        cameras_ab = {"cameras_per_step": cpr,
+                      "serial_rasterizations_per_s": cpr * args.steps / dt_serial,
+                      "two_in_flight_rasterizations_per_s": cpr * args.steps / dt_pipe2,
+                      "speedup": dt_serial / dt_pipe2,
+                      "note": "same cameras, same buffers, %d steps each; two_in_flight: camera j+1's per-Gaussian "
+                              "forward + binning + compositing forward on a second stream under camera j's "
+                              "compositing backward (bench.step_two_in_flight)" % args.steps}
 
     # ---- a second, longer plain block (>= 200 steps and >= 0.25 s), reported beside the headline: what the
     # path sustains once a run is long enough for the clocks to stop moving ----
@@ -855,6 +1007,22 @@ def main():
             exchange_ab = exchange_probe(pipe, world, dev)     # collective: every rank takes part
         except Exception as e:
             exchange_ab = {"error": repr(e)}
+
+    cameras_c12 = None
+    comm = None
+    if world > 1 and not args.stage_kernels:
+        try:
+            cameras_c12 = cameras_probe(scene, dev, flags, factored, world, rank, cams)   # collective
+        except Exception as e:
+            cameras_c12 = {"error": repr(e)}
+        try:   # what the communicator is made of: library version, ranks, devices
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            ver = None
+        names = [None] * world
+        torch.distributed.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(dev), local))
+        comm = {"backend": backend, "rccl_version": ver, "ranks": world, "devices": names,
+                "NCCL_DEBUG": os.environ.get("NCCL_DEBUG")}
 
     if rank == 0:
         N, K, M, P = scene.N, scene.K, pipe.num_isects, scene.W * scene.H
@@ -955,6 +1123,16 @@ def main():
                                       else pipe.grads.nbytes),
             # both exchanges timed alone in this run (N > 1): flat = north_star's single all-reduce
             "exchange_ab": exchange_ab,
+            # --gpus 1 --cameras-per-rank c >= 2: serial camera loop against two cameras in flight, this run
+            "cameras_ab": cameras_ab,
+            # N > 1: one against two cameras per rank and exchange, this run; the communicator
+            "cameras_c1_c2": cameras_c12,
+            "communicator": comm,
+            # per-link xGMI bytes of the exchange as launched: a ring over W ranks puts bytes_moved_per_rank on
+            # each rank's outgoing link (RCCL rings on an 8-GPU MI355X node use one xGMI link per neighbour)
+            "per_link_bytes_per_step": (None if world == 1 else
+                                        pipe.fx.bytes_moved_per_rank if pipe.fx is not None else
+                                        int(2 * (world - 1) / world * pipe.grads.nbytes)),
             "allreduce_ms_rank0": stage_ms.get("allreduce", 0.0),
             # the whole exchange (all-reduce [+ all-gather + SH backward over the gathered cameras]) as
             # timed by HIP events on rank 0, apart from ms_per_step

@@ -94,9 +94,11 @@ def test_single_process_is_noop():
     assert (buf.flat == 3.0).all()
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` (the driver's command form, no torchrun around it) must start two
-    ranks by itself; GSPLAT_BENCH_DRY_LAUNCH stops each rank after the rendezvous."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` (the driver's command form, no torchrun around it) must start N ranks by
+    itself — two, and the eight of BASELINE config 4; GSPLAT_BENCH_DRY_LAUNCH stops each rank after the
+    rendezvous."""
     import json
     import subprocess
     import sys
@@ -105,14 +107,14 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, GSPLAT_DIST_BACKEND="gloo", GSPLAT_BENCH_DRY_LAUNCH="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
-                       env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     import re
 
-    # (the two ranks share stdout: their lines may run together)
+    # (the ranks share stdout: their lines may run together)
     lines = [json.loads(m) for m in re.findall(r'\{"dry_launch".*?\}', r.stdout)]
-    assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["world"] == 2 for l in lines)
+    assert sorted(l["rank"] for l in lines) == list(range(world)) and all(l["world"] == world for l in lines)
 
 
 def test_bench_refuses_a_world_that_does_not_match():
