@@ -702,8 +702,8 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *out = reinterpret_cast<uint64_t *>(smem);           // CAP keys
     int32_t *cnt = reinterpret_cast<int32_t *>(out + CAP);         // B counters / cursors
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words (16 reserved)
-    uint16_t *outm = reinterpret_cast<uint16_t *>(scratch + 16);   // CAP masks
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words (64 reserved)
+    uint16_t *outm = reinterpret_cast<uint16_t *>(scratch + 64);   // CAP masks
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
@@ -1148,14 +1148,20 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     // few tiles, long lists: the 8192 class for what is beyond 1024 keys and the 1024 class for everything else
     // (20 000 Gaussians at 384x288: 30 + 28 + 19 us with the 512 class as a third launch)
     const bool few_long = have_stats && !no_long && tiles <= 1024;
+    // (Launching the classes side by side on helper streams — they work on disjoint tiles, every class clamps the
+    // ranges it reads by `capacity` itself — was built and measured in round 5: each launch got slower by what it
+    // shared, the stage 0.233 -> 0.251 ms on the hot-spot scene.  In a row.)
     if (!only_short && !few_long) {
         GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
                            capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     if (!no_long) {
-        constexpr int CAP = 8192, B = 4096, NT = 256;
-        const size_t lds = 8 * CAP + 4 * B + 64 + 2 * CAP;
+        // 1024 threads per tile: the few tiles of this class are latency chains of one workgroup each —
+        // with 256 threads 77 us for the nine 5 - 8 k-entry lists of the hot-spot scene, 36 us with 1024
+        // (bin_sort 0.272 -> 0.233 ms there)
+        constexpr int CAP = 8192, B = 4096, NT = 1024;
+        const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
         GS_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

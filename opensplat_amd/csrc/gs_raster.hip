@@ -63,6 +63,13 @@
 namespace gs {
 
 constexpr int kChunk = 64;  // entries staged per pass == wave width
+// 1: the forward's four groups read their next slot from per-group queues in LDS (built per chunk from the four
+// ballots, like backward_wave_q's sixteen) instead of walking four 64-bit SGPR masks with s_ff1: twenty scalar
+// instructions per step less on a kernel whose one scalar unit per CU is a co-bottleneck — 169.5 -> 163.5 us at
+// C2, 1.146 -> 1.125 ms at C3, same bits (round 5; 0 = the scalar walk, for measurements)
+#ifndef GS_FWD_QWALK
+#define GS_FWD_QWALK 1
+#endif
 constexpr int kGradRec = 16;  // floats per Gaussian in the backward's gradient records (64 B)
 
 // Optional work counters (build with -DGS_STATS; never in the shipped library): per launch totals of
@@ -226,6 +233,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                     int max_seg) {
     __shared__ SRec stage[kChunk + 1];
     __shared__ uint64_t exp_tab[EXACT ? kExpTabLds : 1];
+#if GS_FWD_QWALK
+    __shared__ __attribute__((aligned(16))) uint8_t fq[4 * kChunk + 16];   // [group][rank] -> slot
+#endif
     const int lane = threadIdx.x;
     int tile, qx0, qy0;
     if (!decode_wave<1>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
@@ -315,6 +325,24 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
         uint64_t m2 = (alive & 0x0000FFFF00000000ull) ? __builtin_amdgcn_ballot_w64((touch & 4u) != 0u) : 0ull;
         uint64_t m3 = (alive & 0xFFFF000000000000ull) ? __builtin_amdgcn_ballot_w64((touch & 8u) != 0u) : 0ull;
+#if GS_FWD_QWALK
+        // the four groups' lists as QUEUES of slot numbers in LDS (as backward_wave_q builds its sixteen): a step
+        // is one byte read with a per-group address instead of four scalar find-first-set chains
+        int nsteps = 0;
+        if (ILP == 1) {
+            reinterpret_cast<uint32_t *>(fq)[lane] = kChunk * 0x01010101u;
+            if (lane < 4) reinterpret_cast<uint32_t *>(fq)[kChunk + lane] = kChunk * 0x01010101u;
+#define GS_FQ(g, m)                                                                                         \
+    if (__builtin_amdgcn_inverse_ballot_w64(m))                                                             \
+        fq[(g) * kChunk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                             \
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =   \
+            (uint8_t)lane;
+            GS_FQ(0, m0) GS_FQ(1, m1) GS_FQ(2, m2) GS_FQ(3, m3)
+#undef GS_FQ
+            nsteps = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
+                         max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
+        }
+#endif
         __syncthreads();
         GS_STAT(3, __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
         GS_STAT(4, 1);
@@ -329,6 +357,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         auto walk = [&](auto binds_tag, auto hot_tag) {
           constexpr bool BINDS = decltype(binds_tag)::value;
           constexpr bool HOT = CK && decltype(hot_tag)::value;
+#if GS_FWD_QWALK
+          const uint8_t *myq = &fq[grp * kChunk];
+          int e_next = myq[0];
+          for (int k = 0; k < nsteps; k++) {
+            const int e = e_next;
+            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+            e_next = myq[k + 1];
+#else
           uint32_t ep_next;
           { GS_WALK_PACK(ep0_) ep_next = ep0_; }
           while (ep_next != kWalkDone) {
@@ -336,6 +372,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             const int e = (int)((ep >> gsh) & 0xFFu);
             const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
             { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
+#endif
             const uint32_t sbits = __float_as_uint(q1.z);
             GS_STAT(0, 1);
             const float dx = q0.x - pxf, dy = q0.y - pyf;
