@@ -263,6 +263,9 @@ class Pipeline:
         # leaves the records in the last-level cache right before the compositing atomics arrive
         ZEROED = cabi.GS_FLAG_RECORDS_ZEROED if os.environ.get("GSPLAT_RECORDS_ZEROED") else 0
         KEEP = cabi.GS_FLAG_KEEP_RECORDS | ZEROED
+        # (the 64 MB record memset on a stream of its own, under the forward kernels that leave the HBM idle, was
+        # measured in round 5: the backward stage 0.263 -> 0.248 ms, the step 0.640 -> 0.648 ms — the per-Gaussian
+        # kernels next to it slow down by more; profiles/HISTORY.md)
         while True:
             ev_local = []
 
@@ -1045,7 +1048,11 @@ def main():
             tname = "traffic_c3.json"
         if tname and os.path.exists(os.path.join(ROOT, "profiles", tname)):
             try:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", tname))).get(dom)
+                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+                # (the file is keyed by kernel name: k_rasterize_backward_q since round 5)
+                traffic = tj.get(dom)
+                if traffic is None:
+                    traffic = next((v for k, v in sorted(tj.items()) if k.startswith(dom)), None)
             except Exception:
                 traffic = None
         ms_per_step = elapsed / args.steps * 1e3

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/calib_r02.json from the counter-calibration run (scripts/ubench/gather_calib under
-rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/gpu_r02a.sh): known bytes of five access patterns
+rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a one-off run script of round 2, in the git history): known bytes of five access patterns
 against what the counters report (KiB units), and the correction factors derived from them."""
 import csv
 import json

@@ -127,7 +127,8 @@ def main():
     # ... and so do profiles of the non-default configurations (tags like r01i_c3)
     tname = "traffic_f2.json" if tag.startswith("f2") else \
         ("traffic_%s.json" % tag.split("_", 1)[1] if "_" in tag else "traffic.json")
-    (dst / tname).write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
+    if len(traffic) > 1:   # (a kernel-stats-only profile has no counters: keep the last measured traffic file)
+        (dst / tname).write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
     # every gs:: kernel of the step in one small file that bench.py attaches to its JSON line
     # (`kernels_profiled`, `roofline_valu`): rocprofv3 average duration, measured HBM bytes, the VALU
     # issue occupancy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, 8 = every SIMD issuing all the time as
