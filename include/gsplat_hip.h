@@ -264,7 +264,12 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            max(512, 2 x mean) — the tiles whose own list exceeds that length to four waves with
  *            one pixel per lane, inside the same launch; a frame of fewer than 1280 / 2560 tiles
  *            gives EVERY tile four / two waves.  Scheduling only: the sums differ by atomic order
- *            as always.
+ *            as always.  (Round 5: the one-wave-per-tile launch runs sixteen four-lane groups per wave,
+ *            one per 4x4-pixel block — gs_raster.hip, backward_wave_q.  Measurement / test bits of
+ *            `flags`, not part of the contract: bits 21..22 = 1 / 2 / 3 force one / two / four pixels
+ *            per lane with the four-group kernels for every tile; bits 23..24 = 1 / 2 force one / two
+ *            list entries per forward step; bits 25..26 = 1 the sixteen-group backward for every
+ *            frame, 2 the four-group kernels of rounds 2 - 4.)
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory
  *            (a device tensor is read by the kernels themselves: no copy, no synchronisation). */
