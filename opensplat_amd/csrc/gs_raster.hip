@@ -206,7 +206,7 @@ __device__ __forceinline__ void stage_sentinel(R *s) {
         GS_WALK_STEP(m3, e3_)                                                                        \
         ep = (uint32_t)e0_ | ((uint32_t)e1_ << 8) | ((uint32_t)e2_ << 16) | ((uint32_t)e3_ << 24);   \
     }
-constexpr uint32_t kWalkDone = 0x40404040u;   // the packed word of four exhausted groups (slot kChunk = 64)
+[[maybe_unused]] constexpr uint32_t kWalkDone = 0x40404040u;   // the packed word of four exhausted groups (slot kChunk = 64)
 
 // ---------------------------------------------------------------------------------------------
 // ILP: entries of a group's list taken per step (1: full frames; 2: frames of few tiles, see walk2).
@@ -246,7 +246,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     if (lane == 0) stage_sentinel(&stage[kChunk]);
 
     const int grp = lane >> 4, li = lane & 15;
-    const uint32_t gsh = 8u * (uint32_t)grp;
+    const uint32_t gsh = 8u * (uint32_t)grp;   // (the group's byte of the packed slot word: scalar walk only)
+    (void)gsh;
     const int px = qx0 + 4 * (grp & 1) + (li & 3), py = qy0 + 4 * (grp >> 1) + (li >> 2);
     const bool inimg = px < W && py < H;
     const float pxf = (float)px;
@@ -329,7 +330,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         // the four groups' lists as QUEUES of slot numbers in LDS (as backward_wave_q builds its sixteen): a step
         // is one byte read with a per-group address instead of four scalar find-first-set chains
         int nsteps = 0;
-        if (ILP == 1) {
+        {
             reinterpret_cast<uint32_t *>(fq)[lane] = kChunk * 0x01010101u;
             if (lane < 4) reinterpret_cast<uint32_t *>(fq)[kChunk + lane] = kChunk * 0x01010101u;
 #define GS_FQ(g, m)                                                                                         \
@@ -432,6 +433,18 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         auto walk2 = [&](auto binds_tag, auto hot_tag) {
           constexpr bool BINDS = decltype(binds_tag)::value;
           constexpr bool HOT = CK && decltype(hot_tag)::value;
+#if GS_FWD_QWALK
+          // (the queue holds the group's slots in list order, the sentinel slot behind them: entries 2k and
+          // 2k + 1 of the queue are this step's pair — on a frame of lone waves every instruction of a step
+          // counts, and the forty scalar ones of the two mask walks were half of them)
+          const uint16_t *myq2 = reinterpret_cast<const uint16_t *>(&fq[grp * kChunk]);
+          uint32_t pair_next = myq2[0];
+          for (int k = 0; k < (nsteps + 1) / 2; k++) {
+            const int ea = (int)(pair_next & 0xFFu), eb = (int)(pair_next >> 8);
+            const float4 qa0 = stage[ea].p0, qa1 = stage[ea].p1, qa2 = stage[ea].p2;
+            const float4 qb0 = stage[eb].p0, qb1 = stage[eb].p1, qb2 = stage[eb].p2;
+            pair_next = myq2[k + 1];
+#else
           uint32_t epa_next, epb_next;
           { GS_WALK_PACK(wa0_) epa_next = wa0_; }
           { GS_WALK_PACK(wb0_) epb_next = wb0_; }
@@ -442,6 +455,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             { GS_WALK_PACK(wa1_) epa_next = wa1_; }
             { GS_WALK_PACK(wb1_) epb_next = wb1_; }
             asm volatile("" : "+s"(epa_next), "+s"(epb_next));
+#endif
             const uint32_t sba = __float_as_uint(qa1.z), sbb = __float_as_uint(qb1.z);
             GS_STAT(0, 1);
             const float dxa = qa0.x - pxf, dya = qa0.y - pyf, dxb = qb0.x - pxf, dyb = qb0.y - pyf;
@@ -667,6 +681,13 @@ __device__ __forceinline__ float mfma_reduce9(float v0, float v1, float v2, floa
 constexpr int kAcc = 9;           // accumulator floats per staged entry
 constexpr int kAccStride = kChunk + 1;  // component-major [9][65]: the nine components of an entry in nine banks
 constexpr float kFixScale = 1099511627776.0f;  // 2^40: fixed-point scale of GS_FLAG_DETERMINISTIC
+// 1: the four groups of backward_wave read their next slot from per-group queues in LDS (behind the accumulators)
+// instead of walking four SGPR masks — like the forward (GS_FWD_QWALK): on the frames these kernels still serve
+// (few tiles, pieces, outlying lists) a wave is alone on its SIMD and every instruction of a step counts
+#ifndef GS_BWD_QWALK
+#define GS_BWD_QWALK 1
+#endif
+constexpr int kAccFloats = kAcc * kAccStride + (GS_BWD_QWALK ? (4 * kChunk + 16) / 4 : 0);   // + the queues
 
 // (five waves per SIMD: the compiler keeps the rare exact-exponential / rectangle paths out of the
 // register budget)
@@ -727,7 +748,8 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
 #endif
     const int fj = (lane * 7282) >> 16;        // flush: lane = 9 * fj + fcomp (lane 63: fj = 7, no work)
     const int fcomp = lane == 63 ? kAcc : lane - 9 * fj;
-    const uint32_t gsh = 8u * (uint32_t)grp;
+    const uint32_t gsh = 8u * (uint32_t)grp;   // (scalar walk only)
+    (void)gsh;
     const int px = wx0 + G::BW * (grp & 1) + (li % G::LW);
     const int py0 = wy0 + G::BH * (grp >> 1) + (li / G::LW);   // pixel p of the lane: row py0 + p * LH
     const float pxf = (float)px;
@@ -881,6 +903,20 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     }
         GS_TRIM(m0, gl0) GS_TRIM(m1, gl1) GS_TRIM(m2, gl2) GS_TRIM(m3, gl3)
 #undef GS_TRIM
+#if GS_BWD_QWALK && !GS_BWD_MFMA
+        uint8_t *fq = reinterpret_cast<uint8_t *>(acc + kAcc * kAccStride);   // [group][rank] -> slot
+        reinterpret_cast<uint32_t *>(fq)[lane] = kChunk * 0x01010101u;
+        if (lane < 4) reinterpret_cast<uint32_t *>(fq)[kChunk + lane] = kChunk * 0x01010101u;
+#define GS_FQ(g, m)                                                                                         \
+    if (__builtin_amdgcn_inverse_ballot_w64(m))                                                             \
+        fq[(g) * kChunk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                             \
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =   \
+            (uint8_t)lane;
+        GS_FQ(0, m0) GS_FQ(1, m1) GS_FQ(2, m2) GS_FQ(3, m3)
+#undef GS_FQ
+        const int nsteps = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
+                               max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
+#endif
         __syncthreads();
         GS_STAT(11, __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
         GS_STAT(12, 1);
@@ -897,6 +933,14 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
         bool flushed_any = false;  // wave-uniform
         auto walk = [&](auto binds_tag) {
             constexpr bool BINDS = decltype(binds_tag)::value;
+#if GS_BWD_QWALK && !GS_BWD_MFMA
+            const uint8_t *myq = &fq[grp * kChunk];
+            int e_next = myq[0];
+            for (int k = 0; k < nsteps; k++) {
+                const int e = e_next;
+                const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+                e_next = myq[k + 1];
+#else
             uint32_t ep_next;
             { GS_WALK_PACK(ep0_) ep_next = ep0_; }
             while (ep_next != kWalkDone) {
@@ -904,6 +948,7 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
                 const int e = (int)((ep >> gsh) & 0xFFu);
                 const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
                 { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
+#endif
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
@@ -1431,7 +1476,7 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
-    __shared__ float acc[kAcc * kAccStride];
+    __shared__ float acc[kAccFloats];
     int tile, wx0, wy0;
     if (!decode_wave<PX>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
     backward_wave<EXACT, DET, PX>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
@@ -1458,7 +1503,7 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
                            float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
-    __shared__ float acc[kAcc * kAccStride];
+    __shared__ float acc[kAccFloats];
     const int b = blockIdx.x;
     if (b < 4 * kLongSlots) {
         const int slot = b >> 2, part = b & 3;
@@ -1506,7 +1551,7 @@ k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *
 struct ClassicLds {
     SRecB stage[kChunk + 1];
     int sid[kChunk];
-    float acc[kAcc * kAccStride];
+    float acc[kAccFloats];
 };
 template <bool EXACT, bool DET>
 __global__ void __launch_bounds__(64, GS_BWD_WAVES)
@@ -1570,7 +1615,7 @@ k_rasterize_backward_seg(int W, int H, int tiles_x, int num_tiles, int seg_shift
                          unsigned long long *__restrict__ gfix) {
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
-    __shared__ float acc[kAcc * kAccStride];
+    __shared__ float acc[kAccFloats];
     // block -> (XCD x, k): k = (slot / 8, piece, part of the tile), like decode_wave<PX> with PER_TILE * max_seg
     // parts per tile
     using G = WaveGeom<PX>;
