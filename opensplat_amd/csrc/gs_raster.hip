@@ -2004,9 +2004,19 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     // Every tile one wave with four pixels per lane: since round 5 that wave is sixteen four-lane groups
     // (backward_wave_q: 286 -> 244 us at BASELINE config 2, level at config 3).  Flag bits 25..26: 1 = that
     // geometry for every frame (tests), 2 = the four-group kernels of rounds 2 - 4 (measurements).
+    // ... where the footprints are SMALL: what the sixteen groups buy is live lanes on 4 x 4 blocks that a Gaussian
+    // covers half of; splats of tens of pixels (SfM-initialised scenes at the start of a run) fill whole tiles,
+    // every entry then has sixteen (block, entry) pairs colliding on its record, and the four-group kernels are
+    // 1.3 ... 1.5 x faster (100 000 Gaussians at 1504 x 1000: 126 against 163 us; the pieces with sixteen groups,
+    // built and measured: 188 -> 240 us at 1008 x 756 — not kept).  The statistic at hand is the list entries per
+    // Gaussian, M / N, of the frame the list statistics come from: 2.2 at BASELINE config 2, 3.8 at config 3,
+    // 15 ... 35 on those scenes; sixteen groups up to kQMaxEntriesPerGaussian.
+    constexpr int64_t kQMaxEntriesPerGaussian = 6;
     const int qsel = (int)((flags >> 25) & 3u);
+    const bool small_footprints = list_stats && list_stats[0] > 0 &&
+                                  (int64_t)list_stats[0] <= kQMaxEntriesPerGaussian * (int64_t)N;
     const bool use_q = !checkpoints && ((flags >> 21) & 3u) == 0u && qsel != 2 &&
-                       (qsel == 1 || px_per_lane == 4 || px_per_lane == 0);
+                       (qsel == 1 || ((px_per_lane == 4 || px_per_lane == 0) && small_footprints));
     const bool q_mixed = use_q && px_per_lane == 0;
     const float4 *ck = static_cast<const float4 *>(checkpoints);
     const int seg_shift = ck ? __builtin_ctz((unsigned)seg_len) : 0;
