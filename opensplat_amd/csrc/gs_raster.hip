@@ -53,6 +53,13 @@
 //     chunk with one atomic lane per (entry, component): a Gaussian costs one global atomic
 //     line-request per wave it contributes to (its nine lanes hit ONE 64-byte record).
 //
+//
+// Round 5 (profiles/HISTORY.md): (a) the lists of the groups are no longer walked as SGPR masks
+// but read from per-group slot QUEUES in LDS, built per chunk from the same ballots (GS_FWD_QWALK, GS_BWD_QWALK);
+// (b) the backward of a full frame with small footprints runs SIXTEEN four-lane groups per wave, one per 4x4
+// block (backward_wave_q: orbit reduction, claimed plain read-add-write instead of LDS atomics), the four-group
+// backward_wave below stays for frames of few tiles, the pieces, outlying lists and big splats.
+//
 // Roofline: HBM traffic is one 48-byte gather per entry (per wave of the tile, served by L2) plus
 // 20 B per pixel; DESIGN.md states the algorithmic bytes used for roofline.achieved and the VALU
 // accounting.  Measured history of both kernels: DESIGN.md 4.1, profiles/.
