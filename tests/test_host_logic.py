@@ -1,4 +1,6 @@
 """CPU: host-side logic — scene generators, gradient buffer layout, byte accounting, helpers."""
+import os
+
 import numpy as np
 import torch
 
@@ -103,3 +105,32 @@ def test_trainer_schedules_and_morton_permutation_on_cpu():
     # points next to the 0.5 planes may sit on the other side)
     octant = ((m > 0.5).long() * torch.tensor([1, 2, 4])).sum(1)
     assert (octant[1:] != octant[:-1]).sum() <= 40
+
+
+def test_host_model_of_the_backward_geometries_reproduces_the_measured_counters():
+    """scripts/sim_bwd_geometry.py — the host model that picked the sixteen-group backward over the entry-parallel
+    forms — rebuilds lists, coverage masks and last contributors of a window of BASELINE
+    config 2's tiles on the CPU.  Its model of the round-4 kernel must stay where the instrumented kernel's
+    counters are (profiles/work_stats_r04_c2.json), and its prediction for sixteen groups where the round-5
+    kernel's are (profiles/work_stats_r05_c2.json): otherwise the numbers quoted from it mean nothing."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "sim_bwd_geometry.py"), "--config", "c2",
+                        "--tiles", "12x8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sim = json.loads(r.stdout)
+    r4 = json.load(open(os.path.join(root, "profiles", "work_stats_r04_c2.json")))["backward"]
+    r5 = json.load(open(os.path.join(root, "profiles", "work_stats_r05_c2.json")))["backward"]
+    M4 = json.load(open(os.path.join(root, "profiles", "work_stats_r04_c2.json")))["M"]
+    # four 16-lane groups on 8 x 8 blocks: steps and (block, entry) pairs per list entry, passes per step, live lanes
+    assert abs(sim["cur"]["steps_per_entry"] / r4["steps_per_list_entry"] - 1.0) < 0.08
+    assert abs(sim["cur"]["pairs_per_entry"] / (r4["block_entries"] / M4) - 1.0) < 0.08
+    assert abs(sim["cur"]["passes_per_step"] / (r4["steps_with_a_needing_lane"] / r4["steps"]) - 1.0) < 0.05
+    assert abs(sim["cur"]["live_lanes_per_pass"] / r4["live_lanes_per_needing_step"] - 1.0) < 0.10
+    # sixteen four-lane groups on 4 x 4 blocks, 64-entry chunks: predicted before the kernel existed
+    assert abs(sim["q64"]["steps_per_entry"] / r5["steps_per_list_entry"] - 1.0) < 0.08
+    assert abs(sim["q64"]["pairs_per_entry"] / (r5["block_entries"] / M4) - 1.0) < 0.08
+    assert 0.6 < sim["q64"]["vs_cur"] < 0.75          # the instruction-count ratio the decision rested on
