@@ -92,10 +92,11 @@ typedef struct GsCamera {
 const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
 /* ABI version of THIS header: 10000*major + 100*minor + patch.  Bumped whenever an entry point changes its
- * argument list (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0: round 4).  A consumer
+ * argument list or an entry point is added (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0:
+ * round 4; 0.4.2: gs_bin_strips, round 6).  A consumer
  * compiled against another header must refuse the library instead of calling through shifted arguments:
  * opensplat_amd/cabi.py and libgsplat_torch.so compare gs_version() with this constant when they load. */
-#define GS_ABI_VERSION 401
+#define GS_ABI_VERSION 402
 int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 
 /* ---------------------------------------------------------------------------------------------
@@ -219,6 +220,22 @@ int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, cons
                 const int32_t *list_stats /*host int32[2] {M, longest list} of an earlier frame,
                                             nullable: lets the launch skip empty size classes*/,
                 void *workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* The same lists as gs_bin_scan + gs_bin_sort through a two-level partition (round 6), in ONE call and without a
+ * host synchronisation: Gaussians -> strips of sixteen consecutive tiles of a tile row (32-byte records
+ * {depth key, id, rectangle, block-row table}, counted with one LDS atomic per strip) -> one workgroup per strip
+ * counts, scans and fills its sixteen tiles' segments -> the per-tile sorts.  No per-tile count pass over the
+ * Gaussians, no scan launch.  Same contract as the pair it replaces: tile_bins[tiles,2] tile-major and
+ * contiguous, lists ordered by (depth, id), block_masks, tile_order (tiles by descending list length, in
+ * steps of eight entries), {M, longest list} to num_isects_host (pinned, nullable; [0] is stored by the second
+ * kernel, [1] by the last one) and M on the device at gs_bin_num_isects_offset; `capacity` may be a guess
+ * (slots beyond it are never written, tile_bins is clamped).  Images of more than 8192 strips (beyond
+ * 7680 x 4320) take the tile-level kernels inside the same call.  Workspace: gs_bin_workspace_bytes. */
+int gs_bin_strips(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                  int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks /*[capacity]*/,
+                  int32_t *tile_order /*[tiles]*/, int32_t *num_isects_host /*pinned host int32[2], nullable*/,
+                  const int32_t *list_stats /*host int32[2] of an earlier frame, nullable*/, void *workspace,
+                  size_t workspace_bytes, gs_stream_t stream);
 
 /* Coverage masks of a sorted list: block_masks[i], bit 4 r + c set <=> list entry i (Gaussian
  * gaussian_ids_sorted[i] in the tile whose segment holds i) can reach the 4x4-pixel block at block

@@ -244,6 +244,29 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
     return v;
 }
 
+// ---- the order the compositing launches start their tiles in ---------------------------------------
+// Longest lists first ("longest processing time first": evens out the end of the launches) — but only to
+// classes of sixteen entries, and INSIDE a class the tiles are scattered over the image: tile j of the
+// sequence i(j) = j * mult mod tiles (mult ~ 0.618 tiles, coprime to tiles) is visited j-th, so tiles that
+// start together are far apart.  Measured (scripts/exp_tile_order.py, profiles/exp_tile_order_r06_*.json):
+// with the exact order of rounds 2 - 5 (ties in the arrival order of contiguous slices: neighbouring tiles
+// next to each other) the C2 compositing kernels take 174 / 273 us, with tiles of a strip side by side
+// 198 / 298 us, with this order 162 / 237 us — neighbouring tiles gather the same Gaussians' lines and add to
+// the same gradient records at the same time.  Scheduling only.
+__device__ __forceinline__ int order_shift(int longest) {
+    int shift = 4;
+    while ((longest >> shift) >= 1024) shift++;
+    return shift;
+}
+__device__ __forceinline__ int order_first(int t, int tiles, int mult) {
+    return (int)(((int64_t)t * mult) % tiles);
+}
+__device__ __forceinline__ int order_next(int i, int tiles, int mult) {   // i(j + 1024) from i(j)
+    const int step = (int)(((int64_t)1024 * mult) % tiles);
+    i += step;
+    return i >= tiles ? i - tiles : i;
+}
+
 // The scan for images whose counters fit in LDS (up to 36 864 tiles) — the usual case.  One 1024-thread
 // workgroup sits between two launches that fill the chip, so what counts is its LATENCY: every thread
 // reads its contiguous slice of counters straight from global memory (a wave's slices are contiguous:
@@ -251,7 +274,7 @@ __device__ __forceinline__ int wave_inclusive_scan_i(int v) {
 // sort for the longest-first tile order reuses the same pattern: five barriers in all (the general
 // kernel below: a dozen, plus a Hillis-Steele loop of shuffles) — 14 -> ~6 us at 1080p.
 __global__ void __launch_bounds__(1024)
-k_scan_tiles_fast(int tiles, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
                   int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
                   int32_t *__restrict__ order) {
     extern __shared__ int32_t c_lds[];
@@ -296,10 +319,11 @@ k_scan_tiles_fast(int tiles, const int32_t *__restrict__ counts, int2 *__restric
         }
     }
     if (!order) return;
-    // tiles by descending list length (counting sort on min(n >> shift, 1023), bucket 0 = longest)
-    int shift = 0;
-    while ((longest_all >> shift) >= 1024) shift++;
-    for (int i = lo; i < hi; i++) atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1);
+    // tiles by descending list length in classes of (at least) sixteen entries, scattered over the image inside a
+    // class (order_classes below): counting sort on min(n >> shift, 1023), bucket 0 = longest
+    const int shift = order_shift(longest_all);
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1);
     __syncthreads();
     const int32_t own = part[t];
     const int32_t incl2 = wave_inclusive_scan_i(own);
@@ -310,11 +334,12 @@ k_scan_tiles_fast(int tiles, const int32_t *__restrict__ counts, int2 *__restric
     for (int w = 0; w < 16; w++) base2 += w < wave ? psum[w] : 0;
     part[t] = base2 + incl2 - own;
     __syncthreads();
-    for (int i = lo; i < hi; i++) order[atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1)] = i;
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        order[atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1)] = i;
 }
 
 __global__ void __launch_bounds__(1024)
-k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+k_scan_tiles(int tiles, int use_lds, int order_mult, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
              int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
              int32_t *__restrict__ order) {
     extern __shared__ int32_t c_lds[];
@@ -366,8 +391,7 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
     if (order) {
         __syncthreads();
         const int32_t longest_all = s_longest;
-        int shift = 0;
-        while ((longest_all >> shift) >= 1024) shift++;
+        const int shift = order_shift(longest_all);
         part[t] = 0;
         __syncthreads();
         // list length of tile i: from the exclusive starts still in LDS (no global read-back)
@@ -376,14 +400,14 @@ k_scan_tiles(int tiles, int use_lds, const int32_t *__restrict__ counts, int2 *_
             const int32_t st = c_lds[skew(i)];
             return ((i + 1 < tiles) ? c_lds[skew(i + 1)] : total_keep) - st;
         };
-        for (int i = t; i < tiles; i += 1024)
+        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
             atomicAdd(&part[1023 - (length(i) >> shift)], 1);  // bucket 0 = longest lists
         __syncthreads();
         const int32_t own = part[t];
         const int32_t first = block_scan_1024(own, ws) - own;
         part[t] = first;
         __syncthreads();
-        for (int i = t; i < tiles; i += 1024)
+        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
             order[atomicAdd(&part[1023 - (length(i) >> shift)], 1)] = i;
     }
     if (t == 1023) {
@@ -650,6 +674,12 @@ __device__ __forceinline__ void sort_in_global(uint4 *__restrict__ recs, int n, 
     }
 }
 
+// what the strip binning hands to the last per-tile sort launch (null for the tile-level path)
+struct StripOrder {
+    const int32_t *longest;   // device: longest list of the frame
+    int32_t *stats_host;      // pinned {M, longest list}, nullable
+};
+
 // ---- 4b. bucket sort ---------------------------------------------------------------------------
 // The keys of one tile are (nearly) uniformly spread between the tile's nearest and farthest
 // Gaussian, so a counting sort on the leading bits of (depth key - min) puts almost every key in
@@ -800,7 +830,7 @@ template <int PL, int B>
 __global__ void __launch_bounds__(64)
 k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
                    int2 *__restrict__ bins, uint4 *__restrict__ keys,
-                   int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks) {
+                   int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks, StripOrder so) {
     constexpr int CAP = 64 * PL, PER = B / 64;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
@@ -808,6 +838,9 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
+    // strip binning: the frame's longest list goes to the host with the last launch (the tile-level path's
+    // scan kernel stores it itself)
+    if (so.stats_host && blockIdx.x == 0 && threadIdx.x == 0) so.stats_host[1] = *so.longest;
     // capacity overflow (the caller sized the id list from a stale count): make the ranges safe to
     // walk — the compositing kernels then read inside the buffer; the caller detects the overflow
     // from the true total and repeats the call
@@ -918,6 +951,320 @@ k_block_masks(int tiles_x, const int2 *__restrict__ bins, const int32_t *__restr
     }
 }
 
+// ---- 6. strip binning (round 6) -------------------------------------------------------------------
+// The same lists through a two-level partition, without a per-tile count pass over the Gaussians and
+// without the 256 x tiles offset table:
+//   a. k_cell_count     one lane per Gaussian counts, per STRIP (kStripTiles = 16 consecutive tiles of
+//                       one tile row — "cell"), how many of its rectangles reach the strip (entries) and
+//                       how many tiles of the strip they cover (intersections): 544 pairs of counters at
+//                       1080p instead of 8160 tile counters, one 64-bit LDS atomic per (Gaussian, strip);
+//   b. k_cell_scatter   every workgroup scans the strip counters itself (no scan launch), then one lane
+//                       per Gaussian forms the Gaussian's block-row table ONCE and appends a 32-byte
+//                       record {depth key, id, rectangle | row table} to each strip it reaches: 1.5
+//                       records per Gaussian at C2 (2.15 tile intersections), 2.1 at C3 (3.8), each a
+//                       full 32-byte sector;
+//   c. k_strip_scatter  one workgroup per strip reads the strip's records ONCE, coalesced; counts its
+//                       sixteen tiles with ballots, scans them (tile_bins: the strip's segment starts at
+//                       the scanned intersection count of the strips before it — strips of a row are
+//                       sixteen consecutive tiles, so the list stays tile-major), and writes the 16-byte
+//                       {depth key, id, mask} records of the per-tile sort into the tiles' segments: a
+//                       68-KiB window of memory per strip, written by one workgroup in one go, which the
+//                       L2 merges into full lines (the Gaussian-major scatter opened a line per store);
+//   d. the per-tile bucket sorts of section 4, unchanged.
+// A rectangle is clipped to the strip by tile index alone, so the records carry no strip coordinates.
+constexpr int kStripTiles = 16;
+constexpr int kStripShift = 4;
+// strips whose counters (8 B) and cursors fit the LDS of the persistent kernels comfortably: 8192 strips =
+// a 7680 x 4320 frame; larger images take the tile-level path above
+constexpr int kMaxCells = 8192;
+
+// Visit every strip of every Gaussian of this wave's 64-lane slice: f(cell, payload lane).  Rectangles
+// reaching up to kLaneTiles strips are walked by their own lane (src = the lane itself), larger ones by
+// the whole wave (src = the owning lane: the caller broadcasts what it needs with readlane).
+template <typename F>
+__device__ __forceinline__ void for_each_cell(const TileRect &r, bool valid, int cells_x, F f) {
+    const int lane = threadIdx.x & 63;
+    const int cx0 = r.tx0 >> kStripShift;
+    const int cw = (valid && r.count() > 0) ? (((r.tx1 - 1) >> kStripShift) - cx0 + 1) : 0;
+    const int cnt = cw * (r.ty1 - r.ty0);
+    if (cnt > 0 && cnt <= kLaneTiles) {
+        for (int ty = r.ty0; ty < r.ty1; ty++)
+            for (int c = 0; c < cw; c++) f(ty * cells_x + cx0 + c, lane, false);
+    }
+    uint64_t big = __builtin_amdgcn_ballot_w64(cnt > kLaneTiles);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bcx0 = __builtin_amdgcn_readlane(cx0, src), bcw = __builtin_amdgcn_readlane(cw, src);
+        const int bty0 = __builtin_amdgcn_readlane(r.ty0, src);
+        const int total = __builtin_amdgcn_readlane(cnt, src);
+        for (int i = lane; i < total; i += 64) f((bty0 + i / bcw) * cells_x + bcx0 + i % bcw, src, true);
+    }
+}
+// tiles of the rectangle [tx0, tx1) inside strip column cx
+__device__ __forceinline__ int tiles_in_strip(int tx0, int tx1, int cx) {
+    return min(tx1, (cx + 1) << kStripShift) - max(tx0, cx << kStripShift);
+}
+
+// a. counters: low word = records (entries), high word = tile intersections.  wg_base[workgroup][cell] =
+// where this workgroup's records start inside the strip's list (the value the flush's returning atomic
+// hands back), exactly as k_count_tiles does per tile.
+__global__ void __launch_bounds__(kPersistentThreads)
+k_cell_count(int N, int cells, int cells_x, const float4 *__restrict__ packed,
+             unsigned long long *__restrict__ counts, int32_t *__restrict__ wg_base) {
+    extern __shared__ unsigned long long hc[];
+    const int stride = (blockDim.x >> 6) * gridDim.x, lane = threadIdx.x & 63;
+    int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    auto request = [&](int ch, uint32_t &rx, uint32_t &ry) {
+        const int64_t n = (int64_t)ch * 64 + lane;
+        const bool ok = n < N;
+        rx = ok ? __float_as_uint(packed[3 * (size_t)n + 1].w) : 0u;
+        ry = ok ? __float_as_uint(packed[3 * (size_t)n + 2].w) : 0u;
+        return ok;
+    };
+    uint32_t rx, ry;
+    bool valid = request(chunk, rx, ry);
+    for (int t = threadIdx.x; t < cells; t += blockDim.x) hc[t] = 0ull;
+    __syncthreads();
+    for (; (int64_t)chunk * 64 < N; chunk += stride) {
+        uint32_t nrx, nry;
+        const bool nvalid = request(chunk + stride, nrx, nry);
+        const TileRect r = tile_rect_of(rx, ry);
+        for_each_cell(r, valid, cells_x, [&](int cell, int src, bool bcast) {
+            const int tx0 = bcast ? __builtin_amdgcn_readlane(r.tx0, src) : r.tx0;
+            const int tx1 = bcast ? __builtin_amdgcn_readlane(r.tx1, src) : r.tx1;
+            const int nt = tiles_in_strip(tx0, tx1, cell % cells_x);
+            atomicAdd(&hc[cell], 1ull | ((unsigned long long)nt << 32));
+        });
+        rx = nrx; ry = nry; valid = nvalid;
+    }
+    __syncthreads();
+    int32_t *my_base = wg_base + (size_t)blockIdx.x * cells;
+    const int step = (int)blockDim.x;
+    for (int t0 = threadIdx.x; t0 < cells; t0 += 4 * step) {
+        unsigned long long c[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = t0 + j * step < cells ? hc[t0 + j * step] : 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = c[j] ? atomicAdd(&counts[t0 + j * step], c[j]) : 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (t0 + j * step < cells) my_base[t0 + j * step] = (int32_t)(uint32_t)b[j];
+    }
+}
+
+// b. cell_bins[cell] = {first record, records, first intersection, intersections}.  Records are 32 bytes
+// {depth key, id, rectangle x, rectangle y | row table r0..r3}, stored as two adjacent 16-byte halves: one
+// full sector, and ONE open cache line per (workgroup, strip) — with the halves in two arrays the lines a
+// workgroup keeps open (2 x strips x 128 B) no longer fitted the XCD's L2 next to its 31 neighbours'.
+struct StripRec {
+    uint4 a, b;
+};
+__global__ void __launch_bounds__(kPersistentThreads)
+k_cell_scatter(int N, int cells, int cells_x, int32_t capacity,
+               const float4 *__restrict__ packed, const float *__restrict__ depths,
+               const unsigned long long *__restrict__ counts, const int32_t *__restrict__ wg_base,
+               int4 *__restrict__ cell_bins, int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
+               StripRec *__restrict__ recs) {
+    extern __shared__ int32_t h[];              // the workgroup's cursor of every strip
+    __shared__ int32_t ws[17];
+    const int t = threadIdx.x;
+    const int per = (cells + 1023) / 1024;
+    const int lo = min(t * per, cells), hi = min(lo + per, cells);
+    const int32_t *my_base = wg_base + (size_t)blockIdx.x * cells;
+    const int stride = (blockDim.x >> 6) * gridDim.x, lane = threadIdx.x & 63;
+    int chunk = (threadIdx.x >> 6) * gridDim.x + blockIdx.x;
+    ScatterIn in = scatter_request(packed, depths, chunk * 64 + lane, (int64_t)chunk * 64 + lane < N);
+    {   // exclusive scan of the strip counters (records and intersections), by every workgroup for itself
+        int32_t se = 0, si = 0;
+        for (int i = lo; i < hi; i++) {
+            const unsigned long long c = counts[i];
+            se += (int32_t)(uint32_t)c;
+            si += (int32_t)(uint32_t)(c >> 32);
+        }
+        int32_t re = block_scan_1024(se, ws) - se;
+        const int32_t incl_i = block_scan_1024(si, ws);
+        int32_t ri = incl_i - si;
+        const int32_t total_i = ws[16];
+        for (int i = lo; i < hi; i++) {
+            const unsigned long long c = counts[i];
+            const int32_t ce = (int32_t)(uint32_t)c, ci = (int32_t)(uint32_t)(c >> 32);
+            h[i] = re + my_base[i];
+            if (blockIdx.x == 0) cell_bins[i] = make_int4(re, ce, ri, ci);
+            re += ce;
+            ri += ci;
+        }
+        if (blockIdx.x == 0 && t == 1023) {
+            *total_dev = total_i;
+            if (total_host) total_host[0] = total_i;   // pinned, device-mapped
+        }
+    }
+    __syncthreads();
+    for (; (int64_t)chunk * 64 < N; chunk += stride) {
+        const int n = chunk * 64 + lane;
+        const int64_t nn = (int64_t)n + (int64_t)stride * 64;
+        const ScatterIn next = scatter_request(packed, depths, (int)(nn < N ? nn : 0), nn < N);
+        TileRect r = {0, 0, 0, 0};
+        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu, 0x0F0F0F0Fu);
+        if (in.valid) {
+            a.z = __float_as_uint(in.p1.w);
+            a.w = __float_as_uint(in.p2w);
+            r = tile_rect_of(a.z, a.w);
+            uint32_t db = __float_as_uint(in.depth);
+            a.x = (db & 0x80000000u) ? ~db : (db | 0x80000000u);
+            a.y = (uint32_t)n;
+        }
+        const bool any = in.valid && r.count() > 0;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+            if (any) {
+                const RowTable w = block_rows_table(in.p0.x, in.p0.y, in.p0.z, in.p0.w, in.p1.x,
+                                                    __float_as_uint(in.p1.z), a.z, a.w);
+                b = make_uint4(w.r0, w.r1, w.r2, w.r3);   // (base follows from the rectangle)
+            }
+        }
+        for_each_cell(r, in.valid, cells_x, [&](int cell, int src, bool bcast) {
+            uint4 ra = a, rb = b;
+            if (bcast) {
+#define GS_BC(v) (uint32_t) __builtin_amdgcn_readlane((int)(v), src)
+                ra = make_uint4(GS_BC(a.x), GS_BC(a.y), GS_BC(a.z), GS_BC(a.w));
+                rb = make_uint4(GS_BC(b.x), GS_BC(b.y), GS_BC(b.z), GS_BC(b.w));
+#undef GS_BC
+            }
+            const int pos = atomicAdd(&h[cell], 1);
+            if (pos < capacity) {
+                recs[pos].a = ra;
+                recs[pos].b = rb;
+            }
+        });
+        in = next;
+    }
+}
+
+// the row table a strip record carries: its base follows from the rectangle, as block_rows_table sets it
+__device__ __forceinline__ RowTable row_table_of(const uint4 a, const uint4 b) {
+    const int x0 = (int)(a.z & 0xFFFFu), x1 = (int)(a.z >> 16) - 1;
+    const int y0 = (int)(a.w & 0xFFFFu), y1 = (int)(a.w >> 16) - 1;
+    RowTable w = {kNoRowTable, b.x, b.y, b.z, b.w};
+    if (x1 < x0 || y1 < y0) return w;
+    const int br0 = y0 >> 2, br1 = y1 >> 2, bc0 = x0 >> 2, bc1 = x1 >> 2;
+    if (br1 - br0 >= kRowTableRows || bc1 - bc0 >= 16) return w;
+    w.base = (uint32_t)br0 | ((uint32_t)bc0 << 16);
+    return w;
+}
+
+// c. one workgroup per strip.
+__global__ void __launch_bounds__(kPersistentThreads)
+k_strip_scatter(int cells_x, int tiles_x, int32_t capacity, const int4 *__restrict__ cell_bins,
+                const StripRec *__restrict__ recs, const float4 *__restrict__ packed,
+                uint4 *__restrict__ keys, int2 *__restrict__ bins, int32_t *__restrict__ longest) {
+    __shared__ int32_t cnt[kStripTiles], cur[kStripTiles];
+    const int cell = blockIdx.x, ty = cell / cells_x, cx = cell % cells_x;
+    const int tile0 = cx << kStripShift, nt = min(tiles_x - tile0, kStripTiles);
+    const int4 cb = cell_bins[cell];
+    const int es = min(cb.x, capacity), en = min(cb.x + cb.y, capacity) - es;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < kStripTiles) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // span of a record inside the strip: tiles [ta, tb], strip-local
+    auto span = [&](uint32_t rx, int &ta, int &tb) {
+        const int x0 = (int)(rx & 0xFFFFu), x1 = (int)(rx >> 16);
+        ta = max(x0 / GS_TILE, tile0) - tile0;
+        tb = min((x1 + GS_TILE - 1) / GS_TILE, tile0 + nt) - 1 - tile0;
+    };
+    {   // 1. tile counts: sixteen ballots per 64 records, the wave's totals into LDS once
+        int32_t c = 0;   // lane t < 16 keeps the wave's count of tile t
+        for (int base = (threadIdx.x >> 6) * 64; base < en; base += (int)blockDim.x) {
+            const int i = base + lane;
+            int ta = 1, tb = 0;
+            if (i < en) span(recs[es + i].a.z, ta, tb);
+#pragma unroll
+            for (int t = 0; t < kStripTiles; t++) {
+                const int k = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ta <= t && t <= tb));
+                c += lane == t ? k : 0;
+            }
+        }
+        if (lane < kStripTiles && c) atomicAdd(&cnt[lane], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < kStripTiles) {
+        const int t = threadIdx.x;
+        const int32_t len = cnt[t];
+        int32_t start = cb.z, mx = 0;
+        for (int j = 0; j < kStripTiles; j++) {
+            const int32_t cj = cnt[j];
+            start += j < t ? cj : 0;
+            mx = max(mx, cj);
+        }
+        cur[t] = start;
+        if (t < nt) bins[ty * tiles_x + tile0 + t] = make_int2(start, start + len);
+        // (a plain read first: the maximum only grows, a stale value costs an atomic, never a miss)
+        if (t == 0 && mx > *longest) atomicMax(longest, mx);
+    }
+    __syncthreads();
+    // 2. the records of the per-tile sort
+    for (int base = (threadIdx.x >> 6) * 64; base < en; base += (int)blockDim.x) {
+        const int i = base + lane;
+        if (i >= en) continue;
+        const uint4 a = recs[es + i].a, b = recs[es + i].b;
+        int ta, tb;
+        span(a.z, ta, tb);
+        const RowTable w = row_table_of(a, b);
+        for (int t = ta; t <= tb; t++) {
+            uint32_t m;
+            if (w.base != kNoRowTable) {
+                m = mask_from_rows(w, tile0 + t, ty);
+            } else {
+                const float4 p0 = packed[3 * (size_t)a.y + 0], p1 = packed[3 * (size_t)a.y + 1];
+                m = block_mask16(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z), a.z, a.w,
+                                 (tile0 + t) * GS_TILE, ty * GS_TILE);
+            }
+            const int pos = atomicAdd(&cur[t], 1);
+            if (pos < capacity) keys[pos] = make_uint4(a.x, a.y, m, 0u);
+        }
+    }
+}
+
+// the same order from finished tile_bins (strip binning: the tile counts only exist once the strips have been
+// split): one 1024-thread workgroup, list lengths in LDS when they fit
+__global__ void __launch_bounds__(1024)
+k_tile_order(int tiles, int use_lds, int order_mult, const int2 *__restrict__ bins,
+             const int32_t *__restrict__ longest, int32_t *__restrict__ order) {
+    extern __shared__ int32_t len_lds[];
+    __shared__ int32_t part[1024];
+    __shared__ int32_t ws[17];
+    const int t = threadIdx.x;
+    if (use_lds)
+        for (int i = t; i < tiles; i += 1024) {
+            const int2 b = bins[i];
+            len_lds[i] = b.y - b.x;
+        }
+    part[t] = 0;
+    const int shift = order_shift(*longest);
+    __syncthreads();
+    auto length = [&](int i) -> int32_t {
+        if (use_lds) return len_lds[i];
+        const int2 b = bins[i];
+        return b.y - b.x;
+    };
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        atomicAdd(&part[1023 - min(length(i) >> shift, 1023)], 1);
+    __syncthreads();
+    const int32_t own = part[t];
+    const int32_t first = block_scan_1024(own, ws) - own;
+    part[t] = first;
+    __syncthreads();
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        order[atomicAdd(&part[1023 - min(length(i) >> shift, 1023)], 1)] = i;
+}
+
+// mult of the scattered tile sequence (order_first / order_next): ~0.618 tiles, coprime to tiles
+static int order_multiplier(int tiles) {
+    auto gcd = [](int a, int b) { while (b) { const int r = a % b; a = b; b = r; } return a; };
+    int m = (int)(tiles * 0.6180339887) | 1;
+    while (gcd(m, tiles) != 1) m += 2;
+    return m;
+}
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // LDS budget of the privatised count / scatter kernels (the CU has 160 KiB) and their grid: one
@@ -934,6 +1281,10 @@ static int persistent_blocks(int N) {
 // THE SAME WORKSPACE (the offsets of the key array move with the capacity, wg_base does not).
 struct BinLayout {
     size_t counters, total_dev, wg_base, keys, total;
+    // strip binning (section 6): [ strip counters u64 x cells | longest list ] is one zeroed block; cell_bins
+    // int4 x cells; cell_base 256 x cells i32; recs: capacity x 32 B behind the keys
+    size_t cell_counts, longest, zero_bytes, cell_bins, cell_base, recs;
+    int cells_x, cells;   // cells = 0: the image has too many strips, tile-level path only
 };
 // What gs_bin_scan remembers (on the host, per workspace address) so that gs_bin_sort can tell that the
 // workspace it is handed holds the scan's leftovers — the per-workgroup offsets — for the same
@@ -973,9 +1324,88 @@ static BinLayout bin_layout(int N, int64_t capacity, int W, int H) {
     L.wg_base = L.total_dev + 256;
     // per-(workgroup, tile) offsets handed from the count to the scatter kernel (LDS variants only)
     const size_t base_bytes = tiles * 4 <= kMaxTileLds ? align_up((size_t)256 * tiles * 4) : 0;
-    L.keys = L.wg_base + base_bytes;
-    L.total = L.keys + align_up((size_t)(capacity > 0 ? capacity : 1) * 16) + 256;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    L.cells_x = (tiles_x + kStripTiles - 1) / kStripTiles;
+    L.cells = (size_t)L.cells_x * tiles_y <= (size_t)kMaxCells ? L.cells_x * tiles_y : 0;
+    L.cell_counts = L.wg_base + base_bytes;
+    L.longest = L.cell_counts + align_up((size_t)L.cells * 8);
+    L.zero_bytes = L.longest + 256 - L.cell_counts;
+    L.cell_bins = L.longest + 256;
+    L.cell_base = L.cell_bins + align_up((size_t)L.cells * 16);
+    L.keys = L.cell_base + align_up((size_t)256 * L.cells * 4);
+    const size_t cap_bytes = align_up((size_t)(capacity > 0 ? capacity : 1) * 16);
+    L.recs = L.keys + cap_bytes + 256;
+    L.total = L.recs + (L.cells ? 2 * cap_bytes : 0) + 256;
     return L;
+}
+
+// The per-tile sorts of section 4 over every tile's segment of `keys`: which size classes are launched follows
+// the previous frame's statistics.  `so`: the strip binning's statistics hand-off, done by the launch that
+// visits every tile (always the last one).
+static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_stats, int2 *bins_rw,
+                             uint4 *keys, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                             StripOrder so, hipStream_t s) {
+    const int2 *bins = bins_rw;
+    const StripOrder none{nullptr, nullptr};
+    // Every class also moves the coverage masks (third word of the records) along with the keys.
+    // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
+    // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
+    // longer: in place in global memory.
+    // Which classes are launched follows the PREVIOUS frame's statistics (list_stats = {M, longest
+    // list}); a launch over all tiles that finds nothing to do still costs its dispatch (39 us for the
+    // 256-thread class at 4K).  Whatever is launched last-in-class takes any longer segment itself (in
+    // place in global memory: slow, correct, and only on the frame where a list first outgrows the guess).
+    //   longest <= 400:              the 512 class alone
+    //   longest <= 900:              no 8192 class; lists mostly beyond 512 (mean > 300): the 1024 class
+    //                                alone, for every segment
+    //   otherwise / no statistics:   all three
+    //   at most 1024 tiles (launch-bound): longest <= 900 -> the 1024 class alone; beyond -> 8192 + 1024 classes
+    const bool have_stats = list_stats && list_stats[0] > 0;
+    const bool only_short = have_stats && list_stats[1] <= 400;
+    const bool no_long = have_stats && list_stats[1] <= 900;
+    // (a frame of few tiles is bound by the launches, not by the sorting: one launch of the wider class —
+    // 6000 Gaussians at 384x288: 23 us instead of 23 + 18)
+    const bool only_mid = no_long && !only_short &&
+                          ((int64_t)list_stats[0] > 300 * (int64_t)tiles || tiles <= 1024);
+    if (only_mid) {
+        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
+                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+        GS_LAUNCH_CHECK();
+        return GS_OK;
+    }
+    // few tiles, long lists: the 8192 class for what is beyond 1024 keys and the 1024 class for everything else
+    // (20 000 Gaussians at 384x288: 30 + 28 + 19 us with the 512 class as a third launch)
+    const bool few_long = have_stats && !no_long && tiles <= 1024;
+    // (Launching the classes side by side on helper streams — they work on disjoint tiles, every class clamps the
+    // ranges it reads by `capacity` itself — was built and measured in round 5: each launch got slower by what it
+    // shared, the stage 0.233 -> 0.251 ms on the hot-spot scene.  In a row.)
+    if (!only_short && !few_long) {
+        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks, none);
+        GS_LAUNCH_CHECK();
+    }
+    if (!no_long) {
+        // 1024 threads per tile: the few tiles of this class are latency chains of one workgroup each —
+        // with 256 threads 77 us for the nine 5 - 8 k-entry lists of the hot-spot scene, 36 us with 1024
+        // (bin_sort 0.272 -> 0.233 ms there)
+        constexpr int CAP = 8192, B = 4096, NT = 1024;
+        const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
+        GS_HIP_CHECK(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(k_bucket_sort_tiles<CAP, B, NT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GS_LAUNCH((k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
+                           CAP, capacity, bins, keys, gaussian_ids_sorted, block_masks);
+        GS_LAUNCH_CHECK();
+    }
+    // (the short class last: it also clamps overflowing ranges, after the others have read them)
+    if (few_long)
+        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
+                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+    else
+        GS_LAUNCH((k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+                           1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
 }
 
 }  // namespace gs
@@ -1052,10 +1482,10 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)gs::kMaxTileLds));
         if (use_lds)
-            GS_LAUNCH(gs::k_scan_tiles_fast, dim3(1), dim3(1024), lds, s, tiles, counts,
+            GS_LAUNCH(gs::k_scan_tiles_fast, dim3(1), dim3(1024), lds, s, tiles, gs::order_multiplier(tiles), counts,
                                reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
         else
-            GS_LAUNCH(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, 0, counts,
+            GS_LAUNCH(gs::k_scan_tiles, dim3(1), dim3(1024), 0, s, tiles, 0, gs::order_multiplier(tiles), counts,
                                reinterpret_cast<int2 *>(tile_bins), total_dev, num_isects_host, tile_order);
     }
     GS_LAUNCH_CHECK();
@@ -1118,66 +1548,71 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
                            keys);
     }
     GS_LAUNCH_CHECK();
-    int2 *bins_rw = reinterpret_cast<int2 *>(tile_bins);
-    // Every class also moves the coverage masks (third word of the records) along with the keys.
-    // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
-    // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
-    // longer: in place in global memory.
-    // Which classes are launched follows the PREVIOUS frame's statistics (list_stats = {M, longest
-    // list}); a launch over all tiles that finds nothing to do still costs its dispatch (39 us for the
-    // 256-thread class at 4K).  Whatever is launched last-in-class takes any longer segment itself (in
-    // place in global memory: slow, correct, and only on the frame where a list first outgrows the guess).
-    //   longest <= 400:              the 512 class alone
-    //   longest <= 900:              no 8192 class; lists mostly beyond 512 (mean > 300): the 1024 class
-    //                                alone, for every segment
-    //   otherwise / no statistics:   all three
-    //   at most 1024 tiles (launch-bound): longest <= 900 -> the 1024 class alone; beyond -> 8192 + 1024 classes
-    const bool have_stats = list_stats && list_stats[0] > 0;
-    const bool only_short = have_stats && list_stats[1] <= 400;
-    const bool no_long = have_stats && list_stats[1] <= 900;
-    // (a frame of few tiles is bound by the launches, not by the sorting: one launch of the wider class —
-    // 6000 Gaussians at 384x288: 23 us instead of 23 + 18)
-    const bool only_mid = no_long && !only_short &&
-                          ((int64_t)list_stats[0] > 300 * (int64_t)tiles || tiles <= 1024);
-    if (only_mid) {
-        GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
-                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
-        GS_LAUNCH_CHECK();
-        return GS_OK;
+    return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
+                                 gaussian_ids_sorted, block_masks, gs::StripOrder{nullptr, nullptr}, s);
+}
+
+extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float *packed,
+                             const float *depths, int32_t *tile_bins, int32_t *gaussian_ids_sorted,
+                             uint16_t *block_masks, int32_t *tile_order, int32_t *num_isects_host,
+                             const int32_t *list_stats, void *workspace, size_t workspace_bytes,
+                             gs_stream_t stream) {
+    GS_TRACE("gs_bin_strips");
+    if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (!tile_bins || !workspace || !tile_order) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)workspace & 15u) return GS_ERR_INVALID_ARGUMENT;
+    if (N > 0 && (!packed || !depths)) return GS_ERR_INVALID_ARGUMENT;
+    if (capacity > 0 && (!gaussian_ids_sorted || !block_masks)) return GS_ERR_INVALID_ARGUMENT;
+    const gs::BinLayout L = gs::bin_layout(N, capacity, W, H);
+    if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
+    if (L.cells == 0 || N == 0 || capacity == 0) {
+        // more strips than the persistent kernels keep in LDS (or nothing to sort): the tile-level path
+        int rc = gs_bin_scan(W, H, N, packed, tile_bins, tile_order, num_isects_host, workspace, workspace_bytes,
+                             stream);
+        if (rc != GS_OK) return rc;
+        return gs_bin_sort(W, H, N, capacity, packed, depths, tile_bins, gaussian_ids_sorted, block_masks,
+                           list_stats, workspace, workspace_bytes, stream);
     }
-    // few tiles, long lists: the 8192 class for what is beyond 1024 keys and the 1024 class for everything else
-    // (20 000 Gaussians at 384x288: 30 + 28 + 19 us with the 512 class as a third launch)
-    const bool few_long = have_stats && !no_long && tiles <= 1024;
-    // (Launching the classes side by side on helper streams — they work on disjoint tiles, every class clamps the
-    // ranges it reads by `capacity` itself — was built and measured in round 5: each launch got slower by what it
-    // shared, the stage 0.233 -> 0.251 ms on the hot-spot scene.  In a row.)
-    if (!only_short && !few_long) {
-        GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
-        GS_LAUNCH_CHECK();
-    }
-    if (!no_long) {
-        // 1024 threads per tile: the few tiles of this class are latency chains of one workgroup each —
-        // with 256 threads 77 us for the nine 5 - 8 k-entry lists of the hot-spot scene, 36 us with 1024
-        // (bin_sort 0.272 -> 0.233 ms there)
-        constexpr int CAP = 8192, B = 4096, NT = 1024;
-        const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
-        GS_HIP_CHECK(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GS_LAUNCH((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
-                           CAP, capacity, bins, keys, gaussian_ids_sorted, block_masks);
-        GS_LAUNCH_CHECK();
-    }
-    // (the short class last: it also clamps overflowing ranges, after the others have read them)
-    if (few_long)
-        GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
-                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
-    else
-        GS_LAUNCH((gs::k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                           1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    const int tiles = tiles_x * tiles_y;
+    char *base = static_cast<char *>(workspace);
+    auto *counts = reinterpret_cast<unsigned long long *>(base + L.cell_counts);
+    int32_t *longest = reinterpret_cast<int32_t *>(base + L.longest);
+    int4 *cell_bins = reinterpret_cast<int4 *>(base + L.cell_bins);
+    int32_t *cell_base = reinterpret_cast<int32_t *>(base + L.cell_base);
+    uint4 *keys = reinterpret_cast<uint4 *>(base + L.keys);
+    gs::StripRec *recs = reinterpret_cast<gs::StripRec *>(base + L.recs);
+    int32_t *total_dev = reinterpret_cast<int32_t *>(base + L.total_dev);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    gs::timeline_before(s);
+    GS_HIP_CHECK(hipMemsetAsync(base + L.cell_counts, 0, L.zero_bytes, s));
+    gs::timeline_after("memset(strip counters)", s);
+    const int blocks = gs::persistent_blocks(N);
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_cell_count),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, gs::kMaxCells * 8));
+    GS_LAUNCH(gs::k_cell_count, dim3(blocks), dim3(gs::kPersistentThreads), (size_t)L.cells * 8, s, N, L.cells,
+              L.cells_x, pk, counts, cell_base);
     GS_LAUNCH_CHECK();
-    return GS_OK;
+    GS_LAUNCH(gs::k_cell_scatter, dim3(blocks), dim3(gs::kPersistentThreads), (size_t)L.cells * 4, s, N, L.cells,
+              L.cells_x, capacity, pk, depths, counts, cell_base, cell_bins, total_dev, num_isects_host, recs);
+    GS_LAUNCH_CHECK();
+    GS_LAUNCH(gs::k_strip_scatter, dim3(L.cells), dim3(gs::kPersistentThreads), 0, s, L.cells_x, tiles_x, capacity,
+              cell_bins, recs, pk, keys, reinterpret_cast<int2 *>(tile_bins), longest);
+    GS_LAUNCH_CHECK();
+    {
+        const size_t lds = sizeof(int32_t) * (size_t)tiles;
+        const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
+        if (use_lds)
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_tile_order),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));
+        GS_LAUNCH(gs::k_tile_order, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
+                  gs::order_multiplier(tiles), reinterpret_cast<const int2 *>(tile_bins), longest, tile_order);
+        GS_LAUNCH_CHECK();
+    }
+    return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
+                                 gaussian_ids_sorted, block_masks, gs::StripOrder{longest, num_isects_host}, s);
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,

@@ -1,0 +1,176 @@
+"""-m gpu: the strip binning of round 6 (gs_bin_strips: Gaussians -> strips of sixteen tiles -> tiles) against
+the tile-level binning of rounds 1-5 (gs_bin_scan + gs_bin_sort) on the same packed records.
+
+Both end in the same per-tile sort on the unique (depth key, id) keys, so EVERYTHING must agree bit for bit:
+tile_bins (tile-major, contiguous), the id lists, the coverage masks, {M, longest list}.  The tile order of the
+compositing launches is made by different kernels from the same rule (longest lists first in classes of sixteen
+entries, scattered over the image inside a class): a permutation of the tiles with that property in both.  Replaces
+rasterize_gaussians.cpp:6-37 / forward.cu:107-169 (the global sort of (tile | depth) keys)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from opensplat_amd import scenes
+from tests.util import np_, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _packed(s):
+    """Packed records + depths of scene s through the stage kernels."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    cam = cabi.make_camera(s.viewmat, s.projmat, s.fx, s.fy, s.cx, s.cy, s.W, s.H)
+    p = cabi.project_forward(cam, to_dev(s.means), to_dev(s.scales), to_dev(s.quats))
+    colors = to_dev(s.colors) if s.sh_coeffs is None else torch.clamp_min(
+        cabi.sh_forward(s.degrees_to_use, to_dev(s.dirs), to_dev(s.sh_coeffs)) + 0.5, 0.0)
+    N = s.N
+    packed = torch.empty((N, 12), device="cuda", dtype=torch.float32)
+    tiles_hit = torch.empty((N,), device="cuda", dtype=torch.int32)
+    l = cabi.lib()
+    cabi._check(l.gs_pack_splats(C.c_int(s.W), C.c_int(s.H), C.c_int(N), cabi._p(p["xys"]), cabi._p(p["radii"]),
+                                 cabi._p(p["conics"]), cabi._p(colors), cabi._p(to_dev(s.opacities.reshape(-1))),
+                                 cabi._p(p["cov2d"]), cabi._p(packed), cabi._p(tiles_hit), C.c_uint32(0),
+                                 cabi._stream()), "gs_pack_splats")
+    return packed, p["depths"], tiles_hit
+
+
+def _bin(which, W, H, packed, depths, cap, list_stats=None):
+    import torch
+
+    from opensplat_amd import cabi
+
+    l = cabi.lib()
+    N = depths.shape[0]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    i32 = dict(device="cuda", dtype=torch.int32)
+    bins = torch.full((tiles, 2), -7, **i32)
+    order = torch.full((tiles,), -7, **i32)
+    ids = torch.full((max(cap, 1),), -7, **i32)
+    masks = torch.zeros((max(cap, 1),), device="cuda", dtype=torch.int16)
+    m_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+    nb = l.gs_bin_workspace_bytes(N, cap, W, H)
+    ws = torch.empty((nb,), device="cuda", dtype=torch.uint8)
+    ws.fill_(0xA5)     # whatever the allocator left there
+    stats = (C.c_int32 * 2)(*list_stats) if list_stats is not None else None
+    args = (C.c_int(W), C.c_int(H), C.c_int(N))
+    if which == "strips":
+        cabi._check(l.gs_bin_strips(*args, C.c_int32(cap), cabi._p(packed), cabi._p(depths), cabi._p(bins),
+                                    cabi._p(ids), cabi._p(masks), cabi._p(order), C.c_void_p(m_host.data_ptr()),
+                                    stats, cabi._p(ws), C.c_size_t(nb), cabi._stream()), "gs_bin_strips")
+    else:
+        cabi._check(l.gs_bin_scan(*args, cabi._p(packed), cabi._p(bins), cabi._p(order),
+                                  C.c_void_p(m_host.data_ptr()), cabi._p(ws), C.c_size_t(nb), cabi._stream()),
+                    "gs_bin_scan")
+        cabi._check(l.gs_bin_sort(*args, C.c_int32(cap), cabi._p(packed), cabi._p(depths), cabi._p(bins),
+                                  cabi._p(ids), cabi._p(masks), stats, cabi._p(ws), C.c_size_t(nb),
+                                  cabi._stream()), "gs_bin_sort")
+    torch.cuda.synchronize()
+    off = l.gs_bin_num_isects_offset(W, H)
+    m_dev = int(ws[off:off + 4].view(torch.int32)[0])
+    return dict(tiles_x=(W + 15) // 16, bins=np_(bins), order=np_(order), ids=np_(ids), masks=np_(masks).view(np.uint16),
+                M=int(m_host[0]), longest=int(m_host[1]), M_dev=m_dev)
+
+
+def _same_lists(a, b, tiles_hit):
+    M = a["M"]
+    assert M == b["M"] == a["M_dev"] == b["M_dev"] == int(np_(tiles_hit).sum())
+    assert a["longest"] == b["longest"] == int((b["bins"][:, 1] - b["bins"][:, 0]).max(initial=0))
+    assert np.array_equal(a["bins"], b["bins"])
+    assert np.array_equal(a["ids"][:M], b["ids"][:M])
+    assert np.array_equal(a["masks"][:M], b["masks"][:M])
+    lens = a["bins"][:, 1] - a["bins"][:, 0]
+    for r in (a, b):
+        assert np.array_equal(np.sort(r["order"]), np.arange(len(lens)))
+    # both: longest lists first in classes of (at least) sixteen entries — 1024 classes up to the longest list —
+    # and the tiles of a class scattered over the image (gs_bin.hip: order_shift / order_first)
+    shift = 4
+    while (int(lens.max(initial=0)) >> shift) >= 1024:
+        shift += 1
+    for r in (a, b):
+        assert (np.diff(lens[r["order"]] >> shift) <= 0).all()
+    if len(lens) >= 2048 and (lens > 0).mean() > 0.5:
+        # scattered: tiles that start next to each other are rarely neighbours in the image
+        tiles_x = a["tiles_x"]
+        o = a["order"]
+        dx, dy = np.abs(np.diff(o % tiles_x)), np.abs(np.diff(o // tiles_x))
+        assert ((dx <= 1) & (dy <= 1)).mean() < 0.05
+
+
+SCENES = {
+    # (scene factory, comment)
+    "c2_200k": lambda: scenes.camera_scene(200_000, 1920, 1080, K=0, seed=1),
+    "ragged_1000x700": lambda: scenes.camera_scene(60_000, 1000, 700, K=0, seed=5, sigma_px=(0.5, 9.0)),
+    "one_strip_wide_250x40": lambda: scenes.camera_scene(3000, 250, 40, K=0, seed=6, sigma_px=(1.0, 12.0)),
+    "tiny_17x9": lambda: scenes.camera_scene(50, 17, 9, K=0, seed=7),
+    # rectangles far beyond 64 x 64 pixels (no row table; the whole wave walks their strips)
+    "huge_gaussians": lambda: scenes.camera_scene(1500, 1280, 720, K=0, seed=8, sigma_px=(20.0, 160.0)),
+    "c1": lambda: scenes.simple_trainer_scene(10_000, 256, 256, 0),
+    "4k_sparse": lambda: scenes.camera_scene(30_000, 3840, 2160, K=0, seed=9, sigma_px=(2.0, 30.0)),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_strips_give_the_tile_level_lists_bit_for_bit(name):
+    s = SCENES[name]()
+    packed, depths, tiles_hit = _packed(s)
+    M = int(np_(tiles_hit).sum())
+    a = _bin("strips", s.W, s.H, packed, depths, M + 100)
+    b = _bin("tiles", s.W, s.H, packed, depths, M + 100)
+    _same_lists(a, b, tiles_hit)
+    # the statistics of the frame itself (another choice of sort classes): the same lists again
+    c = _bin("strips", s.W, s.H, packed, depths, M, list_stats=(a["M"], a["longest"]))
+    _same_lists(c, b, tiles_hit)
+
+
+def test_strips_with_long_lists_and_tied_depths():
+    """Lists beyond 1024 and 8192 entries (the big sort classes) and many equal depths (ties in id order)."""
+    s = scenes.camera_scene(14_000, 40, 24, K=0, seed=31, znear=1.0, zfar=100.0, sigma_px=(3.0, 6.0))
+    packed, depths, tiles_hit = _packed(s)
+    depths = (depths * 4).round() / 4          # a handful of distinct depths
+    M = int(np_(tiles_hit).sum())
+    a = _bin("strips", s.W, s.H, packed, depths, M)
+    b = _bin("tiles", s.W, s.H, packed, depths, M)
+    assert a["longest"] > 8192
+    _same_lists(a, b, tiles_hit)
+    for stats in [(M, 300), (M, 800), (M, a["longest"])]:          # stale and exact statistics
+        _same_lists(_bin("strips", s.W, s.H, packed, depths, M, list_stats=stats), b, tiles_hit)
+
+
+def test_strips_survive_a_too_small_capacity():
+    """A capacity below M: nothing is written beyond it, the bins are clamped, M is still the true count."""
+    s = scenes.camera_scene(20_000, 320, 200, K=0, seed=61, znear=1.0, zfar=100.0)
+    packed, depths, tiles_hit = _packed(s)
+    M = int(np_(tiles_hit).sum())
+    cap = M // 3
+    assert cap > 4096
+    a = _bin("strips", s.W, s.H, packed, depths, cap)
+    assert a["M"] == a["M_dev"] == M
+    assert int(a["bins"].max()) <= cap and int(a["bins"].min()) >= 0
+    assert (a["bins"][:, 1] >= a["bins"][:, 0]).all()
+    # the strips that fit entirely are the true list's head (segments are filled strip by strip, tile-major)
+    b = _bin("tiles", s.W, s.H, packed, depths, M)
+    tiles_x = (s.W + 15) // 16
+    t = np.arange(len(b["bins"]))
+    strip_end = ((t % tiles_x) % 16 == 15) | (t % tiles_x == tiles_x - 1)
+    last = int(b["bins"][strip_end & (b["bins"][:, 1] <= cap), 1].max())
+    assert last > 0
+    assert np.array_equal(a["ids"][:last], b["ids"][:last])
+    assert np.array_equal(a["bins"][b["bins"][:, 1] <= last], b["bins"][b["bins"][:, 1] <= last])
+
+
+def test_strips_with_no_visible_gaussian_and_with_none():
+    import torch
+
+    s = scenes.camera_scene(500, 320, 200, K=0, seed=3)
+    packed, depths, tiles_hit = _packed(s)
+    packed[:, 7] = 0            # empty rectangles (x0 = x1 = 0)
+    a = _bin("strips", s.W, s.H, packed, depths, 64)
+    assert a["M"] == 0 and a["longest"] == 0 and not a["bins"].any()
+    assert np.array_equal(np.sort(a["order"]), np.arange(len(a["order"])))
+    e = torch.empty((0, 12), device="cuda"), torch.empty((0,), device="cuda")
+    a = _bin("strips", s.W, s.H, e[0], e[1], 64)
+    assert a["M"] == 0 and not a["bins"].any()
