@@ -261,8 +261,8 @@ __device__ __forceinline__ int order_shift(int longest) {
 __device__ __forceinline__ int order_first(int t, int tiles, int mult) {
     return (int)(((int64_t)t * mult) % tiles);
 }
-__device__ __forceinline__ int order_next(int i, int tiles, int mult) {   // i(j + 1024) from i(j)
-    const int step = (int)(((int64_t)1024 * mult) % tiles);
+__device__ __forceinline__ int order_step(int tiles, int mult) { return (int)(((int64_t)1024 * mult) % tiles); }
+__device__ __forceinline__ int order_next(int i, int tiles, int step) {   // i(j + 1024) from i(j)
     i += step;
     return i >= tiles ? i - tiles : i;
 }
@@ -321,8 +321,8 @@ k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts,
     if (!order) return;
     // tiles by descending list length in classes of (at least) sixteen entries, scattered over the image inside a
     // class (order_classes below): counting sort on min(n >> shift, 1023), bucket 0 = longest
-    const int shift = order_shift(longest_all);
-    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+    const int shift = order_shift(longest_all), ostep = order_step(tiles, order_mult);
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
         atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1);
     __syncthreads();
     const int32_t own = part[t];
@@ -334,7 +334,7 @@ k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts,
     for (int w = 0; w < 16; w++) base2 += w < wave ? psum[w] : 0;
     part[t] = base2 + incl2 - own;
     __syncthreads();
-    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
         order[atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1)] = i;
 }
 
@@ -391,7 +391,7 @@ k_scan_tiles(int tiles, int use_lds, int order_mult, const int32_t *__restrict__
     if (order) {
         __syncthreads();
         const int32_t longest_all = s_longest;
-        const int shift = order_shift(longest_all);
+        const int shift = order_shift(longest_all), ostep = order_step(tiles, order_mult);
         part[t] = 0;
         __syncthreads();
         // list length of tile i: from the exclusive starts still in LDS (no global read-back)
@@ -400,14 +400,14 @@ k_scan_tiles(int tiles, int use_lds, int order_mult, const int32_t *__restrict__
             const int32_t st = c_lds[skew(i)];
             return ((i + 1 < tiles) ? c_lds[skew(i + 1)] : total_keep) - st;
         };
-        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
             atomicAdd(&part[1023 - (length(i) >> shift)], 1);  // bucket 0 = longest lists
         __syncthreads();
         const int32_t own = part[t];
         const int32_t first = block_scan_1024(own, ws) - own;
         part[t] = first;
         __syncthreads();
-        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
+        for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
             order[atomicAdd(&part[1023 - (length(i) >> shift)], 1)] = i;
     }
     if (t == 1023) {
@@ -674,12 +674,6 @@ __device__ __forceinline__ void sort_in_global(uint4 *__restrict__ recs, int n, 
     }
 }
 
-// what the strip binning hands to the last per-tile sort launch (null for the tile-level path)
-struct StripOrder {
-    const int32_t *longest;   // device: longest list of the frame
-    int32_t *stats_host;      // pinned {M, longest list}, nullable
-};
-
 // ---- 4b. bucket sort ---------------------------------------------------------------------------
 // The keys of one tile are (nearly) uniformly spread between the tile's nearest and farthest
 // Gaussian, so a counting sort on the leading bits of (depth key - min) puts almost every key in
@@ -826,54 +820,15 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
 // into registers (PL per lane), bucket b is owned by lane b % 64 (conflict-free LDS access), the
 // exclusive scan is B/64 DPP wave scans.  LDS: 10*64*PL + 4*B bytes (7 KiB for PL = 8, B = 512),
 // so that many tiles are resident per CU and their global-memory round trips overlap.
+// The sort of one wave's n <= 64 * PL records held in registers (kk: (depth key << 32 | id), mm: the 16-bit
+// masks two to a register, slot j * 64 + lane; mn / mx: this lane's range of the depth keys) through the
+// wave's LDS buffers, written to ids_dst / masks_dst[0 .. n).
 template <int PL, int B>
-__global__ void __launch_bounds__(64)
-k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
-                   int2 *__restrict__ bins, uint4 *__restrict__ keys,
-                   int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks, StripOrder so) {
-    constexpr int CAP = 64 * PL, PER = B / 64;
-    __shared__ uint64_t out[CAP];
-    __shared__ int32_t cnt[B];
-    __shared__ uint16_t outm[CAP];
-    const int2 range = bins[blockIdx.x];
-    const int start = range.x;
-    const int n = min(range.y, capacity) - start;
-    // strip binning: the frame's longest list goes to the host with the last launch (the tile-level path's
-    // scan kernel stores it itself)
-    if (so.stats_host && blockIdx.x == 0 && threadIdx.x == 0) so.stats_host[1] = *so.longest;
-    // capacity overflow (the caller sized the id list from a stale count): make the ranges safe to
-    // walk — the compositing kernels then read inside the buffer; the caller detects the overflow
-    // from the true total and repeats the call
-    if (clamp_bins && range.y > capacity && threadIdx.x == 0)
-        bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
-    if (n <= lo_n) return;
-    const int lane = threadIdx.x;
-    if (n > hi_n) {
-        // a longer segment: normally another launch's job.  When the host skipped those launches
-        // (the previous frame had no long list) this wave sorts it in place in global memory —
-        // slow, but only ever hit on the frame where a list first outgrows this class.
-        if (!take_longer) return;
-        sort_in_global<64>(keys + start, n, lane, ids_sorted + start, masks + start);
-        return;
-    }
-    const uint4 *src = keys + start;
-    uint64_t kk[PL];
-    uint32_t mm[PL / 2];   // the 16-bit masks, two to a register
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-#pragma unroll
-    for (int j = 0; j < PL / 2; j++) mm[j] = 0u;
-#pragma unroll
-    for (int j = 0; j < PL; j++) {
-        const int i = j * 64 + lane;
-        uint4 r = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-        if (i < n) r = src[i];
-        kk[j] = rec_key(r);
-        mm[j >> 1] |= (r.z & 0xFFFFu) << (16 * (j & 1));
-        if (i < n) {
-            mn = min(mn, r.x);
-            mx = max(mx, r.x);
-        }
-    }
+__device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const uint32_t (&mm)[PL / 2],
+                                                 uint32_t mn, uint32_t mx, int n, int lane, uint64_t *out,
+                                                 int32_t *cnt, uint16_t *outm, int32_t *__restrict__ ids_dst,
+                                                 uint16_t *__restrict__ masks_dst) {
+    constexpr int PER = B / 64;
     for (int off = 32; off > 0; off >>= 1) {
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
@@ -927,10 +882,58 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
     for (int j = 0; j < PL; j++) {
         const int i = j * 64 + lane;
         if (i < n) {
-            ids_sorted[start + i] = (int32_t)(uint32_t)out[i];
-            masks[start + i] = outm[i];
+            ids_dst[i] = (int32_t)(uint32_t)out[i];
+            masks_dst[i] = outm[i];
         }
     }
+}
+
+template <int PL, int B>
+__global__ void __launch_bounds__(64)
+k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int take_longer,
+                   int2 *__restrict__ bins, uint4 *__restrict__ keys,
+                   int32_t *__restrict__ ids_sorted, uint16_t *__restrict__ masks) {
+    constexpr int CAP = 64 * PL;
+    __shared__ uint64_t out[CAP];
+    __shared__ int32_t cnt[B];
+    __shared__ uint16_t outm[CAP];
+    const int2 range = bins[blockIdx.x];
+    const int start = range.x;
+    const int n = min(range.y, capacity) - start;
+    // capacity overflow (the caller sized the id list from a stale count): make the ranges safe to
+    // walk — the compositing kernels then read inside the buffer; the caller detects the overflow
+    // from the true total and repeats the call
+    if (clamp_bins && range.y > capacity && threadIdx.x == 0)
+        bins[blockIdx.x] = make_int2(min(start, capacity), capacity);
+    if (n <= lo_n) return;
+    const int lane = threadIdx.x;
+    if (n > hi_n) {
+        // a longer segment: normally another launch's job.  When the host skipped those launches
+        // (the previous frame had no long list) this wave sorts it in place in global memory —
+        // slow, but only ever hit on the frame where a list first outgrows this class.
+        if (!take_longer) return;
+        sort_in_global<64>(keys + start, n, lane, ids_sorted + start, masks + start);
+        return;
+    }
+    const uint4 *src = keys + start;
+    uint64_t kk[PL];
+    uint32_t mm[PL / 2];   // the 16-bit masks, two to a register
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < PL / 2; j++) mm[j] = 0u;
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        const int i = j * 64 + lane;
+        uint4 r = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+        if (i < n) r = src[i];
+        kk[j] = rec_key(r);
+        mm[j >> 1] |= (r.z & 0xFFFFu) << (16 * (j & 1));
+        if (i < n) {
+            mn = min(mn, r.x);
+            mx = max(mx, r.x);
+        }
+    }
+    wave_bucket_sort<PL, B>(kk, mm, mn, mx, n, lane, out, cnt, outm, ids_sorted + start, masks + start);
 }
 
 // ---- 5. coverage masks ------------------------------------------------------------------------
@@ -1056,7 +1059,9 @@ k_cell_count(int N, int cells, int cells_x, const float4 *__restrict__ packed,
 // b. cell_bins[cell] = {first record, records, first intersection, intersections}.  Records are 32 bytes
 // {depth key, id, rectangle x, rectangle y | row table r0..r3}, stored as two adjacent 16-byte halves: one
 // full sector, and ONE open cache line per (workgroup, strip) — with the halves in two arrays the lines a
-// workgroup keeps open (2 x strips x 128 B) no longer fitted the XCD's L2 next to its 31 neighbours'.
+// workgroup keeps open (2 x strips x 128 B) no longer fitted the XCD's L2 next to its 31 neighbours'
+// (k_cell_scatter 47 -> 32 us at C2).  filt[pos] repeats the rectangle's x range (4 B): the filter pass of
+// k_tile_gather_sort reads that array alone.
 struct StripRec {
     uint4 a, b;
 };
@@ -1065,7 +1070,7 @@ k_cell_scatter(int N, int cells, int cells_x, int32_t capacity,
                const float4 *__restrict__ packed, const float *__restrict__ depths,
                const unsigned long long *__restrict__ counts, const int32_t *__restrict__ wg_base,
                int4 *__restrict__ cell_bins, int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
-               StripRec *__restrict__ recs) {
+               StripRec *__restrict__ recs, uint32_t *__restrict__ filt) {
     extern __shared__ int32_t h[];              // the workgroup's cursor of every strip
     __shared__ int32_t ws[17];
     const int t = threadIdx.x;
@@ -1134,6 +1139,7 @@ k_cell_scatter(int N, int cells, int cells_x, int32_t capacity,
             if (pos < capacity) {
                 recs[pos].a = ra;
                 recs[pos].b = rb;
+                if (filt) filt[pos] = ra.z;   // the x range alone: what k_tile_gather_sort's filter pass reads
             }
         });
         in = next;
@@ -1172,6 +1178,8 @@ k_strip_scatter(int cells_x, int tiles_x, int32_t capacity, const int4 *__restri
         tb = min((x1 + GS_TILE - 1) / GS_TILE, tile0 + nt) - 1 - tile0;
     };
     {   // 1. tile counts: sixteen ballots per 64 records, the wave's totals into LDS once
+        // (four records per thread and pass with every load requested up front: 33 -> 45 us at C2 — measured,
+        // profiles/r06/bench_binab_e_*.json; the registers cost more waves than the round trips saved)
         int32_t c = 0;   // lane t < 16 keeps the wave's count of tile t
         for (int base = (threadIdx.x >> 6) * 64; base < en; base += (int)blockDim.x) {
             const int i = base + lane;
@@ -1189,16 +1197,10 @@ k_strip_scatter(int cells_x, int tiles_x, int32_t capacity, const int4 *__restri
     if (threadIdx.x < kStripTiles) {
         const int t = threadIdx.x;
         const int32_t len = cnt[t];
-        int32_t start = cb.z, mx = 0;
-        for (int j = 0; j < kStripTiles; j++) {
-            const int32_t cj = cnt[j];
-            start += j < t ? cj : 0;
-            mx = max(mx, cj);
-        }
+        int32_t start = cb.z;
+        for (int j = 0; j < t; j++) start += cnt[j];
         cur[t] = start;
         if (t < nt) bins[ty * tiles_x + tile0 + t] = make_int2(start, start + len);
-        // (a plain read first: the maximum only grows, a stale value costs an atomic, never a miss)
-        if (t == 0 && mx > *longest) atomicMax(longest, mx);
     }
     __syncthreads();
     // 2. the records of the per-tile sort
@@ -1224,37 +1226,176 @@ k_strip_scatter(int cells_x, int tiles_x, int32_t capacity, const int4 *__restri
     }
 }
 
+// d. (round 6, second step) k_strip_scatter + the per-tile sort in ONE kernel, one wave per tile, without the
+// 16-byte key records in between.  The wave reads the x ranges of ALL its strip's records (filt: 4 B each, the
+// strip's sixteen waves run on one XCD and share the lines), keeps the records that reach its tile by ballot
+// compaction and — from the same pass — counts the intersections of the strip's tiles to its LEFT: its segment
+// starts at (intersections of the strips before) + that count, so tile_bins stays tile-major without a count
+// pass, a scan or any word exchanged between waves.  The kept records are then gathered (32 B, lines the
+// strip's other waves pull through the same L2), their masks formed from the row tables, and the keys sorted
+// by the wave exactly as k_bucket_sort_wave sorts them.  A list beyond the wave's capacity is written out as
+// key records for the larger sort classes (or sorted in place by the wave itself when the host skipped them).
+template <int PL, int B>
+__global__ void __launch_bounds__(64)
+k_tile_gather_sort(int cells, int cells_x, int tiles_x, int32_t capacity, int take_longer,
+                   const int4 *__restrict__ cell_bins, const uint32_t *__restrict__ filt,
+                   const StripRec *__restrict__ recs, const float4 *__restrict__ packed,
+                   int2 *__restrict__ bins, uint4 *__restrict__ keys, int32_t *__restrict__ ids_sorted,
+                   uint16_t *__restrict__ masks) {
+    constexpr int CAP = 64 * PL;
+    __shared__ uint64_t out[CAP];
+    __shared__ int32_t cnt[B];
+    __shared__ uint16_t outm[CAP];
+    uint32_t *queue = reinterpret_cast<uint32_t *>(out);   // kept record indices, until the sort needs `out`
+    // consecutive workgroups go to the 8 XCDs in turn: the sixteen waves of a strip are 8 apart
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int cell = (q >> kStripShift) * 8 + xcd, tl = q & (kStripTiles - 1);
+    if (cell >= cells) return;
+    const int ty = cell / cells_x, cx = cell % cells_x;
+    const int tile0 = cx << kStripShift, nt = min(tiles_x - tile0, kStripTiles);
+    if (tl >= nt) return;
+    const int lane = threadIdx.x;
+    const int4 cb = cell_bins[cell];
+    const int es = min(cb.x, capacity), en = min(cb.x + cb.y, capacity) - es;
+    const int tx = tile0 + tl;
+    // 1. filter: four independent loads in flight per lane
+    int32_t before = 0;
+    int n = 0;
+    for (int base = 0; base < en; base += 256) {
+        uint32_t f[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + 64 * k + lane;
+            f[k] = i < en ? filt[es + i] : 0u;     // (x0 = x1 = 0: reaches no tile)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x0 = (int)(f[k] & 0xFFFFu), x1 = (int)(f[k] >> 16);
+            const int ta = max(x0 / GS_TILE, tile0), tb = min((x1 + GS_TILE - 1) / GS_TILE, tile0 + nt) - 1;   // inclusive
+            before += max(min(tb, tx - 1) - ta + 1, 0);
+            const bool keep = ta <= tx && tx <= tb;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep && slot < CAP) queue[slot] = (uint32_t)(base + 64 * k + lane);
+            n += __builtin_popcountll(m);
+        }
+    }
+    before = __builtin_amdgcn_readlane(wave_inclusive_scan_i(before), 63);
+    const int start = cb.z + before;
+    if (lane == 0) bins[ty * tiles_x + tx] = make_int2(min(start, capacity), min(start + n, capacity));
+    const int nfit = min(start + n, capacity) - min(start, capacity);   // what the id list holds of this segment
+    if (nfit <= 0) return;
+    auto entry = [&](int i, uint64_t &key, uint32_t &mask) {
+        const uint4 a = recs[es + i].a, b = recs[es + i].b;
+        const RowTable w = row_table_of(a, b);
+        if (w.base != kNoRowTable) {
+            mask = mask_from_rows(w, tx, ty);
+        } else {
+            const float4 p0 = packed[3 * (size_t)a.y + 0], p1 = packed[3 * (size_t)a.y + 1];
+            mask = block_mask16(p0.x, p0.y, p0.z, p0.w, p1.x, __float_as_uint(p1.z), a.z, a.w, tx * GS_TILE,
+                                ty * GS_TILE);
+        }
+        key = ((uint64_t)a.x << 32) | a.y;
+    };
+    if (n > CAP) {
+        // a list beyond this class: the filter again, writing the key records of the larger classes
+        int m2 = 0;
+        for (int base = 0; base < en; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            if (i < en) {
+                const uint32_t f = filt[es + i];
+                const int x0 = (int)(f & 0xFFFFu), x1 = (int)(f >> 16);
+                keep = max(x0 / GS_TILE, tile0) <= tx && tx <= min((x1 + GS_TILE - 1) / GS_TILE, tile0 + nt) - 1;
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+            const int slot = m2 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (keep && slot < nfit) {
+                uint64_t key;
+                uint32_t mask;
+                entry(i, key, mask);
+                keys[start + slot] = make_uint4((uint32_t)(key >> 32), (uint32_t)key, mask, 0u);
+            }
+            m2 += __builtin_popcountll(m);
+        }
+        if (take_longer) {
+            __syncthreads();   // (one wave: orders the global stores above against the loads of the network)
+            __threadfence_block();
+            sort_in_global<64>(keys + start, nfit, lane, ids_sorted + start, masks + start);
+        }
+        return;
+    }
+    __syncthreads();   // the queue is complete
+    // 2. gather the kept records: keys and masks into registers
+    uint64_t kk[PL];
+    uint32_t mm[PL / 2];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < PL / 2; j++) mm[j] = 0u;
+    uint32_t qi[PL];
+#pragma unroll
+    for (int j = 0; j < PL; j++) qi[j] = j * 64 + lane < nfit ? queue[j * 64 + lane] : 0u;
+    __syncthreads();   // `out` is free for the sort
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        kk[j] = ~0ull;
+        if (j * 64 + lane < nfit) {
+            uint32_t mask;
+            entry((int)qi[j], kk[j], mask);
+            mm[j >> 1] |= (mask & 0xFFFFu) << (16 * (j & 1));
+            const uint32_t d = (uint32_t)(kk[j] >> 32);
+            mn = min(mn, d);
+            mx = max(mx, d);
+        }
+    }
+    wave_bucket_sort<PL, B>(kk, mm, mn, mx, nfit, lane, out, cnt, outm, ids_sorted + start, masks + start);
+}
+
 // the same order from finished tile_bins (strip binning: the tile counts only exist once the strips have been
-// split): one 1024-thread workgroup, list lengths in LDS when they fit
+// split): one 1024-thread workgroup, list lengths in LDS when they fit.  Also the frame's longest list, to the
+// device word and — with M — to the pinned statistics of the host.
 __global__ void __launch_bounds__(1024)
 k_tile_order(int tiles, int use_lds, int order_mult, const int2 *__restrict__ bins,
-             const int32_t *__restrict__ longest, int32_t *__restrict__ order) {
+             int32_t *__restrict__ longest_dev, int32_t *__restrict__ stats_host,
+             int32_t *__restrict__ order) {
     extern __shared__ int32_t len_lds[];
     __shared__ int32_t part[1024];
     __shared__ int32_t ws[17];
+    __shared__ int32_t s_longest;
     const int t = threadIdx.x;
-    if (use_lds)
-        for (int i = t; i < tiles; i += 1024) {
-            const int2 b = bins[i];
-            len_lds[i] = b.y - b.x;
-        }
+    if (t == 0) s_longest = 0;
     part[t] = 0;
-    const int shift = order_shift(*longest);
     __syncthreads();
+    int32_t mx = 0;
+    for (int i = t; i < tiles; i += 1024) {
+        const int2 b = bins[i];
+        if (use_lds) len_lds[i] = b.y - b.x;
+        mx = max(mx, b.y - b.x);
+    }
+    mx = wave_max_i(mx);
+    if ((t & 63) == 0) atomicMax(&s_longest, mx);
+    __syncthreads();
+    const int32_t longest = s_longest;
+    if (t == 0) {
+        *longest_dev = longest;
+        if (stats_host) stats_host[1] = longest;   // pinned, device-mapped
+    }
+    if (!order) return;
+    const int shift = order_shift(longest), ostep = order_step(tiles, order_mult);
     auto length = [&](int i) -> int32_t {
         if (use_lds) return len_lds[i];
         const int2 b = bins[i];
         return b.y - b.x;
     };
-    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
-        atomicAdd(&part[1023 - min(length(i) >> shift, 1023)], 1);
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
+        atomicAdd(&part[1023 - (length(i) >> shift)], 1);
     __syncthreads();
     const int32_t own = part[t];
     const int32_t first = block_scan_1024(own, ws) - own;
     part[t] = first;
     __syncthreads();
-    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, order_mult))
-        order[atomicAdd(&part[1023 - min(length(i) >> shift, 1023)], 1)] = i;
+    for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
+        order[atomicAdd(&part[1023 - (length(i) >> shift)], 1)] = i;
 }
 
 // mult of the scattered tile sequence (order_first / order_next): ~0.618 tiles, coprime to tiles
@@ -1282,8 +1423,8 @@ static int persistent_blocks(int N) {
 struct BinLayout {
     size_t counters, total_dev, wg_base, keys, total;
     // strip binning (section 6): [ strip counters u64 x cells | longest list ] is one zeroed block; cell_bins
-    // int4 x cells; cell_base 256 x cells i32; recs: capacity x 32 B behind the keys
-    size_t cell_counts, longest, zero_bytes, cell_bins, cell_base, recs;
+    // int4 x cells; cell_base 256 x cells i32; recs: capacity x 32 B and filt: capacity x 4 B behind the keys
+    size_t cell_counts, longest, zero_bytes, cell_bins, cell_base, recs, filt;
     int cells_x, cells;   // cells = 0: the image has too many strips, tile-level path only
 };
 // What gs_bin_scan remembers (on the host, per workspace address) so that gs_bin_sort can tell that the
@@ -1335,18 +1476,17 @@ static BinLayout bin_layout(int N, int64_t capacity, int W, int H) {
     L.keys = L.cell_base + align_up((size_t)256 * L.cells * 4);
     const size_t cap_bytes = align_up((size_t)(capacity > 0 ? capacity : 1) * 16);
     L.recs = L.keys + cap_bytes + 256;
-    L.total = L.recs + (L.cells ? 2 * cap_bytes : 0) + 256;
+    L.filt = L.recs + (L.cells ? 2 * cap_bytes : 0) + 256;
+    L.total = L.filt + (L.cells ? align_up((size_t)(capacity > 0 ? capacity : 1) * 4) : 0) + 256;
     return L;
 }
 
 // The per-tile sorts of section 4 over every tile's segment of `keys`: which size classes are launched follows
-// the previous frame's statistics.  `so`: the strip binning's statistics hand-off, done by the launch that
-// visits every tile (always the last one).
+// the previous frame's statistics.
 static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_stats, int2 *bins_rw,
                              uint4 *keys, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
-                             StripOrder so, hipStream_t s) {
+                             hipStream_t s) {
     const int2 *bins = bins_rw;
-    const StripOrder none{nullptr, nullptr};
     // Every class also moves the coverage masks (third word of the records) along with the keys.
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
     // the same with 1024 buckets (12 KiB); <= 8192 keys: 256 threads, 4096 buckets (80 KiB LDS);
@@ -1369,7 +1509,7 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
                           ((int64_t)list_stats[0] > 300 * (int64_t)tiles || tiles <= 1024);
     if (only_mid) {
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
-                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
         return GS_OK;
     }
@@ -1381,7 +1521,7 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     // shared, the stage 0.233 -> 0.251 ms on the hot-spot scene.  In a row.)
     if (!only_short && !few_long) {
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks, none);
+                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     if (!no_long) {
@@ -1400,10 +1540,10 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
     if (few_long)
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
-                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     else
         GS_LAUNCH((k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
-                           1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks, so);
+                           1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     GS_LAUNCH_CHECK();
     return GS_OK;
 }
@@ -1549,7 +1689,7 @@ extern "C" int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *p
     }
     GS_LAUNCH_CHECK();
     return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
-                                 gaussian_ids_sorted, block_masks, gs::StripOrder{nullptr, nullptr}, s);
+                                 gaussian_ids_sorted, block_masks, s);
 }
 
 extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float *packed,
@@ -1595,24 +1735,79 @@ extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float 
     GS_LAUNCH(gs::k_cell_count, dim3(blocks), dim3(gs::kPersistentThreads), (size_t)L.cells * 8, s, N, L.cells,
               L.cells_x, pk, counts, cell_base);
     GS_LAUNCH_CHECK();
+    uint32_t *filt = reinterpret_cast<uint32_t *>(base + L.filt);
+    int2 *bins = reinterpret_cast<int2 *>(tile_bins);
+    // measurement switch: GSPLAT_STRIPS_FUSED=1 replaces k_strip_scatter + the tile-level path's sort kernels by
+    // k_tile_gather_sort (measured slower: profiles/HISTORY.md)
+    static const bool fused = [] { const char *e = getenv("GSPLAT_STRIPS_FUSED"); return e && e[0] == '1'; }();
     GS_LAUNCH(gs::k_cell_scatter, dim3(blocks), dim3(gs::kPersistentThreads), (size_t)L.cells * 4, s, N, L.cells,
-              L.cells_x, capacity, pk, depths, counts, cell_base, cell_bins, total_dev, num_isects_host, recs);
+              L.cells_x, capacity, pk, depths, counts, cell_base, cell_bins, total_dev, num_isects_host, recs,
+              fused ? filt : nullptr);
     GS_LAUNCH_CHECK();
-    GS_LAUNCH(gs::k_strip_scatter, dim3(L.cells), dim3(gs::kPersistentThreads), 0, s, L.cells_x, tiles_x, capacity,
-              cell_bins, recs, pk, keys, reinterpret_cast<int2 *>(tile_bins), longest);
-    GS_LAUNCH_CHECK();
-    {
+    int rc = GS_OK;
+    auto order_tiles = [&]() -> int {
         const size_t lds = sizeof(int32_t) * (size_t)tiles;
         const int use_lds = lds <= gs::kMaxTileLds ? 1 : 0;
         if (use_lds)
             GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_tile_order),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));
         GS_LAUNCH(gs::k_tile_order, dim3(1), dim3(1024), use_lds ? lds : 0, s, tiles, use_lds,
-                  gs::order_multiplier(tiles), reinterpret_cast<const int2 *>(tile_bins), longest, tile_order);
+                  gs::order_multiplier(tiles), bins, longest, num_isects_host, tile_order);
         GS_LAUNCH_CHECK();
+        return GS_OK;
+    };
+    if (!fused) {
+        GS_LAUNCH(gs::k_strip_scatter, dim3(L.cells), dim3(gs::kPersistentThreads), 0, s, L.cells_x, tiles_x, capacity,
+                  cell_bins, recs, pk, keys, bins, longest);
+        GS_LAUNCH_CHECK();
+        // (before the sorts: their last launch clamps tile_bins to the capacity, and the statistics must be the
+        // frame's true ones also when the id list was too small)
+        rc = order_tiles();
+        if (rc != GS_OK) return rc;
+        return gs::launch_tile_sorts(tiles, capacity, list_stats, bins, keys, gaussian_ids_sorted, block_masks, s);
+    } else {
+        // one wave per tile: filter + gather + sort.  Size classes as in launch_tile_sorts, from the previous
+        // frame's statistics: the wave takes what fits its registers (512 or 1024 keys) and leaves longer lists
+        // as key records to the larger classes launched behind it — or sorts them in place itself where the
+        // host skipped those launches.
+        const bool have_stats = list_stats && list_stats[0] > 0;
+        const bool only_short = have_stats && list_stats[1] <= 400;
+        const bool no_long = have_stats && list_stats[1] <= 900;
+        const bool only_mid = no_long && !only_short &&
+                              ((int64_t)list_stats[0] > 300 * (int64_t)tiles || tiles <= 1024);
+        const bool few_long = have_stats && !no_long && tiles <= 1024;
+        const int waves = (L.cells + 7) / 8 * 8 * gs::kStripTiles;
+#define GS_FUSED(PL, B, TAKE)                                                                                  \
+    GS_LAUNCH((gs::k_tile_gather_sort<PL, B>), dim3(waves), dim3(64), 0, s, L.cells, L.cells_x, tiles_x,       \
+              capacity, TAKE, cell_bins, filt, recs, pk, bins, keys, gaussian_ids_sorted, block_masks)
+        if (only_mid) {
+            GS_FUSED(16, 1024, 1);
+        } else if (few_long) {
+            GS_FUSED(16, 1024, 0);
+        } else {
+            GS_FUSED(8, 512, only_short ? 1 : 0);
+        }
+        GS_LAUNCH_CHECK();
+        if (!only_mid && !only_short && !few_long) {
+            GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024, capacity, 0,
+                      no_long ? 1 : 0, bins, keys, gaussian_ids_sorted, block_masks);
+            GS_LAUNCH_CHECK();
+        }
+        if (!no_long) {
+            constexpr int CAP = 8192, B = 4096, NT = 1024;
+            const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
+            GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            GS_LAUNCH((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024, CAP, capacity, bins,
+                      keys, gaussian_ids_sorted, block_masks);
+            GS_LAUNCH_CHECK();
+        }
+#undef GS_FUSED
     }
-    return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
-                                 gaussian_ids_sorted, block_masks, gs::StripOrder{longest, num_isects_host}, s);
+    if (rc != GS_OK) return rc;
+    // (fused: tile_bins are clamped as they are written — on a frame whose id list was too small the longest list
+    // reported is the clamped one)
+    return order_tiles();
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
