@@ -95,7 +95,8 @@ const char *gs_last_hip_error(void); /* thread-local text of the last failing HI
  * argument list or an entry point is added (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0:
  * round 4; 0.4.2: gs_bin_strips, round 6).  A consumer
  * compiled against another header must refuse the library instead of calling through shifted arguments:
- * opensplat_amd/cabi.py and libgsplat_torch.so compare gs_version() with this constant when they load. */
+ * opensplat_amd/cabi.py compares gs_version() with this constant when it loads the library, libgsplat_torch.so in
+ * front of its first call into it (torch_ops.cpp: current_stream()). */
 #define GS_ABI_VERSION 402
 int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 

@@ -383,7 +383,7 @@ class Checkpoints:
         for ITS backward — a later plan() on the shared object (another render in between, e.g. an evaluation
         view) then changes neither.  The records themselves are only safe until the next forward
         writes the shared buffer: a render() / backward() pair must not be interleaved with another render()
-        that plans pieces, which Trainer.backward checks."""
+        that plans pieces (Trainer.backward always differentiates the LAST render())."""
         f = Checkpoints()
         f.buf, f.seg_len, f.max_segments, f.bytes = self.buf, self.seg_len, self.max_segments, self.bytes
         return f

@@ -15,9 +15,11 @@
 
 using torch::Tensor;
 
+gs_stream_t gsplatCurrentStream();   // torch_ops.cpp (same library): current HIP stream + the once-per-process ABI check
+
 namespace {
 
-gs_stream_t stream() { return (gs_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+gs_stream_t stream() { return gsplatCurrentStream(); }   // torch_ops.cpp: runs the ABI check in front of the first call
 
 void ok(int rc, const char *what) {
     TORCH_CHECK(rc == GS_OK, what, " failed: ", gs_strerror(rc),

@@ -1418,6 +1418,11 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                     // before the passes, to take its round trip off the end of the step, measured 252 us: every
                     // active group then reads, not only the winners)
                     asm volatile("; claim lost: another round");
+                    // The losers re-read records the winners have just stored with PLAIN LDS accesses: ordered by
+                    // program order and the in-order LDS pipe on the hardware, but a data race under the memory
+                    // model — a wavefront-scope release / acquire pair (no instruction on gfx950) keeps the
+                    // compiler from forwarding or hoisting across it.
+                    wave_sync();
                     bool w = false;
                     if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
                         __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -16,6 +16,7 @@
 #include <torch/torch.h>
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <tuple>
 #include <vector>
@@ -242,6 +243,46 @@ public:
 
 private:
     void *comm_ = nullptr;
+};
+
+// SURVEY.md §8e / f2 — the render work of ONE optimiser step over a BATCH of cameras on this rank, two of
+// them in flight: camera j + 1's per-Gaussian forward, binning and compositing forward (HBM- / latency-bound) run
+// on a second HIP stream under camera j's compositing backward (VALU-bound) — 1.2 x the serial loop at 1 M
+// Gaussians, 1080p.  Generalises the per-image body of opensplat.cpp:151-170 (model.forward + backward); the
+// Python twin is opensplat_amd.train.Trainer.train_step_batch.  The gradients of the six raw parameter tensors
+// are overwritten by camera 0 and ACCUMULATED in camera order (an event orders the lanes' accumulation), i.e.
+// exactly the sums of the serial loop, bit-identical with deterministic = true.  With an exchange the summed
+// gradients are all-reduced once, behind the last camera (the factored exchange of the Python path is not
+// offered here).  The caller's stream waits for the batch; no host synchronisation beyond the intersection-count
+// validation of each frame (validateBinning).
+struct BatchCamera {
+    torch::Tensor viewMat, projMat, camPos;   // [4,4], [4,4] (= proj @ view), [3]; host or device
+    double fx = 0, fy = 0, cx = 0, cy = 0;
+};
+class CameraBatch {
+public:
+    // cotangent(j, rgb): d loss / d rgb [H,W,3] of camera j from its clamped image; called with the lane's stream
+    // current, so whatever it enqueues (mainLoss, a copy) joins that lane
+    using Cotangent = std::function<torch::Tensor(int, const torch::Tensor &)>;
+    CameraBatch(int64_t imgHeight, int64_t imgWidth);
+    ~CameraBatch();
+    CameraBatch(const CameraBatch &) = delete;
+    CameraBatch &operator=(const CameraBatch &) = delete;
+    // grads = { v_means [N,3], v_logScales [N,3], v_quats [N,4], v_opacityLogits [N] or [N,1], v_featuresDc [N,3],
+    // v_featuresRest [N,K-1,3] (ignored for K = 1) }: contiguous float32 on the parameters' device.
+    // serial: one camera after the other on one lane (the reference order: tests)
+    void forwardBackward(const torch::Tensor &means, const torch::Tensor &logScales, const torch::Tensor &quats,
+                         const torch::Tensor &opacityLogits, const torch::Tensor &featuresDc,
+                         const torch::Tensor &featuresRest, const std::vector<BatchCamera> &cameras,
+                         int64_t degreesToUse, const torch::Tensor &background, const Cotangent &cotangent,
+                         std::vector<torch::Tensor> &grads, bool deterministic = false, bool serial = false,
+                         GradExchange *exchange = nullptr);
+    int64_t lastIntersections() const { return lastM_; }
+
+private:
+    struct Lane;
+    std::unique_ptr<Lane> lanes_[2];
+    int64_t H_, W_, lastM_ = 0;
 };
 
 // Process-wide switch for the compositing kernels' exponential: false (default) = glibc-bit-exact

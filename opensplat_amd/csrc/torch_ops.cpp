@@ -48,7 +48,14 @@ void check_status(int rc, const char *what) {
                 rc == GS_ERR_HIP ? std::string(" — ") + gs_last_hip_error() : std::string());
 }
 
+// The stream argument of EVERY C-ABI call of this library is fetched here (bindings_hip_native.cpp: stream()),
+// i.e. before the call is made: the place where the ABI check runs by itself, once per process, for every
+// consumer — OpenSplat patched by integration/apply_hip_native.py included — without throwing inside dlopen
+// (a static initialiser that throws ends in std::terminate; ADVICE r05: a check only ops.py calls
+// protects nobody else).
+static std::once_flag g_abiOnce;
 gs_stream_t current_stream() {
+    std::call_once(g_abiOnce, [] { gsplatCheckAbi(); });   // (an exception leaves the flag unset: checked again)
     return (gs_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
 }
 
@@ -1150,11 +1157,180 @@ static std::vector<Tensor> op_bin_and_sort_gaussians(int64_t numPoints, int64_t 
     return {std::get<0>(t), std::get<1>(t), std::get<2>(t), std::get<3>(t), std::get<4>(t)};
 }
 
-// libgsplat_hip.so must be the one this file's header describes (shifted arguments otherwise).  Checked by
-// ops.py right after load_library (a readable Python error) and by C++ callers through gsplatCheckAbi();
-// NOT inside the static initialiser below: an exception thrown while dlopen runs ends in std::terminate
-// (ADVICE r04).
+
+// ---- CameraBatch: a camera batch with two cameras in flight (gsplat_ops.hpp) -----------------------------
+struct CameraBatch::Lane {
+    c10::hip::HIPStreamMasqueradingAsCUDA stream;
+    at::cuda::CUDAEvent done;
+    // what one camera in flight owns
+    Tensor packed, depths, radii, rgbRaw, imgRaw, img, finalTs, finalIdx, records;
+    BinnedLists lists;
+    GsCamera cam;
+    Tensor vmHold, pmHold, cpHold;
+    const float *vmDev = nullptr, *pmDev = nullptr, *cp = nullptr;
+    int64_t N = -1, K = 0;
+    bool det = false;
+    explicit Lane(int device) : stream(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, (c10::DeviceIndex)device)) {}
+};
+
+CameraBatch::CameraBatch(int64_t imgHeight, int64_t imgWidth) : H_(imgHeight), W_(imgWidth) {}
+CameraBatch::~CameraBatch() = default;
+
+void CameraBatch::forwardBackward(const Tensor &meansIn, const Tensor &logScalesIn, const Tensor &quatsIn,
+                                  const Tensor &opacityLogitsIn, const Tensor &featuresDcIn,
+                                  const Tensor &featuresRestIn, const std::vector<BatchCamera> &cameras,
+                                  int64_t degreesToUse, const Tensor &background, const Cotangent &cotangent,
+                                  std::vector<Tensor> &grads, bool deterministic, bool serial,
+                                  GradExchange *exchange) {
+    TORCH_CHECK(!cameras.empty(), "CameraBatch: no camera");
+    GS_CHECK_DEV(meansIn); GS_CHECK_F32(meansIn);
+    const int64_t N = meansIn.size(0);
+    const bool hasRest = featuresRestIn.defined() && featuresRestIn.numel() > 0;
+    const int64_t K = 1 + (hasRest ? featuresRestIn.size(1) : 0);
+    TORCH_CHECK(grads.size() >= 5 && (K == 1 || grads.size() >= 6), "CameraBatch: six gradient tensors expected");
+    for (size_t i = 0; i < grads.size(); i++)
+        if (i < 5 || K > 1) {
+            GS_CHECK_DEV(grads[i]); GS_CHECK_F32(grads[i]);
+            TORCH_CHECK(grads[i].is_contiguous(), "CameraBatch: gradient tensors must be contiguous");
+        }
+    TORCH_CHECK(grads[0].numel() == 3 * N && grads[1].numel() == 3 * N && grads[2].numel() == 4 * N &&
+                grads[3].numel() == N && grads[4].numel() == 3 * N && (K == 1 || grads[5].numel() == 3 * (K - 1) * N),
+                "CameraBatch: gradient tensors do not match the parameters");
+    c10::DeviceGuard guard(meansIn.device());
+    const int device = meansIn.get_device();
+    Tensor means = meansIn.contiguous(), logScales = logScalesIn.contiguous(), quats = quatsIn.contiguous();
+    Tensor opacityLogits = opacityLogitsIn.contiguous(), featuresDc = featuresDcIn.contiguous();
+    Tensor featuresRest = hasRest ? featuresRestIn.contiguous() : Tensor();
+    const int W = (int)W_, H = (int)H_;
+    auto f32 = means.options();
+    auto i32 = means.options().dtype(torch::kInt32);
+    Tensor bgHold;
+    const float *bg = vec3_arg(background, bgHold);
+    const uint32_t flags = (g_fast_exp.load() ? GS_FLAG_FAST_EXP : 0u) | GS_FLAG_CLAMP_IMAGE | GS_FLAG_LOGIT_OPACITY;
+    const uint32_t keep = GS_FLAG_KEEP_RECORDS | (deterministic ? GS_FLAG_DETERMINISTIC : 0u);
+    const size_t wsBytes = deterministic ? gs_rasterize_backward_workspace_bytes_det((int)N)
+                                         : gs_rasterize_backward_workspace_bytes((int)N);
+    auto mainStream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA();
+    at::cuda::CUDAEvent start;
+    start.record(mainStream);
+    for (auto &lp : lanes_) {
+        if (!lp) lp = std::make_unique<Lane>(device);
+        Lane &L = *lp;
+        c10::hip::HIPStreamGuardMasqueradingAsCUDA sg(L.stream);   // (allocations belong to the lane's stream)
+        if (L.N != N || L.K != K || L.det != deterministic) {
+            L.packed = torch::empty({N, GS_SPLAT_DWORDS}, f32); L.depths = torch::empty({N}, f32);
+            L.radii = torch::empty({N}, i32); L.rgbRaw = torch::empty({N, 3}, f32);
+            L.imgRaw = torch::empty({H, W, 3}, f32); L.img = torch::empty({H, W, 3}, f32);
+            L.finalTs = torch::empty({H, W}, f32); L.finalIdx = torch::empty({H, W}, i32);
+            L.records = torch::zeros({(int64_t)(wsBytes ? wsBytes : 64)}, f32.dtype(torch::kUInt8));
+            L.N = N; L.K = K; L.det = deterministic;
+        }
+        start.block(L.stream);
+    }
+    auto front = [&](Lane &L, int j) {
+        const BatchCamera &c = cameras[(size_t)j];
+        c10::hip::HIPStreamGuardMasqueradingAsCUDA sg(L.stream);
+        gs_stream_t s = current_stream();
+        L.cam = make_camera(c.fx, c.fy, c.cx, c.cy, H_, W_, 0.01, 1.0, GS_CAM_LOG_SCALES);
+        L.vmDev = matrix_arg(c.viewMat, L.vmHold, L.cam.viewmat);
+        L.pmDev = matrix_arg(c.projMat, L.pmHold, L.cam.projmat);
+        L.cp = vec3_arg(c.camPos, L.cpHold);
+        check_status(gs_gaussian_forward(&L.cam, L.vmDev, L.pmDev, (int)N, (int)K, (int)degreesToUse, fptr(means),
+                                         fptr(logScales), fptr(quats), fptr(opacityLogits), fptr(featuresDc),
+                                         hasRest ? fptr(featuresRest) : nullptr, L.cp, fptr_mut(L.packed),
+                                         fptr_mut(L.depths), L.radii.data_ptr<int32_t>(), fptr_mut(L.rgbRaw),
+                                         nullptr, flags, s),
+                     "gs_gaussian_forward");
+        L.lists = binPackedRecords(L.packed, L.depths, H, W);
+        check_status(gs_rasterize_forward(W, H, L.lists.gaussianIdsSorted.data_ptr<int32_t>(), maskptr(L.lists.blockMasks),
+                                          L.lists.tileBins.data_ptr<int32_t>(), fptr(L.packed), bg, fptr_mut(L.imgRaw),
+                                          fptr_mut(L.finalTs), L.finalIdx.data_ptr<int32_t>(), fptr_mut(L.img), nullptr,
+                                          L.lists.tileOrder.data_ptr<int32_t>(), flags, s),
+                     "gs_rasterize_forward");
+    };
+    auto back = [&](Lane &L, int j, Lane *prev) {
+        c10::hip::HIPStreamGuardMasqueradingAsCUDA sg(L.stream);
+        gs_stream_t s = current_stream();
+        Tensor v = cotangent(j, L.img).contiguous();
+        GS_CHECK_DEV(v); GS_CHECK_F32(v);
+        TORCH_CHECK(v.numel() == (int64_t)H * W * 3, "CameraBatch: the cotangent must be [H,W,3]");
+        check_status(gs_rasterize_backward(W, H, (int)N, L.lists.gaussianIdsSorted.data_ptr<int32_t>(),
+                                           maskptr(L.lists.blockMasks), L.lists.tileBins.data_ptr<int32_t>(),
+                                           fptr(L.packed), bg, fptr(L.finalTs), L.finalIdx.data_ptr<int32_t>(), fptr(v),
+                                           nullptr, fptr(L.imgRaw), nullptr, nullptr, nullptr, nullptr,
+                                           L.records.data_ptr(), wsBytes, L.lists.listStats,
+                                           L.lists.tileOrder.data_ptr<int32_t>(), flags | keep, s),
+                     "gs_rasterize_backward");
+        if (prev) prev->done.block(L.stream);     // the gradient tensors: camera order
+        check_status(gs_gaussian_backward(&L.cam, L.vmDev, L.pmDev, (int)N, (int)K, (int)degreesToUse, fptr(means),
+                                          fptr(logScales), fptr(quats), fptr(opacityLogits), L.cp,
+                                          L.radii.data_ptr<int32_t>(), fptr(L.rgbRaw), L.records.data_ptr(), wsBytes,
+                                          fptr_mut(grads[0]), fptr_mut(grads[1]), fptr_mut(grads[2]),
+                                          fptr_mut(grads[3]), fptr_mut(grads[4]), K > 1 ? fptr_mut(grads[5]) : nullptr,
+                                          nullptr, flags | (j > 0 ? GS_FLAG_ACCUMULATE_GRADS : 0u), s),
+                     "gs_gaussian_backward");
+        L.done.record(L.stream);
+    };
+    const int n = (int)cameras.size();
+    Lane *prev = nullptr;
+    if (N > 0) {
+        if (!serial) front(*lanes_[0], 0);
+        for (int j = 0; j < n; j++) {
+            Lane &L = *lanes_[serial ? 0 : j % 2];
+            if (serial) front(L, j);
+            while (!validateBinning(L.lists)) front(L, j);     // (the id list was too small: this camera's front again)
+            lastM_ = L.lists.listStats[0];
+            if (!serial && j + 1 < n) front(*lanes_[(j + 1) % 2], j + 1);
+            back(L, j, prev);
+            prev = &L;
+        }
+        prev->done.block(mainStream);
+    }
+    if (exchange && exchange->worldSize() > 1)
+        for (size_t i = 0; i < grads.size(); i++)
+            if (i < 5 || K > 1) exchange->allReduce(grads[i]);
+}
+
+// test face: fixed cotangents v_out [c,H,W,3]; -> { v_means, v_logScales, v_quats, v_opacityLogits, v_dc, v_rest, rgb [c,H,W,3] }
+static std::vector<Tensor> op_camera_batch_step(const Tensor &means, const Tensor &logScales, const Tensor &quats,
+                                                const Tensor &opacityLogits, const Tensor &featuresDc,
+                                                const Tensor &featuresRest, const Tensor &viewMats,
+                                                const Tensor &projMats, const Tensor &camPos, double fx, double fy,
+                                                double cx, double cy, int64_t imgHeight, int64_t imgWidth,
+                                                int64_t degreesToUse, const Tensor &background, const Tensor &vOut,
+                                                bool deterministic, bool serial) {
+    const int64_t c = viewMats.size(0), N = means.size(0);
+    TORCH_CHECK(projMats.size(0) == c && camPos.size(0) == c && vOut.size(0) == c, "camera_batch_step: c cameras expected");
+    std::vector<BatchCamera> cams((size_t)c);
+    for (int64_t j = 0; j < c; j++) {
+        cams[(size_t)j].viewMat = viewMats[j]; cams[(size_t)j].projMat = projMats[j]; cams[(size_t)j].camPos = camPos[j];
+        cams[(size_t)j].fx = fx; cams[(size_t)j].fy = fy; cams[(size_t)j].cx = cx; cams[(size_t)j].cy = cy;
+    }
+    auto f32 = means.options();
+    const bool hasRest = featuresRest.defined() && featuresRest.numel() > 0;
+    std::vector<Tensor> grads = {torch::empty({N, 3}, f32), torch::empty({N, 3}, f32), torch::empty({N, 4}, f32),
+                                 torch::empty({N}, f32), torch::empty({N, 3}, f32),
+                                 hasRest ? torch::empty_like(featuresRest) : torch::empty({0}, f32)};
+    Tensor rgb = torch::empty({c, imgHeight, imgWidth, 3}, f32);
+    static std::mutex batchMutex;
+    static std::map<std::tuple<int, int64_t, int64_t>, std::unique_ptr<CameraBatch>> batches;   // lanes re-used across calls
+    std::lock_guard<std::mutex> lock(batchMutex);
+    auto &cb = batches[std::make_tuple(means.get_device(), imgHeight, imgWidth)];
+    if (!cb) cb = std::make_unique<CameraBatch>(imgHeight, imgWidth);
+    cb->forwardBackward(means, logScales, quats, opacityLogits, featuresDc, featuresRest, cams, degreesToUse,
+                        background, [&](int j, const Tensor &img) { rgb[j].copy_(img); return vOut[j]; }, grads,
+                        deterministic, serial);
+    grads.push_back(rgb);
+    return grads;
+}
+
+// libgsplat_hip.so must be the one this file's header describes (shifted arguments otherwise).  Checked
+// lazily by current_stream() in front of the first C-ABI call of the process (every consumer), by ops.py right
+// after load_library (a readable Python error at import) and on request through gsplatCheckAbi(); NOT inside the
+// static initialiser below: an exception thrown while dlopen runs ends in std::terminate.
 static std::vector<int64_t> op_abi_versions() { return {(int64_t)gs_version(), (int64_t)GS_ABI_VERSION}; }
+// (bindings_hip_native.cpp, the other translation unit of this library)
+gs_stream_t gsplatCurrentStream() { return current_stream(); }
 void gsplatCheckAbi() {
     TORCH_CHECK(gs_version() == GS_ABI_VERSION, "libgsplat_hip.so has ABI version ", gs_version(),
                 ", libgsplat_torch.so was built against ", GS_ABI_VERSION, ": rebuild both");
@@ -1186,6 +1362,11 @@ TORCH_LIBRARY(opensplat_amd, m) {
           "float fx, float fy, float cx, float cy, int img_height, int img_width, int degrees_to_use, "
           "Tensor background, Tensor? xys_grad_out=None) -> Tensor[]",
           &op_splat_render);
+    m.def("camera_batch_step(Tensor means, Tensor log_scales, Tensor quats, Tensor opacity_logits, "
+          "Tensor features_dc, Tensor features_rest, Tensor viewmats, Tensor projmats, Tensor cam_pos, float fx, "
+          "float fy, float cx, float cy, int img_height, int img_width, int degrees_to_use, Tensor background, "
+          "Tensor v_out, bool deterministic=False, bool serial=False) -> Tensor[]",
+          &op_camera_batch_step);
     m.def("set_fast_exp(bool enabled) -> ()", &op_set_fast_exp);
     m.def("set_segmented_backward(bool enabled) -> ()", &op_set_segmented_backward);
     m.def("main_loss(Tensor rgb, Tensor gt, float ssim_weight) -> Tensor", &op_main_loss);

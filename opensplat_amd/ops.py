@@ -113,6 +113,17 @@ def splat_render(means, log_scales, quats, opacity_logits, features_dc, features
                              degrees_to_use, background, xys_grad_out)
 
 
+def camera_batch_step(means, log_scales, quats, opacity_logits, features_dc, features_rest, viewmats, projmats,
+                      cam_pos, fx, fy, cx, cy, img_height, img_width, degrees_to_use, background, v_out,
+                      deterministic=False, serial=False):
+    """gsplat_ops.hpp CameraBatch::forwardBackward with fixed cotangents v_out [c,H,W,3] (test face): c cameras
+    over the same raw parameters with two of them in flight -> [v_means, v_log_scales, v_quats, v_opacity_logits,
+    v_features_dc, v_features_rest, rgb [c,H,W,3]]; the gradients are the sums over the cameras, in camera order."""
+    return _ops.camera_batch_step(means, log_scales, quats, opacity_logits, features_dc, features_rest, viewmats,
+                                  projmats, cam_pos, fx, fy, cx, cy, img_height, img_width, degrees_to_use,
+                                  background, v_out, deterministic, serial)
+
+
 def main_loss(rgb, gt, ssim_weight=0.2):
     """Model::mainLoss (model.cpp:780-784) as one autograd node: (1 - w) * L1 + w * (1 - SSIM) with the
     reference's 11x11 window; returns a 0-dim tensor, differentiable w.r.t. rgb (row f2)."""

@@ -73,17 +73,24 @@ class Trainer:
                  num_cameras: int = 1, morton_order: bool = False, num_downscales: int = 2,
                  resolution_schedule: int = 3000, sh_degree_interval: int = 1000,
                  reference_alpha_reset: bool = False, grad_buckets: int = 4, exchange: str = "auto",
-                 deterministic: bool = False, graph: bool = False, segmented: bool = True):
+                 deterministic: bool = False, segmented: bool = True, experimental_graph: bool = False):
         """Parameters as Model holds them (model.hpp): means [N,3], log-scales [N,3], raw quats
         [N,4], opacity logits [N] or [N,1], featuresDc [N,3], featuresRest [N,K-1,3].
         segmented: on frames of few tiles the compositing backward runs the pieces of a tile's list side by
-        side from checkpoints the forward leaves (cabi.Checkpoints; scheduling only).  The captured iteration
-        (graph=True) does not use it: its launch grid would follow every frame's longest list."""
+        side from checkpoints the forward leaves (cabi.Checkpoints; scheduling only).
+        experimental_graph: NOT part of the supported surface (round 6: taken out of it).  Replays the iteration
+        as one captured HIP graph on a stream of its own; pays only below ~1500 Gaussians; a GPU write fault seen
+        in round 4 when replays shared a stream with eager launches was worked around (own stream), never
+        explained (profiles/HISTORY.md).  The building blocks it is made of — gs_adam_step_scheduled,
+        gs_stage_f32, gs_copy_indirect_f32 — are supported and tested eagerly (tests/test_gpu_train_blocks.py)."""
+        graph = experimental_graph
         self.segmented, self._ckpt = segmented, cabi.Checkpoints()
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a,
                                       dtype=torch.float32).to(device)
         N = means.shape[0]
         K = 1 + (int(features_rest.shape[1]) if features_rest is not None else 0)
+        # (an index-less 'cuda' would compare unequal to the tensors' 'cuda:0')
+        device = torch.empty(0, device=device).device
         self.N, self.K, self.dev = N, K, device
         self.max_steps, self.ssim_weight = max_steps, ssim_weight
         self.params = dist.GradBuffer(N, K, device)   # same layout, holds the parameters
@@ -144,7 +151,7 @@ class Trainer:
         # intrinsics, id-list capacity) on a stream of its own; see _train_step_graph.
         self.graph = bool(graph) and self.world == 1
         if self.graph and reference_alpha_reset:
-            raise ValueError("graph=True keeps one optimiser step count for all groups: not with "
+            raise ValueError("experimental_graph=True keeps one optimiser step count for all groups: not with "
                              "reference_alpha_reset (the opacities' Adam state lags behind there)")
         self._graphs = {}
         self._buf_gen = 0            # bumped whenever a device buffer a captured graph points at is replaced
@@ -246,11 +253,9 @@ class Trainer:
             f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd, checkpoints=ck)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
-        # the plan as THIS forward used it (a later render() re-plans the shared object); the generation counter
-        # tells backward() whether another forward has overwritten the shared record buffer since
-        self._ckpt_generation = getattr(self, "_ckpt_generation", 0) + (1 if ck is not None else 0)
+        # the plan as THIS forward used it (a later render() re-plans the shared object).  backward() differentiates
+        # the LAST render(): the context, the plan and the records are replaced together (self._ctx)
         f["checkpoints"] = ck.frozen() if ck is not None else None
-        f["checkpoints_generation"] = self._ckpt_generation
         # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
         # no gradient and afterTrain returns at once (model.cpp:315)
         self._visible = b.num_isects > 0
@@ -260,9 +265,6 @@ class Trainer:
     def backward(self, v_rgb):
         """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
-        if f.get("checkpoints") is not None and f["checkpoints_generation"] != self._ckpt_generation:
-            raise RuntimeError("Trainer.backward: another render() has overwritten the checkpoint records of the "
-                               "frame being differentiated; call backward() before the next render()")
         keep = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0)
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
                                 flags | keep, workspace=self.bwd_ws, img_raw=f["img"],
@@ -427,7 +429,7 @@ class Trainer:
         # (a uint8 or strided target would be read as garbage or out of bounds)
         if not (isinstance(gt, torch.Tensor) and gt.is_cuda and gt.device == torch.device(self.dev)
                 and gt.dtype == torch.float32 and gt.is_contiguous() and gt.numel() == H * W * 3):
-            raise ValueError("Trainer(graph=True): gt must be a contiguous float32 [H, W, 3] tensor on %s, got %s"
+            raise ValueError("Trainer(experimental_graph=True): gt must be a contiguous float32 [H, W, 3] tensor on %s, got %s"
                              % (self.dev, (tuple(gt.shape), gt.dtype, gt.device) if isinstance(gt, torch.Tensor) else type(gt)))
         self._g_gt_ptr_np[0] = gt.data_ptr()
         self._g_gt_ref = gt          # (alive until the iteration that reads it has completed)
@@ -491,11 +493,140 @@ class Trainer:
         if self.graph:
             return self._train_step_graph(cam, gt, background, degrees_to_use)
         rgb = self.render(cam, background, degrees_to_use)
+        self._cot_div = self.world
         loss, v_rgb = cabi.main_loss(rgb, gt, self.ssim_weight, 1.0 / self.world, True,
                                      out=self.loss_out, workspace=self.loss_ws)
         self.backward(v_rgb)
         self.optimizer_step()
         return loss
+
+
+    # ---- a batch of cameras per optimiser step on this rank (two in flight) --------------------------
+    def _batch_lanes(self, W, H):
+        from .pipeline import CameraLane
+
+        if getattr(self, "_lane_key", None) != (W, H, self.N):
+            self._lanes = [CameraLane(self.N, W, H, self.dev, clamped=True, loss=True) for _ in range(2)]
+            self._lane_key = (W, H, self.N)
+        return self._lanes
+
+    def train_step_batch(self, cams, gts, background, degrees_to_use: int, step: int | None = None,
+                         step_optimizer: bool = True, serial: bool = False):
+        """One optimiser step over the cameras `cams` (same image size) with ground truths `gts` on THIS rank — on
+        several ranks every rank brings its own batch of the same length, and the step's loss is the mean over
+        all world x len(cams) cameras.  Generalises the per-image body of opensplat.cpp:151-170: render, loss and
+        backward of every camera, ONE gradient exchange, ONE optimiser step.
+
+        Two cameras are in flight (pipeline.two_in_flight): camera j + 1's per-Gaussian forward, binning,
+        compositing forward and loss run on a second stream under camera j's compositing backward.  The
+        gradients are accumulated in camera order (GS_FLAG_ACCUMULATE_GRADS behind an event): the sums of the
+        serial loop, bit-identical with Trainer(deterministic=True) (serial=True runs that loop, for tests).
+        Factored exchange: every camera's colour-cotangent all-gather starts behind ITS backward and travels under
+        the next camera; one geometry all-reduce closes the batch (dist.FactoredExchange).
+
+        step: the iteration number, when the caller runs after_train(step) afterwards — the densification
+        statistics (model.cpp:317-337) are then accumulated here, camera by camera in camera order, exactly as a
+        sequence of single-camera iterations would, and after_train(step) only takes the refinement decisions.
+        Returns the device tensor [len(cams), 3] of {mainLoss, l1, ssim} per camera (no host sync).  The pieces
+        schedule of small frames (segmented) is not used for batches."""
+        from .pipeline import two_in_flight
+
+        assert len(cams) == len(gts) and len(cams) >= 1
+        assert not self.graph, "a captured iteration holds one camera"
+        W, H = cams[0]["W"], cams[0]["H"]
+        assert all(c["W"] == W and c["H"] == H for c in cams), "one image size per batch"
+        self._buffers(W, H)
+        lanes = self._batch_lanes(W, H)
+        c, N = len(cams), self.N
+        flags = cabi.GS_FLAG_LOGIT_OPACITY | cabi.GS_FLAG_CLAMP_IMAGE
+        keep = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0)
+        scale = 1.0 / (self.world * c)
+        losses = torch.empty((c, 3), device=self.dev, dtype=torch.float32)
+        rest = self.features_rest if self.K > 1 else None
+        host = []
+        for cam in cams:
+            vm = np.asarray(cam["viewmat"], dtype=np.float32)
+            host.append((cabi.make_camera(cam["viewmat"], cam["projmat"], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                                          W, H, flags=cabi.GS_CAM_LOG_SCALES),
+                         (-vm[:3, :3].T @ vm[:3, 3]).astype(np.float32)))        # model.cpp:95
+        fx = None
+        if self.factored:
+            if self.fx is None or self.fx.N != N or self.fx.cpr != c:
+                self.fx = dist.FactoredExchange(N, self.K, c, self.dev)
+            fx = self.fx
+            pos_dev = []
+            for cam, (_, cam_pos) in zip(cams, host):      # (one synchronising upload per camera, ever)
+                key = (np.asarray(cam["viewmat"], dtype=np.float32).tobytes(), str(self.dev))
+                hit = cam.get("_cam_pos_dev")
+                if hit is None or hit[0] != key:
+                    hit = cam["_cam_pos_dev"] = (key, torch.from_numpy(cam_pos).to(self.dev))
+                pos_dev.append(hit[1])
+        collect = step is not None and step < self.stop_split_at
+        first_stats = [collect and self._stats is None]
+        if first_stats[0]:
+            self._stats = tuple(torch.zeros(N, device=self.dev, dtype=torch.float32) for _ in range(3))
+
+        def front(L, j):
+            gcam, cam_pos = host[j]
+            with torch.cuda.stream(L.stream):
+                L.g = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
+                                            self.features_dc, rest, cam_pos, degrees_to_use, flags, out=L.gfwd)
+                L.b = cabi.bin_and_sort(W, H, None, L.g["depths"], None, None, None, None, None, L.ws,
+                                        speculative=True, packed=L.g["packed"])
+                L.f = cabi.rasterize_forward(W, H, L.b, background, flags, out=L.fwd)
+                L.loss, L.v_rgb = cabi.main_loss(L.f["img_clamped"], gts[j], self.ssim_weight, scale, True,
+                                                 out=L.loss_out, workspace=L.loss_ws)
+
+        def back(L, j, prev):
+            gcam, cam_pos = host[j]
+            with torch.cuda.stream(L.stream):
+                losses[j].copy_(L.loss)
+                cabi.rasterize_backward(W, H, N, L.b, background, L.f["final_Ts"], L.f["final_idx"], L.v_rgb,
+                                        flags | keep, workspace=L.bwd_ws, img_raw=L.f["img"])
+                if prev is not None:
+                    L.stream.wait_event(prev.done)      # the flat gradient buffer and the statistics: camera order
+                gout, gflags = self.gout, flags | (cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0)
+                if fx is not None:
+                    gout = dict(self.gout, v_dc=fx.v_color(j), v_rest=None)
+                    fx.set_cam_pos(j, pos_dev[j])
+                    gflags |= cabi.GS_FLAG_EMIT_VCOLOR
+                cabi.gaussian_backward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits, cam_pos,
+                                       self.K, degrees_to_use, L.g["radii"], L.g["rgb_raw"], L.bwd_ws, gout, gflags,
+                                       v_xy=L.v_xy)
+                if fx is not None:
+                    fx.start_camera(j)
+                if collect:
+                    # (only rank 0's first camera takes the "first iteration" branch: see after_train)
+                    cabi.densify_stats(L.v_xy, L.g["radii"], float(max(H, W)),
+                                       first_stats[0] and j == 0 and self.rank == 0, *self._stats)
+                L.done.record(L.stream)
+
+        seen = [False]
+
+        def validate(L):
+            ok = cabi.validate_binning(L.b)
+            seen[0] = seen[0] or (ok and L.b.num_isects > 0)
+            return ok
+
+        last = two_in_flight(lanes, c, front, validate, back, serial=serial)
+        # the exchange, consumed bucket by bucket by optimizer_step() like backward()'s
+        if fx is not None:
+            fx.start(self.grads)
+            sh = self.grads.sh_numel
+            self._pending = [(0, sh, lambda: fx.finish_sh(self.grads, self.means, degrees_to_use)),
+                             (sh, self.grads.flat.numel(), fx.finish_geometry)]
+        else:
+            self._pending = [(lo, hi, (lambda w=w: dist.wait_all(w)))
+                             for lo, hi, w in dist.allreduce_buckets_async(self.grads, self.grad_buckets)] \
+                if (self.world > 1 or self.bucket_single_rank) else None
+        self._visible = seen[0]                     # (some camera of the batch saw a Gaussian)
+        self._batch_stats_step = step if collect else None
+        self._cot_div = self.world * c              # what the cameras' cotangents were divided by (see _refine)
+        self._ctx = (host[-1][0], host[-1][1], last.g, last.g["rgb_raw"], last.b, last.f, flags, degrees_to_use,
+                     background, W, H)
+        if step_optimizer:
+            self.optimizer_step()
+        return losses
 
     # ---- Model::afterTrain (model.cpp:311-494) -------------------------------------------------
     def _param_list(self, buf):
@@ -509,7 +640,9 @@ class Trainer:
         N, dev = self.N, self.dev
         if not self._visible and self.world == 1:   # model.cpp:315 (with a batch, another rank's
             return None                             # camera may see Gaussians: the step counts)
-        if step < self.stop_split_at:   # model.cpp:317-337
+        if getattr(self, "_batch_stats_step", None) == step:
+            self._batch_stats_step = None            # train_step_batch(step=...) has accumulated this step's cameras
+        elif step < self.stop_split_at:   # model.cpp:317-337
             first = self._stats is None
             if first:
                 self._stats = tuple(torch.zeros(N, device=dev, dtype=torch.float32) for _ in range(3))
@@ -551,7 +684,9 @@ class Trainer:
         cfg = cabi.densify_config(W, H, self.densify_grad_thresh, self.densify_size_thresh,
                                   step < self.stop_screen_size_at, self.split_screen_size,
                                   step > self.refine_every * self.reset_alpha_every)
-        cfg = rank_merged_config(cfg, self.world)
+        # (the statistics are linear in the cotangent scale: 1 / world per camera of a train_step, 1 / (world c)
+        # per camera of a train_step_batch)
+        cfg = rank_merged_config(cfg, getattr(self, "_cot_div", self.world))
         gen = torch.Generator(device=self.dev).manual_seed(1_000_003 * step)  # same on every rank
         samples_fn = lambda n: torch.randn((2 * n, 3), device=self.dev, generator=gen)
         new = {}

@@ -9,6 +9,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+from opensplat_amd.pipeline import HotPath as Pipeline  # noqa: E402
 from opensplat_amd import cabi, scenes  # noqa: E402
 
 cfg = "c2"
@@ -17,7 +18,7 @@ if argv and argv[0] in ("c2", "c3"):
     cfg, argv = argv[0], argv[1:]
 flag_sets = [int(a, 16) for a in argv] or [0x0, 0x100]
 s = scenes.config_c3() if cfg == "c3" else scenes.config_c2()
-pipe = bench.Pipeline(s, torch.device("cuda:0"), 0, stage_kernels=True)
+pipe = Pipeline(s, torch.device("cuda:0"), 0, stage_kernels=True)
 pipe.step()
 torch.cuda.synchronize()
 p = pipe.proj

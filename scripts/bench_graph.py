@@ -24,12 +24,12 @@ def main():
     a = ap.parse_args()
     import torch
 
-    import bench
+    from opensplat_amd.pipeline import HotPath as Pipeline
     from opensplat_amd import cabi, scenes
 
     dev = torch.device("cuda", 0)
     s = scenes.camera_scene(6000, 384, 288, K=16, seed=4) if a.small else scenes.config_c2()
-    pipe = bench.Pipeline(s, dev, 0)
+    pipe = Pipeline(s, dev, 0)
     for _ in range(5):
         pipe.step()
     torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Training iterations per second, launch by launch against Trainer(graph=True) (one captured HIP graph per
+"""Training iterations per second, launch by launch against Trainer(experimental_graph=True) (one captured HIP graph per
 iteration), on frames of growing size: where the iteration is launch-bound and where it is not.
 
     python scripts/bench_train_graph.py [--iters 600] > profiles/train_graph_r04.json
@@ -40,7 +40,7 @@ def main():
         init = sfm_like_init(gt, n_init, K, rs)
         row = {"gaussians": n_init, "width": W, "height": H}
         for mode in ("launches", "graph"):
-            T = train.Trainer(*init, dev, max_steps=10 * a.iters, graph=(mode == "graph"), refine_every=10 ** 9)
+            T = train.Trainer(*init, dev, max_steps=10 * a.iters, experimental_graph=(mode == "graph"), refine_every=10 ** 9)
             pcs = [T.prepare_camera(c) for c in cams] if mode == "graph" else cams
             for step in range(1, 21):                      # warm-up (capacity, capture)
                 T.train_step(pcs[step % 8], images[step % 8], bg, 3)

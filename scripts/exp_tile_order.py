@@ -16,6 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from opensplat_amd.pipeline import HotPath as Pipeline  # noqa: E402
 from opensplat_amd import cabi, scenes  # noqa: E402
 
 
@@ -25,7 +26,7 @@ def main():
     if which == "hot":
         s = scenes.camera_scene(1_000_000, 1920, 1080, K=16, seed=1, sigma_px=(0.5, 4.0), name="C2", hot=(0.02, 48))
     dev = torch.device("cuda:0")
-    pipe = bench.Pipeline(s, dev, 0)
+    pipe = Pipeline(s, dev, 0)
     for _ in range(3):
         pipe.step()
     torch.cuda.synchronize()

@@ -62,7 +62,7 @@ def main():
                          "from what opensplat_amd.colmap reads back: poses normalised like the reference, "
                          "Model-style initialisation from the sparse points (row f3)")
     ap.add_argument("--graph", action="store_true",
-                    help="Trainer(graph=True): every iteration replayed as one captured HIP graph")
+                    help="Trainer(experimental_graph=True): every iteration replayed as one captured HIP graph")
     ap.add_argument("--no-segments", action="store_true",
                     help="Trainer(segmented=False): the one-pass compositing backward on every frame")
     ap.add_argument("--reference-schedules", action="store_true",
@@ -112,7 +112,7 @@ def main():
     sched = dict(sh_degree_interval=1000, resolution_schedule=3000) if a.reference_schedules else \
         dict(sh_degree_interval=max(a.iters // 4, 1), resolution_schedule=max(a.iters // 6, 1))
     T = train.Trainer(*init, DEV, max_steps=a.iters, ssim_weight=0.2, num_cameras=n_train,
-                      morton_order=True, num_downscales=a.num_downscales, graph=a.graph,
+                      morton_order=True, num_downscales=a.num_downscales, experimental_graph=a.graph,
                       segmented=not a.no_segments, **sched)
     n_initial = T.N
     sh_interval = T.sh_degree_interval

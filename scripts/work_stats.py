@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+from opensplat_amd.pipeline import HotPath as Pipeline  # noqa: E402
 from opensplat_amd import cabi, scenes  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
@@ -21,7 +22,7 @@ s = {"C1": scenes.config_c1, "C2": scenes.config_c2, "C3": scenes.config_c3}[cfg
 if s.v_out is None:
     import numpy as np
     s.v_out = np.random.RandomState(3).uniform(-1, 1, (s.H, s.W, 3)).astype(np.float32)
-pipe = bench.Pipeline(s, torch.device("cuda:0"), 0)
+pipe = Pipeline(s, torch.device("cuda:0"), 0)
 l = cabi.lib()
 buf = (C.c_ulonglong * 16)()
 pipe.step()

@@ -31,8 +31,28 @@ def main():
     s = small_c4(rank, N=6000, W=208, H=128)
     T = Trainer(*scenes.raw_parameters(s), device=dev, exchange=os.environ.get("GSPLAT_TEST_EXCHANGE", "auto"),
                 sh_degree_interval=1)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
     gt = torch.from_numpy(np.random.RandomState(100 + rank).uniform(0, 1, (s.H, s.W, 3)).astype(np.float32)).to(dev)
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    cpr = int(os.environ.get("GSPLAT_TEST_CPR", "1"))
+    if cpr > 1:
+        # a batch of cpr cameras per rank and optimiser step (Trainer.train_step_batch, two in flight)
+        cams = [camera_dict(small_c4(rank * cpr + j, N=6000, W=208, H=128)) for j in range(cpr)]
+        gts = [torch.from_numpy(np.random.RandomState(100 + rank * cpr + j).uniform(0, 1, (s.H, s.W, 3))
+                                .astype(np.float32)).to(dev) for j in range(cpr)]
+        T.train_step_batch(cams, gts, bg, 3, step_optimizer=False)
+        for lo, hi, ready in (T._pending or []):
+            ready()
+        T._pending = None
+        torch.cuda.synchronize()
+        np.save(sys.argv[1] + "_grads_rank%d.npy" % rank, T.grads.flat.cpu().numpy())
+        for it in range(3):
+            T.train_step_batch(cams, gts, bg, 3)
+        torch.cuda.synchronize()
+        np.save(sys.argv[1] + "_params_rank%d.npy" % rank, T.params.flat.cpu().numpy())
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     cam = camera_dict(s)
     # iteration 1 by hand: backward + the exchange, gradients kept before Adam touches anything
     rgb = T.render(cam, bg, 3)

@@ -23,7 +23,7 @@ def case_bit_for_bit():
     order = [0, 1, 2, 3, 4, 2, 0]
     deg = lambda s: min(s // 9, 1)
     ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
-    got = train.Trainer(*init, dev, graph=True, **kw)
+    got = train.Trainer(*init, dev, experimental_graph=True, **kw)
     n_ref = _run(ref, cams, images, bg, 40, order, deg=deg)
     n_got = _run(got, cams, images, bg, 40, order, deg=deg)
     assert n_ref == n_got and len(n_ref) >= 2, (n_ref, n_got)          # refinements happened, identically
@@ -46,7 +46,7 @@ def case_overflow():
     near = make_camera((0.55, 0.05, 0.3), W, H)
     kw = dict(max_steps=100, deterministic=True)
     ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
-    got = train.Trainer(*init, dev, graph=True, **kw)
+    got = train.Trainer(*init, dev, experimental_graph=True, **kw)
     near_img = ref.render(near, bg, 1).clone() * 0.5
     seq = [(cams[0], images[0]), (cams[0], images[0]), (cams[1], images[1]), (near, near_img),
            (cams[2], images[2]), (near, near_img), (cams[0], images[0])]
@@ -76,7 +76,7 @@ def case_resolution():
             for im in images]
     kw = dict(max_steps=100, deterministic=True)
     ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
-    got = train.Trainer(*init, dev, graph=True, **kw)
+    got = train.Trainer(*init, dev, experimental_graph=True, **kw)
     for T in (ref, got):
         for s in range(10):
             ci = s % len(cams)
@@ -98,7 +98,7 @@ def case_eager_renders():
     dev, cams, images, init, bg = _capture(K=16)
     kw = dict(max_steps=400, deterministic=True)
     ref = train.Trainer(*init, dev, segmented=False, **kw)   # (the captured iteration runs the one-pass backward)
-    got = train.Trainer(*init, dev, graph=True, **kw)
+    got = train.Trainer(*init, dev, experimental_graph=True, **kw)
     for T in (ref, got):
         pcs = [T.prepare_camera(c) for c in cams] if T.graph else cams
         for s in range(1, 241):

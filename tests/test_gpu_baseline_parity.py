@@ -2,7 +2,7 @@
 
 What bench.py times is `Pipeline.step_fused`: gs_gaussian_forward -> binning -> compositing forward
 -> compositing backward (records kept) -> gs_gaussian_backward.  These tests run exactly that object
-(`bench.Pipeline`) and compare it with the plain-C restatement of rasterizer/gsplat-cpu
+(`opensplat_amd.pipeline.HotPath`) and compare it with the plain-C restatement of rasterizer/gsplat-cpu
 (oracle/gsplat_oracle.c, pinned to the compiled reference by the CPU suite) — never with another
 HIP kernel:
 
@@ -23,7 +23,7 @@ chain: the device projection differs from the oracle's by fp32 round-off (xys 2e
 can flip an alpha >= 1/255 or T <= 1e-4 decision for a handful of pixels: at most max(4, 2e-5 P)
 pixels may differ by more than 1e-5, and every gradient tensor must satisfy
 max|d| / max|ref| < 2e-5 (measured: 0 flipped pixels and 3e-7 .. 2e-6 on every configuration,
-profiles/parity_r04.json; the tests rewrite gpurun_out/parity_r04.json).
+profiles/parity_r06.json; the tests rewrite gpurun_out/parity_r06.json).
 """
 import json
 import os
@@ -38,6 +38,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = {}
+# the measured values of THIS round's kernels: written to gpurun_out/, copied to profiles/ by the round script.  The
+# name carries the round so that a table in DESIGN.md cannot cite numbers measured on older kernels.
+PARITY_REPORT = "parity_r06.json"
 
 
 def _report(name, **kv):
@@ -45,7 +48,7 @@ def _report(name, **kv):
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "parity_r04.json"), "w") as f:
+        with open(os.path.join(d, PARITY_REPORT), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -85,12 +88,12 @@ def oracle_chain(O, s, window=None, v_out=None, scales=None, quats=None, opaciti
 
 
 def run_timed_path(s, flags=0):
-    """bench.py's Pipeline (the object whose step() is timed), one step; returns it."""
+    """opensplat_amd.pipeline.HotPath (the object whose step() bench.py times), one step; returns it."""
     import torch
 
-    import bench
+    from opensplat_amd.pipeline import HotPath
 
-    pipe = bench.Pipeline(s, torch.device("cuda", 0), flags)
+    pipe = HotPath(s, torch.device("cuda", 0), flags)
     pipe.step()
     pipe.step()   # second step: the speculative id-list capacity is now the validated one
     torch.cuda.synchronize()

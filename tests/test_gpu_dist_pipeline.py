@@ -1,5 +1,5 @@
 """-m gpu: the multi-rank path THROUGH THE REAL PIPELINE.  Two ranks (gloo, sharing the one GPU of
-the test box) render two different C4-style cameras over the same Gaussians with bench.Pipeline —
+the test box) render two different C4-style cameras over the same Gaussians with opensplat_amd.pipeline.HotPath —
 gs_gaussian_forward ... gs_gaussian_backward writing into the flat GradBuffer, then the gradient
 exchange (flat all-reduce, or the factored exchange: geometry all-reduce + colour-cotangent
 all-gather + local SH backward over all cameras) — and the exchanged buffer must equal the sum of
@@ -30,7 +30,7 @@ def test_two_ranks_allreduced_gradients_equal_the_sum_of_single_rank_runs(tmp_pa
 
     import torch
 
-    import bench
+    from opensplat_amd.pipeline import HotPath
     from tests.dist_pipeline_worker import small_c4
 
     with socket.socket() as so:
@@ -50,7 +50,7 @@ def test_two_ranks_allreduced_gradients_equal_the_sum_of_single_rank_runs(tmp_pa
     dev = torch.device("cuda", 0)
     flats = []
     for cam in range(2 * cpr):
-        pipe = bench.Pipeline(small_c4(cam), dev, 0)
+        pipe = HotPath(small_c4(cam), dev, 0)
         pipe.step()
         pipe.step()
         torch.cuda.synchronize()
@@ -100,13 +100,13 @@ def test_gradient_accumulation_over_a_rank_s_camera_batch():
     of both cameras' gradients in the flat buffer (what ONE all-reduce then exchanges)."""
     import torch
 
-    import bench
+    from opensplat_amd.pipeline import HotPath
     from opensplat_amd import scenes
     from tests.dist_pipeline_worker import small_c4
 
     dev = torch.device("cuda", 0)
     s0 = small_c4(0)
-    pipe = bench.Pipeline(s0, dev, 0)
+    pipe = HotPath(s0, dev, 0)
     cams = [scenes.yaw_camera(s0.W, s0.H, y, 1.0, 100.0) for y in scenes.C4_YAWS[:2]]
     singles = []
     for c in cams:

@@ -4,7 +4,7 @@ The build boxes of rounds 1-4 had one GPU, where RCCL admits one rank only: ever
 and runs the first time a multi-GPU box sees the repo.  What is checked is what the gloo tests
 (tests/test_gpu_dist_pipeline.py, tests/test_dist_gloo.py) check on one device — now with one rank per GPU,
 backend "nccl" (= RCCL over xGMI):
-  * two ranks through bench.Pipeline, flat and factored exchange: the exchanged gradient buffer equals the
+  * two ranks through opensplat_amd.pipeline.HotPath, flat and factored exchange: the exchanged gradient buffer equals the
     sum of single-rank runs of the same cameras;
   * `python bench.py --gpus 2` as the driver starts it: one JSON line, n_gpus = 2, both exchanges timed;
   * include/gsplat_dist.h (libgsplat_dist.so) on a two-rank communicator: all-reduce, bucketed all-reduce,
@@ -56,7 +56,7 @@ def _free_port():
 def test_rccl_two_ranks_exchange_equals_the_sum_of_single_rank_runs(tmp_path, mode, cpr):
     import torch
 
-    import bench
+    from opensplat_amd.pipeline import HotPath
     from tests.dist_pipeline_worker import small_c4
 
     prefix = str(tmp_path / mode)
@@ -72,7 +72,7 @@ def test_rccl_two_ranks_exchange_equals_the_sum_of_single_rank_runs(tmp_path, mo
     dev = torch.device("cuda", 0)
     flats = []
     for cam in range(2 * cpr):
-        pipe = bench.Pipeline(small_c4(cam), dev, 0)
+        pipe = HotPath(small_c4(cam), dev, 0)
         pipe.step()
         pipe.step()
         torch.cuda.synchronize()

@@ -7,7 +7,7 @@
   * Trainer(deterministic=True): the compositing backward sums in fixed point, so two whole training runs —
     refinements, SH-degree and resolution changes included — leave the SAME BITS in every parameter.
 
-(The whole iteration replayed as one captured graph on top of these: Trainer(graph=True),
+(The whole iteration replayed as one captured graph on top of these: Trainer(experimental_graph=True),
 tests/test_gpu_train_graph.py.)
 """
 import math

@@ -1,4 +1,4 @@
-"""-m gpu: Trainer(graph=True) — the training iteration replayed as ONE captured HIP graph on a stream of its
+"""-m gpu: Trainer(experimental_graph=True) — the training iteration replayed as ONE captured HIP graph on a stream of its
 own (VERDICT r03 "next" 7; the loop being replaced: opensplat.cpp:151-170).
 
 With deterministic=True the compositing backward sums in fixed point and Adam is bit-exact by construction

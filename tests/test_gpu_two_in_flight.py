@@ -1,4 +1,4 @@
-"""-m gpu: several cameras per step with TWO of them in flight on one GPU (bench.step_two_in_flight: camera j + 1's
+"""-m gpu: several cameras per step with TWO of them in flight on one GPU (opensplat_amd.pipeline.HotPath.step_cameras: camera j + 1's
 per-Gaussian forward, binning and compositing forward on a second stream under camera j's compositing backward).
 The accumulated gradients must be the serial camera loop's — bit for bit under GS_FLAG_DETERMINISTIC (same
 per-camera sums, accumulated in the same camera order) — for two, three and five cameras (lanes re-used)."""
@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 def test_two_cameras_in_flight_accumulate_like_the_serial_loop(ncam):
     import torch
 
-    import bench
     from opensplat_amd import cabi
+    from opensplat_amd.pipeline import HotPath
 
     s = scenes.camera_scene(30000, 640, 360, K=16, seed=5, znear=0.01, zfar=100.0)
     dev = torch.device("cuda:0")
-    pipe = bench.Pipeline(s, dev, cabi.GS_FLAG_DETERMINISTIC)
+    pipe = HotPath(s, dev, cabi.GS_FLAG_DETERMINISTIC)
     cams = [scenes.yaw_camera(s.W, s.H, y) for y in (-9.0, -3.0, 2.0, 6.0, 11.0)][:ncam]
 
     def serial():
@@ -33,9 +33,12 @@ def test_two_cameras_in_flight_accumulate_like_the_serial_loop(ncam):
     assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
     assert torch.equal(serial(), ref)                      # the serial loop itself is reproducible
     for _ in range(3):
-        bench.step_two_in_flight(pipe, cams, exchange=False)
+        pipe.step_cameras(cams, exchange=False)
         torch.cuda.synchronize()
         assert torch.equal(pipe.grads.flat, ref)
+    pipe.step_cameras(cams, exchange=False, serial=True)      # the library's own serial loop: the same sums
+    torch.cuda.synchronize()
+    assert torch.equal(pipe.grads.flat, ref)
     # every camera contributed: one camera alone gives other sums
     pipe.set_camera(*cams[0])
     pipe.step_fused(accumulate=False, exchange=False)
