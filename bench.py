@@ -196,9 +196,12 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, kernel_live, profiled_name):
     kernels_profiled  REPLAYED: every gs:: kernel from the committed rocprofv3 passes of the same command
                       (profiles/kernels*.json, scripts/summarize_profile.py): average duration, counter
                       traffic, VALU issue occupancy
-    roofline_valu     REPLAYED: the two compositing kernels are bound by VALU issue, not by HBM: of the issue
-                      slots they fill (valu_busy_frac) the fraction of lanes doing needed work
-                      (live_lane_frac, instrumented build) — useful_frac is their product"""
+    roofline_valu     REPLAYED: the two compositing kernels are bound by VALU issue, not by HBM.  issue_roofline =
+                      wave-instructions x the measured cycles per instruction of a saturated loop in the kernel's
+                      own class mix / (1024 SIMDs x 2.4 GHz) / kernel time (profiles/issue_roofline_r06.json);
+                      valu_busy_frac = the counter ratio SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES over what that
+                      saturated loop reads (an independent derivation of the same thing); live_lane_frac = lanes
+                      doing needed work (instrumented build); useful_frac = issue_roofline x live_lane_frac"""
     # algorithmic bytes per kernel (prefix of the kernel's short name -> bytes per launch)
     kalg = [
         ("k_sh_project_pack16", N * (232 + 12) + N * (44 + 68)),
@@ -252,13 +255,33 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, kernel_live, profiled_name):
             src = "replayed from profiles/%s (rocprofv3, tag %s) — not measured in this run" % (
                 profiled_name, d.get("tag"))
             prof = {"source": src, "kernels": d["kernels"]}
+            # the calibrated issue figures of the same profile (scripts/issue_roofline.py; VERDICT r05: the ratio
+            # SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES has no fixed ceiling of 8 — a saturated plain-fp32 loop reads
+            # 13.2, DPP / compare / SGPR-operand / fp64 loops 7.5, a loop in the forward's class mix 10.8)
+            issue = {}
+            try:
+                issue = json.load(open(os.path.join(ROOT, "profiles", "issue_roofline_r06.json")))["profiles"].get(
+                    profiled_name, {})
+            except Exception:
+                issue = {}
             rv = []
             for k, e in sorted(d["kernels"].items()):
                 if k.startswith("k_rasterize_") and "valu_busy_of_8" in e:
-                    busy = min(e["valu_busy_of_8"] / 8.0, 1.0)
+                    iss = issue.get(k)
                     live = e.get("live_lane_frac")
-                    rv.append({"kernel": k, "source": src, "valu_busy_frac": busy, "live_lane_frac": live,
-                               "useful_frac": None if live is None else busy * live,
+                    busy = None if iss is None else iss["counter_frac_of_saturated"]
+                    rv.append({"kernel": k, "source": src,
+                               # counter reading / the reading of a SATURATED loop of this kernel's class mix
+                               "valu_busy_frac": busy,
+                               "counter_reading": e["valu_busy_of_8"],
+                               "counter_reading_if_saturated": None if iss is None else iss["counter_reading_if_saturated"],
+                               # wave-instructions x measured cycles per instruction of that mixed loop / (1024 SIMDs x
+                               # 2.4 GHz) / kernel time: the same thing derived from instruction count and time alone
+                               "issue_roofline": None if iss is None else iss["issue_roofline"],
+                               "issue_time_us": None if iss is None else iss["issue_time_us"],
+                               "loop_class_mix": None if iss is None else iss["loop_class_mix"],
+                               "live_lane_frac": live,
+                               "useful_frac": None if (live is None or iss is None) else iss["issue_roofline"] * live,
                                "salu_per_valu": e.get("salu_per_valu"),
                                "valu_insts_per_launch": e.get("valu_insts_per_launch"),
                                "steps_per_list_entry": e.get("steps_per_list_entry"),
@@ -518,6 +541,32 @@ def main():
                     "SH degree 3, gradients exchanged over RCCL" % (args.gaussians,
                                                                    world * args.cameras_per_rank,
                                                                    args.cameras_per_rank))
+    if world == 1:
+        workload = workload.replace(", gradients exchanged over RCCL", ", one rank (nothing exchanged)")
+    else:
+        # (the backend actually in use: RCCL on a multi-GPU node, gloo when the ranks share one GPU in the tests)
+        workload = workload.replace("exchanged over RCCL", "exchanged over %s" % ("RCCL" if backend == "nccl" else backend))
+    # a line on anything but the plain scene, order, schedule and exponential says so in its workload string
+    # (a hot-spot line must not wear the baseline's label)
+    variants = []
+    if args.hot:
+        variants.append("hot spot: %g %% of the Gaussians in a 48-px window" % (100 * args.hot))
+    if args.order != "given":
+        variants.append("Gaussians re-ordered: %s" % args.order)
+    if args.fast_exp:
+        variants.append("hardware exp (GS_FLAG_FAST_EXP), not the parity mode")
+    if args.stage_kernels:
+        variants.append("operator-granular stage kernels")
+    if os.environ.get("GSPLAT_BENCH_PIECES", "0") != "0":
+        variants.append("backward in pieces of %s entries" % os.environ["GSPLAT_BENCH_PIECES"])
+    for env in ("GSPLAT_BIN", "GSPLAT_STRIPS_FUSED", "GSPLAT_FWD_FLAGS", "GSPLAT_BWD_FLAGS", "GSPLAT_BWD_PX",
+                "GSPLAT_RECORDS_ZEROED", "GSPLAT_HIP_LIB"):
+        if os.environ.get(env):
+            variants.append("%s=%s" % (env, os.environ[env]))
+    if cfg in ("c2", "c3") and (args.gaussians != 1_000_000 or args.width != 1920 or args.height != 1080):
+        variants.append("non-baseline size")
+    if variants:
+        workload += " + " + "; ".join(variants)
     cpr = args.cameras_per_rank if (world > 1 or cfg == "c4") else 1
     cams = [scenes.yaw_camera(scene.W, scene.H, y) for y in scenes.C4_YAWS]
 
@@ -781,6 +830,14 @@ def main():
             # as 256 pixels per (tile, Gaussian) list entry (the upper bound both kernels are sized by)
             "pixel_gaussian_evals_per_s": {k: 256.0 * M / (v * 1e-3) for k, v in kernel_ms.items() if v > 0},
             "warmup_steps_run": warmup_run,
+            # said where the number is quoted: what --warmup became, and how short the timed region is
+            "timing": {"timed_region_ms": elapsed * 1e3, "warmup_steps_asked": args.warmup,
+                       "warmup_steps_run": warmup_run,
+                       "note": "--warmup W is extended until the clocks have settled (>= %.1f s of steps, in blocks of "
+                               "16): W = %d became %d untimed steps.  The timed region is EXACTLY --steps = %d plain "
+                               "steps = %.1f ms of GPU time between barrier + synchronize pairs — shorter than a "
+                               "utilisation sampler's period; `sustained` (a longer plain block, same code) is the "
+                               "cross-check" % (settle, args.warmup, warmup_run, args.steps, elapsed * 1e3)},
             "sustained": sustained,
             "instrumented_steps": n_inst,
             # which fields were MEASURED IN THIS RUN and which are read back from committed files
