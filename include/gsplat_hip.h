@@ -286,7 +286,7 @@ int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,
  *            one per 4x4-pixel block — gs_raster.hip, backward_wave_q.  Measurement / test bits of
  *            `flags`, not part of the contract: bits 21..22 = 1 / 2 / 3 force one / two / four pixels
  *            per lane with the four-group kernels for every tile; bits 23..24 = 1 / 2 force one / two
- *            list entries per forward step; bits 25..26 = 1 the sixteen-group backward for every
+ *            list entries per forward step, 3 = the chunk-compacting forward of round 6 on full frames; bits 25..26 = 1 the sixteen-group backward for every
  *            frame, 2 the four-group kernels of rounds 2 - 4.)
  *            v_out_alpha may be NULL (OpenSplat always passes zeros,
  *            rasterize_gaussians.cpp:108).  background: float[3] in host OR device memory

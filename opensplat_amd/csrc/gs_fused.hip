@@ -19,7 +19,10 @@
 
 namespace gs {
 
-constexpr int kRec = 16;  // floats per gradient record (gs_raster.hip: kGradRec)
+#ifndef GS_GRAD_REC
+#define GS_GRAD_REC 16
+#endif
+constexpr int kRec = GS_GRAD_REC;  // floats per gradient record (gs_raster.hip: kGradRec)
 
 template <int K>
 __global__ void __launch_bounds__(ShSplit<K>::kBlock)
@@ -243,7 +246,7 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         //      the arithmetic instead of a chain of seven: record, opacity, mean, rgb, radius, mean /
         //      scale, quaternion) ----
         // the gradient record of gs_rasterize_backward: {vx vy vA vB | vC vr vg vb | vo - - -}
-        const float4 ra = records[4 * g + 0], rb = records[4 * g + 1];
+        const float4 ra = records[(kRec / 4) * g + 0], rb = records[(kRec / 4) * g + 1];
         float vo = reinterpret_cast<const float *>(records)[kRec * (size_t)g + 8];
         float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
         const float raw0 = rgb_raw[3 * g + 0], raw1 = rgb_raw[3 * g + 1], raw2 = rgb_raw[3 * g + 2];
@@ -253,9 +256,9 @@ k_gaussian_backward(CamArgs cam, const float *__restrict__ vm_dev, const float *
         const float4_u q4 = reinterpret_cast<const float4_u *>(quats)[g];
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
         if (flags & GS_FLAG_RECORDS_ZEROED) {  // keep the "records are zero between frames" invariant
-            records[4 * g + 0] = zero;
-            records[4 * g + 1] = zero;
-            records[4 * g + 2] = zero;
+            records[(kRec / 4) * g + 0] = zero;
+            records[(kRec / 4) * g + 1] = zero;
+            records[(kRec / 4) * g + 2] = zero;
         }
         if (flags & GS_FLAG_LOGIT_OPACITY) {  // d sigmoid: s (1 - s), model.cpp:215
             const float sg = 1.0f / (1.0f + expf(-logit));

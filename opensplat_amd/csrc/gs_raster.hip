@@ -74,10 +74,20 @@ constexpr int kChunk = 64;  // entries staged per pass == wave width
 // ballots, like backward_wave_q's sixteen) instead of walking four 64-bit SGPR masks with s_ff1: twenty scalar
 // instructions per step less on a kernel whose one scalar unit per CU is a co-bottleneck — 169.5 -> 163.5 us at
 // C2, 1.146 -> 1.125 ms at C3, same bits (round 5; 0 = the scalar walk, for measurements)
+#ifndef GS_FWD_COMPACT
+#define GS_FWD_COMPACT 0   // 1: full frames take k_rasterize_forward_c (round 6; measured, not the default)
+#endif
 #ifndef GS_FWD_QWALK
 #define GS_FWD_QWALK 1
 #endif
-constexpr int kGradRec = 16;  // floats per Gaussian in the backward's gradient records (64 B)
+// floats per Gaussian in the backward's gradient records: nine are payload {vx vy vA vB | vC vr vg vb | vo}.
+// 16 (64 B: a record never straddles a cache line) or 12 (48 B: a quarter less memset, atomic write-back and read
+// traffic, two records in eight straddle a 128-byte line) — measured in round 6, profiles/HISTORY.md.
+#ifndef GS_GRAD_REC
+#define GS_GRAD_REC 16
+#endif
+constexpr int kGradRec = GS_GRAD_REC;
+static_assert(kGradRec == 12 || kGradRec == 16, "records are whole float4s holding nine floats");
 
 // Optional work counters (build with -DGS_STATS; never in the shipped library): per launch totals of
 // [0] steps  [1] steps with a needing lane  [2] needing lanes  [3] (block, entry) pairs walked
@@ -551,6 +561,200 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         final_Ts[pix] = T;
         final_idx[pix] = last;
         if (CK) ckpt[0] = record(invG);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the full-frame forward with the chunk COMPACTED before it is staged (k_rasterize_forward_c).
+// A quadrant wave of k_rasterize_forward stages its tile's list 64 entries at a time although only the
+// entries whose coverage mask touches its 8 x 8 pixels are gathered and walked — 43 % of them at C2: a
+// wave runs 2.3 chunks (two barriers, four ballots, a queue build each) for every 64 entries it walks, and
+// its four groups share out ~27 entries per chunk, whose longest queue sets the chunk's steps.  Here the
+// touching entries are collected first — (id, list index, touch bits) appended to a ring in LDS by ballot +
+// mbcnt, 64-entry windows of the list at a time, the windows' ids and masks loaded three windows ahead — and a
+// chunk is the next 64 ring entries: every staged slot is walked, the four queues hold 64 entries' worth.
+// Per pixel the entries arrive in list order with the same arithmetic: the image, final_Ts and final_idx
+// (the LIST index, kept beside the slot) are bit for bit k_rasterize_forward's
+// (tests/test_gpu_forward_compact.py).  ILP = 1, no checkpoints: full frames.  Measured in round 6: 162 -> 160 us
+// at C2, 1119 -> 1191 us at C3 — selected by flag bits 23..24 = 3 only (profiles/HISTORY.md).
+constexpr int kRing = 128;   // ring capacity: at most 63 left over + 64 appended
+template <bool EXACT>
+__global__ void __launch_bounds__(64)
+k_rasterize_forward_c(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
+                      const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
+                      const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
+                      float bg2, const float *__restrict__ bg_dev, float *__restrict__ out_img,
+                      float *__restrict__ final_Ts, int32_t *__restrict__ final_idx,
+                      float *__restrict__ out_clamped) {
+    __shared__ SRec stage[kChunk + 1];
+    __shared__ uint64_t exp_tab[EXACT ? kExpTabLds : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t fq[4 * kChunk + 16];   // [group][rank] -> slot
+    __shared__ int32_t ring_id[kRing];
+    __shared__ uint32_t ring_meta[kRing];      // (list index - range.x) << 4 | touch bits
+    __shared__ int32_t slot_idx[kChunk];       // list index of the staged slots
+    const int lane = threadIdx.x;
+    int tile, qx0, qy0;
+    if (!decode_wave<1>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
+    if (bg_dev) { bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2]; }
+    if (EXACT) load_exp_table(exp_tab, lane, 64);
+    if (lane == 0) stage_sentinel(&stage[kChunk]);
+    const int grp = lane >> 4, li = lane & 15;
+    const int px = qx0 + 4 * (grp & 1) + (li & 3), py = qy0 + 4 * (grp >> 1) + (li >> 2);
+    const bool inimg = px < W && py < H;
+    const float pxf = (float)px;
+    float pyf = inimg ? (float)py : qnan();   // NaN once the pixel is finished (or outside the image)
+    float T = 1.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    int last = -1, le = -1;
+    const int2 range = bins[tile];
+    const int ox = qx0 & (GS_TILE - 1), oy = qy0 & (GS_TILE - 1);
+    // ---- the list's windows, three ahead in registers: {id, mask} of entry cursor + 64 k + lane ----
+    int cursor = range.x;                      // first entry of window 0
+    int32_t wid0 = 0, wid1 = 0, wid2 = 0;
+    uint32_t wm0 = 0u, wm1 = 0u, wm2 = 0u;
+    auto load_window = [&](int first, int32_t &id, uint32_t &m) {
+        id = 0; m = 0u;
+        if (first + lane < range.y) { id = ids[first + lane]; m = masks[first + lane]; }
+    };
+    load_window(cursor, wid0, wm0);
+    load_window(cursor + kChunk, wid1, wm1);
+    load_window(cursor + 2 * kChunk, wid2, wm2);
+    int head = 0, count = 0;                   // ring: entries [head, head + count)
+    // append windows until a chunk's worth is in the ring (or the list is exhausted)
+    auto fill = [&]() {
+        while (count < kChunk && cursor < range.y) {
+            const uint32_t t = touch_from_mask<1>(wm0, ox, oy);   // (mask 0 beyond the list: no touch)
+            const uint64_t m = __builtin_amdgcn_ballot_w64(t != 0u);
+            if (t) {
+                const int pos = (head + count + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (kRing - 1);
+                ring_id[pos] = wid0;
+                ring_meta[pos] = ((uint32_t)(cursor + lane - range.x) << 4) | t;
+            }
+            count += __builtin_popcountll(m);
+            cursor += kChunk;
+            wid0 = wid1; wm0 = wm1; wid1 = wid2; wm1 = wm2;
+            load_window(cursor + 2 * kChunk, wid2, wm2);
+        }
+    };
+    // the next chunk of this lane, gathered one chunk ahead
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    uint32_t nmeta = 0u;
+    int nb = 0;
+    auto take = [&]() {
+        wave_sync();                            // the ring entries fill() wrote, for other lanes
+        nb = min(count, kChunk);
+        nmeta = 0u;
+        if (lane < nb) {
+            const int pos = (head + lane) & (kRing - 1);
+            const size_t g = (size_t)ring_id[pos];
+            nmeta = ring_meta[pos];
+            n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
+        }
+        head = (head + nb) & (kRing - 1);
+        count -= nb;
+        wave_sync();                            // (before fill() overwrites ring slots)
+    };
+    fill();
+    take();
+    while (nb > 0) {
+        const uint64_t alive = __builtin_amdgcn_ballot_w64(pyf == pyf);
+        if (alive == 0ull) break;
+        __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
+        const uint32_t touch = nmeta & 15u;
+        if (touch) {
+            stage[lane].p0 = n0;
+            stage[lane].p1 = n1;
+            stage[lane].p2 = n2;
+            slot_idx[lane] = (int32_t)(nmeta >> 4);
+        }
+        uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
+        uint64_t m1 = (alive & 0x00000000FFFF0000ull) ? __builtin_amdgcn_ballot_w64((touch & 2u) != 0u) : 0ull;
+        uint64_t m2 = (alive & 0x0000FFFF00000000ull) ? __builtin_amdgcn_ballot_w64((touch & 4u) != 0u) : 0ull;
+        uint64_t m3 = (alive & 0xFFFF000000000000ull) ? __builtin_amdgcn_ballot_w64((touch & 8u) != 0u) : 0ull;
+        int nsteps = 0;
+        {
+            reinterpret_cast<uint32_t *>(fq)[lane] = kChunk * 0x01010101u;
+            if (lane < 4) reinterpret_cast<uint32_t *>(fq)[kChunk + lane] = kChunk * 0x01010101u;
+#define GS_FQ(g, m)                                                                                         \
+    if (__builtin_amdgcn_inverse_ballot_w64(m))                                                             \
+        fq[(g) * kChunk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                             \
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =   \
+            (uint8_t)lane;
+            GS_FQ(0, m0) GS_FQ(1, m1) GS_FQ(2, m2) GS_FQ(3, m3)
+#undef GS_FQ
+            nsteps = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
+                         max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
+        }
+        __syncthreads();
+        GS_STAT(3, __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) + __builtin_popcountll(m3));
+        GS_STAT(4, 1);
+        // the next chunk: its ring entries, then its gather — in flight under the walk
+        fill();
+        take();
+        {
+            const uint8_t *myq = &fq[grp * kChunk];
+            int e_next = myq[0];
+            for (int k = 0; k < nsteps; k++) {
+                const int e = e_next;
+                const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
+                e_next = myq[k + 1];
+                const uint32_t sbits = __float_as_uint(q1.z);
+                GS_STAT(0, 1);
+                const float dx = q0.x - pxf, dy = q0.y - pyf;
+                // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217 (same op order)
+                float sg = (q0.z * dx) * dx + (q1.x * dy) * dy;
+                sg = 0.5f * sg;
+                sg = sg + (q0.w * dx) * dy;
+                const uint64_t mbinds = __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u);
+                if (mbinds != 0ull) {
+                    asm volatile("; rectangle binds");
+                    if (__builtin_amdgcn_inverse_ballot_w64(mbinds)) {
+                        const uint32_t rx = __float_as_uint(q1.w), ry = __float_as_uint(q2.w);
+                        const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                        (uint32_t)py >= (ry & 0xFFFFu) && (uint32_t)py < (ry >> 16);
+                        sg = in ? sg + 0.0f : qnan();
+                    }
+                }
+                const uint64_t mneed = __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
+                if (mneed == 0ull) continue;
+                GS_STAT(1, 1);
+                GS_STAT(2, __builtin_popcountll(mneed));
+                const float vis = gs_exp<EXACT>(-sg, exp_tab);
+                float alpha = q1.y * vis;
+                alpha = __builtin_amdgcn_fmed3f(alpha, 0.0f, 0.999f);
+                bool ok = __builtin_amdgcn_inverse_ballot_w64(
+                    mneed & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f)));
+                alpha = ok ? alpha : 0.0f;
+                float nT = T * (1.0f - alpha);
+                if (__builtin_amdgcn_ballot_w64(nT <= 1e-4f) != 0ull) {
+                    asm volatile("; pixel saturates");
+                    if (nT <= 1e-4f) { pyf = qnan(); alpha = 0.0f; nT = T; ok = false; }
+                }
+                const float w = alpha * T;
+                a0 = a0 + w * q2.x;
+                a1 = a1 + w * q2.y;
+                a2 = a2 + w * q2.z;
+                T = nT;
+                le = ok ? e : le;
+            }
+        }
+        last = le >= 0 ? range.x + slot_idx[le] : last;
+        le = -1;
+    }
+    if (inimg) {
+        const size_t pix = (size_t)py * W + px;
+        const float o0 = a0 + T * bg0, o1 = a1 + T * bg1, o2 = a2 + T * bg2;
+        out_img[3 * pix + 0] = o0;
+        out_img[3 * pix + 1] = o1;
+        out_img[3 * pix + 2] = o2;
+        if (out_clamped) {  // fused torch::clamp_max(rgb, 1), model.cpp:222
+            out_clamped[3 * pix + 0] = fminf(o0, 1.0f);
+            out_clamped[3 * pix + 1] = fminf(o1, 1.0f);
+            out_clamped[3 * pix + 2] = fminf(o2, 1.0f);
+        }
+        final_Ts[pix] = T;
+        final_idx[pix] = last;
     }
 }
 
@@ -1165,13 +1369,20 @@ constexpr int kQChunk = 64;
 constexpr int kAccRec = 10;   // floats per accumulator record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
 // dword of component c in an accumulator record
 __device__ __forceinline__ int acc_dword(int c) { return c < 8 ? 2 * (c & 3) + (c >> 2) : 8; }
+// accumulator copies: 1, or 2 = one per checkerboard colour of the blocks — neighbouring blocks hold the same
+// Gaussians at nearly the same queue ranks and meet in the claim; with a copy per colour the model
+// (scripts/sim_bwd_geometry.py: claim_rounds) gives 1.89 rounds per step instead of 2.73, for 2.9 KB more LDS per wave
+#ifndef GS_BWDQ_COPIES
+#define GS_BWDQ_COPIES 1
+#endif
+constexpr int kQCopies = GS_BWDQ_COPIES;
 struct QLds {
     SRecQ stage[kQChunk + 1];
     float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
     alignas(16) uint8_t queue[16 * kQChunk + 16];      // [block][rank] -> slot; (+16: the read one step ahead)
-    alignas(16) float acc[(kQChunk + 1) * kAccRec];    // per-entry sums (entry-major)
+    alignas(16) float acc[kQCopies][(kQChunk + 1) * kAccRec];    // per-entry sums (entry-major)
     int sid[kQChunk];
-    unsigned int tag[kQChunk + 1];                     // the claim: which block adds to an entry this round
+    unsigned int tag[kQCopies][kQChunk + 1];           // the claim: which block adds to an entry this round
 };
 
 template <bool EXACT, bool DET>
@@ -1245,9 +1456,14 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
         stage_sentinel(&lds.stage[CH]);
         lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    float2 *myrec = reinterpret_cast<float2 *>(&lds.acc[lane * kAccRec]);   // (8-byte aligned: 40-byte records)
+    const int copy = kQCopies > 1 ? ((brow + bcol) & 1) : 0;
+    float2 *myrec = reinterpret_cast<float2 *>(&lds.acc[0][lane * kAccRec]);   // (8-byte aligned: 40-byte records)
+    float2 *myrec1 = reinterpret_cast<float2 *>(&lds.acc[kQCopies - 1][lane * kAccRec]);
 #pragma unroll
-    for (int i = 0; i < kAccRec / 2; i++) myrec[i] = make_float2(0.0f, 0.0f);
+    for (int i = 0; i < kAccRec / 2; i++) {
+        myrec[i] = make_float2(0.0f, 0.0f);
+        if (kQCopies > 1) myrec1[i] = make_float2(0.0f, 0.0f);
+    }
 
     int ng = 0;
     uint32_t nmask = 0u;
@@ -1317,7 +1533,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 e_next = myq[k + 1];
                 // the claim's first round: issued here, looked at after the passes
                 const bool active = e < CH;   // (an exhausted group has nothing to add; its dx is NaN)
-                unsigned int *mytag = &lds.tag[e];
+                unsigned int *mytag = &lds.tag[copy][e];
                 if (active) __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
@@ -1327,7 +1543,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
                 const int won = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                float *rec = &lds.acc[e * kAccRec];
+                float *rec = &lds.acc[copy][e * kAccRec];
                 float2 *r2 = reinterpret_cast<float2 *>(rec + 2 * c0);
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
@@ -1441,7 +1657,14 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
         //      (entry, component): the nine lanes of an entry hit ONE 64-byte record ----
         wave_sync();
         if (msk != 0u) {   // (only slots staged THIS chunk, see backward_wave)
-            float *r = &lds.acc[lane * kAccRec];
+            float *r = &lds.acc[0][lane * kAccRec];
+            if (kQCopies > 1) {   // the two colours' sums of this entry
+#pragma unroll
+                for (int i = 0; i < kAccRec / 2; i++) {
+                    const float2 a = myrec[i], b = myrec1[i];
+                    myrec[i] = make_float2(a.x + b.x, a.y + b.y);
+                }
+            }
             const float Ux = r[0], Uy = r[2], Uxx = r[4], Uxy = r[6], Uyy = r[1];
             const float mo = -lds.stage[lane].p1.y;          // v_sigma = -opacity * u
             const float A = lds.rare[lane].z, B = lds.rare[lane].w, C = lds.stage[lane].p2.w;
@@ -1456,7 +1679,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
         for (int i = 0; i < (CH + 6) / 7; i++) {
             const int ent = 7 * i + fj;
             if (fcomp < kAcc && (7 * i + 6 < CH || ent < CH)) {
-                const float v = lds.acc[ent * kAccRec + fdw];
+                const float v = lds.acc[0][ent * kAccRec + fdw];
                 if (v != 0.0f) {
                     const size_t o = (size_t)lds.sid[ent] * kGradRec + fcomp;
                     if (DET)
@@ -1469,7 +1692,10 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
         }
         wave_sync();
 #pragma unroll
-        for (int i = 0; i < kAccRec / 2; i++) myrec[i] = make_float2(0.0f, 0.0f);
+        for (int i = 0; i < kAccRec / 2; i++) {
+            myrec[i] = make_float2(0.0f, 0.0f);
+            if (kQCopies > 1) myrec1[i] = make_float2(0.0f, 0.0f);
+        }
     }
 }
 
@@ -1665,7 +1891,7 @@ k_unpack_grads(int N, const float4 *__restrict__ gacc, const float4 *__restrict_
                float *__restrict__ v_opacity) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float4 a = gacc[4 * (size_t)n + 0], b = gacc[4 * (size_t)n + 1];
+    const float4 a = gacc[(kGradRec / 4) * (size_t)n + 0], b = gacc[(kGradRec / 4) * (size_t)n + 1];
     float o = reinterpret_cast<const float *>(gacc)[kGradRec * (size_t)n + 8];
     if (packed_logit) {  // opacity = sigmoid(logit): d/dlogit = s (1 - s), model.cpp:215
         const float sg = packed_logit[3 * (size_t)n + 1].y;
@@ -1921,11 +2147,23 @@ extern "C" int gs_rasterize_forward_ckpt(int W, int H, const int32_t *gaussian_i
     do {                                                                                                 \
         if (ck) GS_FWD_LAUNCH3(EX, IL, true); else GS_FWD_LAUNCH3(EX, IL, false);                        \
     } while (0)
-    if (flags & GS_FLAG_FAST_EXP) {
+    // flag bits 23..24 = 3: the forward that compacts its chunks (k_rasterize_forward_c, round 6) on full frames
+    // without checkpoints — measured 162 -> 160 us at C2 and 1119 -> 1191 us at C3 (a quadrant touches 43 % of a
+    // tile's list at C2, two thirds at C3: little to compact, and the ring costs): NOT the default; kept for the
+    // bit-for-bit test of the two (tests/test_gpu_forward_compact.py) and the next look
+#define GS_FWD_LAUNCH_C(EX)                                                                               \
+    GS_LAUNCH((gs::k_rasterize_forward_c<EX>), dim3(units), dim3(64), 0, s, W, H, tiles_x, tiles, tile_order, \
+              gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2, bg_dev, out_img, final_Ts, final_idx,  \
+              clamped)
+    const bool compact = ilp == 1 && !ck && (((flags >> 23) & 3u) == 3u || GS_FWD_COMPACT);
+    if (compact) {
+        if (flags & GS_FLAG_FAST_EXP) GS_FWD_LAUNCH_C(false); else GS_FWD_LAUNCH_C(true);
+    } else if (flags & GS_FLAG_FAST_EXP) {
         if (ilp == 2) GS_FWD_LAUNCH(false, 2); else GS_FWD_LAUNCH(false, 1);
     } else {
         if (ilp == 2) GS_FWD_LAUNCH(true, 2); else GS_FWD_LAUNCH(true, 1);
     }
+#undef GS_FWD_LAUNCH_C
 #undef GS_FWD_LAUNCH
 #undef GS_FWD_LAUNCH3
     gs::ev_after(s);
@@ -2022,8 +2260,13 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     // 1.3 ... 1.5 x faster (100 000 Gaussians at 1504 x 1000: 126 against 163 us; the pieces with sixteen groups,
     // built and measured: 188 -> 240 us at 1008 x 756 — not kept).  The statistic at hand is the list entries per
     // Gaussian, M / N, of the frame the list statistics come from: 2.2 at BASELINE config 2, 3.8 at config 3,
-    // 15 ... 35 on those scenes; sixteen groups up to kQMaxEntriesPerGaussian.
-    constexpr int64_t kQMaxEntriesPerGaussian = 6;
+    // 15 ... 35 on those scenes; sixteen groups up to kQMaxEntriesPerGaussian.  The threshold is the measured
+    // crossover (round 6, scripts/sweep_bwd_selection.py, profiles/r06/bwd_selection_sweep.json: 500 000 Gaussians
+    // at 1080p, splat size swept, both kernels on the same lists — sixteen-group time / four-group time at M / N =
+    // 2.2: 0.81, 2.7: 0.95, 3.4: 0.96, 4.2: 1.02, 5.1: 1.04, 6.0: 1.11, 8.8: 1.13, 12: 1.12); rounds 5's "6" stood
+    // on four points.  A frame without statistics (the first one, or after a reset) takes the four-group kernels:
+    // 178 instead of 144 us at M / N = 2.2, once.
+    constexpr int64_t kQMaxEntriesPerGaussian = 4;
     const int qsel = (int)((flags >> 25) & 3u);
     const bool small_footprints = list_stats && list_stats[0] > 0 &&
                                   (int64_t)list_stats[0] <= kQMaxEntriesPerGaussian * (int64_t)N;

@@ -272,3 +272,51 @@ def claim_rounds(config="c2", tiles="12x8"):
                                 cl[key] = cl.get(key, 0) + 1
                         tot[banks] += max(cl.values()) if cl else 0
     return {b: tot[b] / max(steps, 1) for b in tot}
+
+
+def claim_rounds_delayed(config="c2", tiles="8x6", delays=(0, 1, 2, 3, 4)):
+    """Round 6: rounds of the claim per step with ONE accumulator copy when the groups of one checkerboard colour
+    (or of the 2 x 2 parity classes) start d (or d * class) steps late — neighbouring blocks, whose queues hold the
+    same Gaussians at nearly the same ranks, then reach an entry at different steps.  Also the steps per chunk the
+    delay adds.  -> {name: (rounds per step, steps relative to no delay)}"""
+    s = scenes.config_c2() if config == "c2" else scenes.config_c3()
+    ntx, nty = (int(v) for v in tiles.split("x"))
+    TX, TY = (s.W + 15) // 16, (s.H + 15) // 16
+    tx0, ty0 = (TX - ntx) // 2, (TY - nty) // 2
+    g = build_window(s, tx0, ty0, ntx, nty)
+    names = [("cb%d" % d, 2, d) for d in delays] + [("p4_%d" % d, 4, d) for d in delays if d]
+    rounds = {n: 0 for n, _, _ in names}
+    steps = {n: 0 for n, _, _ in names}
+    for ty in range(ty0, ty0 + nty):
+        for tx in range(tx0, tx0 + ntx):
+            r = tile_work(g, tx, ty)
+            if r is None:
+                continue
+            need0, last = r
+            b16 = block16(need0)
+            wave_last = int(last.max())
+            if wave_last < 0:
+                continue
+            gl4 = last.reshape(4, 4, 4, 4).max(axis=(1, 3)).reshape(16)
+            for hi in range(wave_last, -1, -64):
+                lo = max(hi - 63, 0)
+                ent = np.arange(hi, lo - 1, -1)
+                qs = [ent[b16[ent, gi] & (ent <= gl4[gi])] for gi in range(16)]
+                for name, classes, d in names:
+                    off = []
+                    for gi in range(16):
+                        br, bc = gi >> 2, gi & 3
+                        cls = ((br + bc) & 1) if classes == 2 else ((br & 1) * 2 + (bc & 1))
+                        off.append(cls * d)
+                    n = max((len(q) + off[gi]) if len(q) else 0 for gi, q in enumerate(qs))
+                    for k in range(n):
+                        cl = {}
+                        for gi in range(16):
+                            kk = k - off[gi]
+                            if 0 <= kk < len(qs[gi]):
+                                e = int(qs[gi][kk])
+                                cl[e] = cl.get(e, 0) + 1
+                        steps[name] += 1
+                        rounds[name] += max(cl.values()) if cl else 0
+    base = steps["cb0"]
+    return {n: (rounds[n] / max(steps[n], 1), steps[n] / max(base, 1)) for n in rounds}
