@@ -199,6 +199,27 @@ def main():
                         "ms": it_ms, "iterations_per_s": 1e3 / it_ms, "stage_ms": stages,
                         "loss_after": [float(x) for x in T.loss_out[0].cpu()]}
 
+    # ---- camera batches through the library (Trainer.train_step_batch: two cameras in flight, ONE Adam step) ----
+    from opensplat_amd.scenes import C4_YAWS, yaw_camera
+    cams = []
+    for y in C4_YAWS[:4]:
+        vm, pm = yaw_camera(s_.W, s_.H, y)
+        cams.append(dict(viewmat=vm, projmat=pm, fx=s_.fx, fy=s_.fy, cx=s_.cx, cy=s_.cy, W=s_.W, H=s_.H))
+    gts = [gt] * 4
+    batch = {}
+    one = timeit(lambda: T.train_step(cams[0], gt, s_.background, s_.degrees_to_use), reps=30, warm=5)
+    batch["c1_train_step"] = {"ms_per_camera": one, "cameras_per_s": 1e3 / one}
+    for c in (2, 4):
+        for serial in (True, False):
+            ms_b = timeit(lambda: T.train_step_batch(cams[:c], gts[:c], s_.background, s_.degrees_to_use,
+                                                     serial=serial), reps=20, warm=4)
+            batch["c%d_%s" % (c, "serial" if serial else "two_in_flight")] = {
+                "ms_per_step": ms_b, "ms_per_camera": ms_b / c, "cameras_per_s": c * 1e3 / ms_b,
+                "per_camera_speedup_vs_c1": one / (ms_b / c)}
+    batch["note"] = ("C2 Gaussians, the first c C4 cameras (yaw offsets), render + loss + backward per camera, ONE "
+                     "optimiser step per batch; serial = the same cameras one after the other on one lane")
+    out["camera_batches"] = batch
+
     # ---- row f4: Model::afterTrain on the device ------------------------------------------------
     N_ = s_.N
     stats = [torch.zeros(N_, device=DEV) for _ in range(3)]

@@ -131,8 +131,10 @@ def main():
         (dst / tname).write_text(json.dumps(traffic, indent=1, sort_keys=True) + "\n")
     # every gs:: kernel of the step in one small file that bench.py attaches to its JSON line
     # (`kernels_profiled`, `roofline_valu`): rocprofv3 average duration, measured HBM bytes, the VALU
-    # issue occupancy (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES, 8 = every SIMD issuing all the time as
-    # the counters are normalised on gfx950) and — from the instrumented build's work counters
+    # issue RATE (SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES; the key still says "of_8", but there is no fixed
+    # ceiling: a saturated plain-fp32 loop reads 13.2, DPP / compare / SGPR-operand / fp64 loops 7.5 —
+    # profiles/valu_calib_r06.json; scripts/issue_roofline.py turns it into a fraction of the kernel's own
+    # saturated mix) and — from the instrumented build's work counters
     # (scripts/work_stats.py -> profiles/work_stats_<tag>_<cfg>.json) — the fraction of lanes that do
     # needed work in a compositing step.
     kern = {}

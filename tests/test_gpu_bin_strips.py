@@ -28,11 +28,12 @@ def _packed(s):
     colors = to_dev(s.colors) if s.sh_coeffs is None else torch.clamp_min(
         cabi.sh_forward(s.degrees_to_use, to_dev(s.dirs), to_dev(s.sh_coeffs)) + 0.5, 0.0)
     N = s.N
+    opac = to_dev(s.opacities.reshape(-1))      # (a variable: a temporary would be freed before the launch)
     packed = torch.empty((N, 12), device="cuda", dtype=torch.float32)
     tiles_hit = torch.empty((N,), device="cuda", dtype=torch.int32)
     l = cabi.lib()
     cabi._check(l.gs_pack_splats(C.c_int(s.W), C.c_int(s.H), C.c_int(N), cabi._p(p["xys"]), cabi._p(p["radii"]),
-                                 cabi._p(p["conics"]), cabi._p(colors), cabi._p(to_dev(s.opacities.reshape(-1))),
+                                 cabi._p(p["conics"]), cabi._p(colors), cabi._p(opac),
                                  cabi._p(p["cov2d"]), cabi._p(packed), cabi._p(tiles_hit), C.c_uint32(0),
                                  cabi._stream()), "gs_pack_splats")
     return packed, p["depths"], tiles_hit
