@@ -93,11 +93,11 @@ const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
 /* ABI version of THIS header: 10000*major + 100*minor + patch.  Bumped whenever an entry point changes its
  * argument list or an entry point is added (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0:
- * round 4; 0.4.2: gs_bin_strips, round 6).  A consumer
+ * round 4; 0.4.2 / 0.4.3: gs_bin_strips, gs_bin_speculative, round 6).  A consumer
  * compiled against another header must refuse the library instead of calling through shifted arguments:
  * opensplat_amd/cabi.py compares gs_version() with this constant when it loads the library, libgsplat_torch.so in
  * front of its first call into it (torch_ops.cpp: current_stream()). */
-#define GS_ABI_VERSION 402
+#define GS_ABI_VERSION 403
 int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 
 /* ---------------------------------------------------------------------------------------------
@@ -221,6 +221,19 @@ int gs_bin_sort(int W, int H, int N, int32_t capacity, const float *packed, cons
                 const int32_t *list_stats /*host int32[2] {M, longest list} of an earlier frame,
                                             nullable: lets the launch skip empty size classes*/,
                 void *workspace, size_t workspace_bytes, gs_stream_t stream);
+
+/* gs_bin_scan + gs_bin_sort in ONE call for callers that never look at M in between (the speculative id-list
+ * capacity of gs_bin_sort): same outputs, same workspace, same contract — but the scan is no launch of its own any
+ * more: every workgroup of the scatter kernel scans the tile counters itself and one extra workgroup writes
+ * tile_bins, {M, longest list} (to num_isects_host, pinned, nullable, and M to the device word at
+ * gs_bin_num_isects_offset) and tile_order beside the scatter (round 6: -9 us at 1080p, -37 us at 4K).  Images whose
+ * tile counters do not fit in LDS (beyond 36 864 tiles) take the two calls internally. */
+int gs_bin_speculative(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                       int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks /*[capacity]*/,
+                       int32_t *tile_order /*[tiles], nullable*/,
+                       int32_t *num_isects_host /*pinned host int32[2], nullable*/,
+                       const int32_t *list_stats /*host int32[2] of an earlier frame, nullable*/, void *workspace,
+                       size_t workspace_bytes, gs_stream_t stream);
 
 /* The same lists as gs_bin_scan + gs_bin_sort through a two-level partition (round 6), in ONE call and without a
  * host synchronisation: Gaussians -> strips of sixteen consecutive tiles of a tile row (32-byte records

@@ -18,7 +18,7 @@ from . import _build
 
 GS_TILE = 16
 GS_SPLAT_DWORDS = 12
-GS_ABI_VERSION = 402   # include/gsplat_hip.h
+GS_ABI_VERSION = 403   # include/gsplat_hip.h
 GS_FLAG_FAST_EXP = 1
 GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
@@ -33,7 +33,7 @@ GS_CAM_LOG_SCALES = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan", "gs_bin_num_isects_offset",
-    "gs_bin_sort", "gs_bin_strips", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_checkpoint_plan", "gs_rasterize_forward_ckpt",
+    "gs_bin_sort", "gs_bin_strips", "gs_bin_speculative", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_checkpoint_plan", "gs_rasterize_forward_ckpt",
     "gs_rasterize_backward_ckpt", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_timeline", "gs_debug_timeline_read", "gs_debug_row_reduce9", "gs_debug_group_reduce9", "gs_debug_backward_uses_mfma", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
@@ -273,37 +273,31 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
         ids = w.get("ids_sorted", (cap,), torch.int32, dev)
         masks = w.get("block_masks", (cap,), torch.int16, dev)
-        if speculative and _BIN_MODE != "tiles":
-            # round 6: Gaussians -> strips of sixteen tiles -> tiles (gs_bin_strips), one call
-            _check(l.gs_bin_strips(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed), _p(depths),
-                                   _p(tile_bins), _p(ids), _p(masks), _p(tile_order),
-                                   C.c_void_p(m_host.data_ptr()), w.list_stats, _p(ws), C.c_size_t(ws_bytes),
-                                   _stream()), "gs_bin_strips")
-            if w.scan_done is None:
-                w.scan_done = torch.cuda.Event()
-            if not torch.cuda.is_current_stream_capturing():
-                w.scan_done.record()     # {M, longest list} are in pinned memory once the last sort launch has run
-            b = Binned(packed, tiles_hit, -1, ids, tile_bins, masks)
-            b.tile_order = tile_order
-            b.m_host, b.capacity, b.workspace = m_host, cap, w
-            b.list_stats = w.list_stats   # from the previous validated frame
-            return b
         if speculative:
-            _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
-                                 _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
-                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
+            # one call, nothing synchronises: gs_bin_speculative (tile-level kernels, the scan folded into the scatter)
+            # or — GSPLAT_BIN=strips — the two-level partition of round 6 (gs_bin_strips); GSPLAT_BIN=scan_sort: the
+            # two calls of rounds 1 - 5
+            if _BIN_MODE == "scan_sort":
+                _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
+                                     _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
+                                     C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
+                _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
+                                     _p(depths), _p(tile_bins), _p(ids), _p(masks), w.list_stats, _p(ws),
+                                     C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
+            else:
+                fn = l.gs_bin_strips if _BIN_MODE == "strips" else l.gs_bin_speculative
+                _check(fn(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed), _p(depths),
+                          _p(tile_bins), _p(ids), _p(masks), _p(tile_order), C.c_void_p(m_host.data_ptr()),
+                          w.list_stats, _p(ws), C.c_size_t(ws_bytes), _stream()), "gs_bin_speculative")
             if w.scan_done is None:
                 w.scan_done = torch.cuda.Event()
-            # validate_binning waits for THIS, not for the whole stream.  (Not while the stream is being
-            # captured: an event recorded inside a graph cannot be waited for outside it, and replaying a
-            # graph that holds the record node after the event has been recorded eagerly again — a render()
-            # between two replays — ended in GPU memory faults on ROCm 7.0; a captured iteration is validated
+            # validate_binning waits for THIS, not for the whole stream: {M, longest list} are in pinned memory once
+            # the binning's launches have run.  (Not while the stream is being captured: an event recorded inside a
+            # graph cannot be waited for outside it, and replaying a graph that holds the record node after the event
+            # has been recorded eagerly again ended in GPU memory faults on ROCm 7.0; a captured iteration is validated
             # from the pinned count once the replay has completed, train.py.)
             if not torch.cuda.is_current_stream_capturing():
                 w.scan_done.record()
-            _check(l.gs_bin_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),
-                                 _p(depths), _p(tile_bins), _p(ids), _p(masks), w.list_stats, _p(ws),
-                                 C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
             b = Binned(packed, tiles_hit, -1, ids, tile_bins, masks)
             b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w

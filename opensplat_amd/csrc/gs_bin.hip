@@ -273,11 +273,11 @@ __device__ __forceinline__ int order_next(int i, int tiles, int step) {   // i(j
 // coalesced), the prefix is a DPP wave scan + the sixteen wave totals through LDS, and the counting
 // sort for the longest-first tile order reuses the same pattern: five barriers in all (the general
 // kernel below: a dozen, plus a Hillis-Steele loop of shuffles) — 14 -> ~6 us at 1080p.
-__global__ void __launch_bounds__(1024)
-k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
-                  int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
-                  int32_t *__restrict__ order) {
-    extern __shared__ int32_t c_lds[];
+// (the body: also run by the extra workgroup of k_scatter_scan, which folds this launch into the scatter's)
+__device__ __forceinline__ void scan_tiles_fast_body(int tiles, int order_mult, const int32_t *__restrict__ counts,
+                                                     int2 *__restrict__ bins, int32_t *__restrict__ total_dev,
+                                                     int32_t *__restrict__ total_host,
+                                                     int32_t *__restrict__ order, int32_t *c_lds) {
     __shared__ int32_t part[1024];
     __shared__ int32_t wsum[16], wmax[16], psum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -336,6 +336,14 @@ k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts,
     __syncthreads();
     for (int k = 0, i = order_first(t, tiles, order_mult); k * 1024 + t < tiles; k++, i = order_next(i, tiles, ostep))
         order[atomicAdd(&part[1023 - (c_lds[skew(i)] >> shift)], 1)] = i;
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_fast(int tiles, int order_mult, const int32_t *__restrict__ counts, int2 *__restrict__ bins,
+                  int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
+                  int32_t *__restrict__ order) {
+    extern __shared__ int32_t c_lds[];
+    scan_tiles_fast_body(tiles, order_mult, counts, bins, total_dev, total_host, order, c_lds);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -581,6 +589,63 @@ k_scatter(int N, int tiles, int tiles_x, int32_t capacity, const float4 *__restr
     for (; (int64_t)chunk * 64 < N; chunk += stride) {
         const int n = chunk * 64 + lane;
         const int64_t nn = (int64_t)n + (int64_t)stride * 64;   // (may not fit an int beyond the last chunk)
+        const ScatterIn next = scatter_request(packed, depths, (int)(nn < N ? nn : 0), nn < N);
+        scatter_tiles(in, n, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
+            const int pos = atomicAdd(&h[tile], 1);
+            if (pos < capacity) keys[pos] = make_uint4(d, (uint32_t)g, m, 0u);
+        });
+        in = next;
+    }
+}
+
+// k_scatter with the scan folded in (round 6): the launch of k_scan_tiles_fast — one workgroup between two
+// chip-filling launches, 10 us at C2 and 38 us at 4K — disappears.  Every scattering workgroup scans the tile
+// counters ITSELF (32 KB at 1080p, from L2: its cursors need the segment starts anyway, which it used to read from
+// tile_bins), and ONE EXTRA workgroup (the last of the grid) does what the scan kernel did for everybody else —
+// tile_bins, {M, longest list}, the tile order — beside the scatter instead of in front of it.  Grid = the count
+// kernel's + 1; only for images whose counters fit in LDS.
+__global__ void __launch_bounds__(kPersistentThreads)
+k_scatter_scan(int N, int tiles, int tiles_x, int32_t capacity, int order_mult,
+               const float4 *__restrict__ packed, const float *__restrict__ depths,
+               const int32_t *__restrict__ counts, const int32_t *__restrict__ wg_base,
+               int2 *__restrict__ bins, int32_t *__restrict__ total_dev, int32_t *__restrict__ total_host,
+               int32_t *__restrict__ order, uint4 *__restrict__ keys) {
+    extern __shared__ int32_t h[];
+    const int blocks = (int)gridDim.x - 1;
+    if ((int)blockIdx.x == blocks) {
+        scan_tiles_fast_body(tiles, order_mult, counts, bins, total_dev, total_host, order, h);
+        return;
+    }
+    __shared__ int32_t ws[17];
+    const int32_t *my_base = wg_base + (size_t)blockIdx.x * tiles;
+    const int stride = (blockDim.x >> 6) * blocks, lane = threadIdx.x & 63;
+    int chunk = (threadIdx.x >> 6) * blocks + blockIdx.x;
+    ScatterIn in = scatter_request(packed, depths, chunk * 64 + lane, (int64_t)chunk * 64 + lane < N);
+    {   // cursors = exclusive scan of the counters + this workgroup's offset inside every segment.  Coalesced:
+        // wave w scans a contiguous run of the tiles 64 at a time (DPP wave scan + a carry), the sixteen run
+        // totals go through LDS.  (Per-thread slices — 32 consecutive counters per thread at 4K, a cache line per
+        // lane and load — made this preamble cost 42 us at C3.)
+        const int wave = threadIdx.x >> 6;
+        const int run_len = ((tiles + 15) / 16 + 63) / 64 * 64;
+        const int lo = wave * run_len, hi = min(lo + run_len, tiles);
+        int32_t carry = 0;
+        for (int i0 = lo; i0 < hi; i0 += 64) {
+            const int i = i0 + lane;
+            const int32_t c = i < hi ? counts[i] : 0;
+            const int32_t incl = wave_inclusive_scan_i(c);
+            if (i < hi) h[i] = carry + incl - c;
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) ws[wave] = carry;
+        __syncthreads();
+        int32_t off = 0;
+        for (int w = 0; w < wave; w++) off += ws[w];
+        for (int i = lo + lane; i < hi; i += 64) h[i] += off + my_base[i];
+    }
+    __syncthreads();
+    for (; (int64_t)chunk * 64 < N; chunk += stride) {
+        const int n = chunk * 64 + lane;
+        const int64_t nn = (int64_t)n + (int64_t)stride * 64;
         const ScatterIn next = scatter_request(packed, depths, (int)(nn < N ? nn : 0), nn < N);
         scatter_tiles(in, n, tiles_x, [&](int tile, uint32_t d, int g, uint32_t m) {
             const int pos = atomicAdd(&h[tile], 1);
@@ -1808,6 +1873,56 @@ extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float 
     // (fused: tile_bins are clamped as they are written — on a frame whose id list was too small the longest list
     // reported is the clamped one)
     return order_tiles();
+}
+
+extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                                  int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                                  int32_t *tile_order, int32_t *num_isects_host, const int32_t *list_stats,
+                                  void *workspace, size_t workspace_bytes, gs_stream_t stream) {
+    GS_TRACE("gs_bin_speculative");
+    if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
+    if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
+    if (!tile_bins || !workspace) return GS_ERR_INVALID_ARGUMENT;
+    if ((uintptr_t)workspace & 15u) return GS_ERR_INVALID_ARGUMENT;
+    const int tiles_x = (W + GS_TILE - 1) / GS_TILE, tiles_y = (H + GS_TILE - 1) / GS_TILE;
+    const int tiles = tiles_x * tiles_y;
+    const size_t lds = sizeof(int32_t) * ((size_t)tiles + tiles / 32 + 1);
+    // measurement switch: GSPLAT_BIN_SCAN_LAUNCH=1 keeps the scan as a launch of its own (rounds 1 - 5)
+    static const bool own_launch = [] { const char *e = getenv("GSPLAT_BIN_SCAN_LAUNCH"); return e && e[0] == '1'; }();
+    if (own_launch || N == 0 || capacity == 0 || lds > gs::kMaxTileLds || !packed || !depths ||
+        !gaussian_ids_sorted || !block_masks) {
+        int rc = gs_bin_scan(W, H, N, packed, tile_bins, tile_order, num_isects_host, workspace, workspace_bytes,
+                             stream);
+        if (rc != GS_OK) return rc;
+        return gs_bin_sort(W, H, N, capacity, packed, depths, tile_bins, gaussian_ids_sorted, block_masks,
+                           list_stats, workspace, workspace_bytes, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const gs::BinLayout L = gs::bin_layout(N, capacity, W, H);
+    if (workspace_bytes < L.total) return GS_ERR_WORKSPACE;
+    char *base = static_cast<char *>(workspace);
+    int32_t *counts = reinterpret_cast<int32_t *>(base + L.counters);
+    int32_t *total_dev = reinterpret_cast<int32_t *>(base + L.total_dev);
+    int32_t *wg_base = reinterpret_cast<int32_t *>(base + L.wg_base);
+    uint4 *keys = reinterpret_cast<uint4 *>(base + L.keys);
+    const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    gs::timeline_before(s);
+    GS_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)tiles, s));
+    gs::timeline_after("memset(tile counters)", s);
+    const int blocks = gs::persistent_blocks(N);
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_count_tiles),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));
+    GS_LAUNCH(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), sizeof(int32_t) * (size_t)tiles, s, N,
+              tiles, tiles_x, pk, counts, wg_base);
+    GS_LAUNCH_CHECK();
+    GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scatter_scan),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));
+    GS_LAUNCH(gs::k_scatter_scan, dim3(blocks + 1), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x, capacity,
+              gs::order_multiplier(tiles), pk, depths, counts, wg_base, reinterpret_cast<int2 *>(tile_bins), total_dev,
+              num_isects_host, tile_order, keys);
+    GS_LAUNCH_CHECK();
+    return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
+                                 gaussian_ids_sorted, block_masks, s);
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,

@@ -308,19 +308,18 @@ BinnedLists binPackedRecords(const Tensor &packed, const Tensor &depths, int H, 
     Tensor ws = torch::empty({(int64_t)wsBytes}, depths.options().dtype(torch::kUInt8));
     // tiles by descending list length: the compositing launches start with the long lists
     b.tileOrder = torch::empty({tiles}, i32);
-    check_status(gs_bin_scan(W, H, (int)N, fptr(packed), b.tileBins.data_ptr<int32_t>(),
-                             b.tileOrder.data_ptr<int32_t>(), b.count.data_ptr<int32_t>(),
-                             ws.data_ptr(), wsBytes, s),
-                 "gs_bin_scan");
-    // validateBinning waits for this event (the scan kernel has stored the count), not for the stream
+    // (one call: count, scatter with the scan folded in — tile_bins, tile order and the counts come from an extra
+    // workgroup of the scatter launch —, per-tile sorts)
+    check_status(gs_bin_speculative(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
+                                    b.tileBins.data_ptr<int32_t>(), b.gaussianIdsSorted.data_ptr<int32_t>(),
+                                    reinterpret_cast<uint16_t *>(b.blockMasks.data_ptr<int16_t>()),
+                                    b.tileOrder.data_ptr<int32_t>(), b.count.data_ptr<int32_t>(), st.listStats,
+                                    ws.data_ptr(), wsBytes, s),
+                 "gs_bin_speculative");
+    // validateBinning waits for this event (the counts are in pinned memory), not for the stream
     auto scanDone = std::make_shared<at::cuda::CUDAEvent>();
     scanDone->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
     b.scanDone = scanDone;
-    check_status(gs_bin_sort(W, H, (int)N, (int32_t)cap, fptr(packed), fptr(depths),
-                             b.tileBins.data_ptr<int32_t>(), b.gaussianIdsSorted.data_ptr<int32_t>(),
-                             reinterpret_cast<uint16_t *>(b.blockMasks.data_ptr<int16_t>()),
-                             st.listStats, ws.data_ptr(), wsBytes, s),
-                 "gs_bin_sort");
     g_binCalls++;
     return b;
 }

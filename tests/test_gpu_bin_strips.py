@@ -58,8 +58,9 @@ def _bin(which, W, H, packed, depths, cap, list_stats=None):
     ws.fill_(0xA5)     # whatever the allocator left there
     stats = (C.c_int32 * 2)(*list_stats) if list_stats is not None else None
     args = (C.c_int(W), C.c_int(H), C.c_int(N))
-    if which == "strips":
-        cabi._check(l.gs_bin_strips(*args, C.c_int32(cap), cabi._p(packed), cabi._p(depths), cabi._p(bins),
+    if which in ("strips", "speculative"):
+        fn = l.gs_bin_strips if which == "strips" else l.gs_bin_speculative
+        cabi._check(fn(*args, C.c_int32(cap), cabi._p(packed), cabi._p(depths), cabi._p(bins),
                                     cabi._p(ids), cabi._p(masks), cabi._p(order), C.c_void_p(m_host.data_ptr()),
                                     stats, cabi._p(ws), C.c_size_t(nb), cabi._stream()), "gs_bin_strips")
     else:
@@ -125,6 +126,9 @@ def test_strips_give_the_tile_level_lists_bit_for_bit(name):
     # the statistics of the frame itself (another choice of sort classes): the same lists again
     c = _bin("strips", s.W, s.H, packed, depths, M, list_stats=(a["M"], a["longest"]))
     _same_lists(c, b, tiles_hit)
+    # gs_bin_speculative (the scan folded into the scatter launch): the two calls' lists, bit for bit
+    d = _bin("speculative", s.W, s.H, packed, depths, M + 7, list_stats=(a["M"], a["longest"]))
+    _same_lists(d, b, tiles_hit)
 
 
 def test_strips_with_long_lists_and_tied_depths():
@@ -139,6 +143,7 @@ def test_strips_with_long_lists_and_tied_depths():
     _same_lists(a, b, tiles_hit)
     for stats in [(M, 300), (M, 800), (M, a["longest"])]:          # stale and exact statistics
         _same_lists(_bin("strips", s.W, s.H, packed, depths, M, list_stats=stats), b, tiles_hit)
+        _same_lists(_bin("speculative", s.W, s.H, packed, depths, M, list_stats=stats), b, tiles_hit)
 
 
 def test_strips_survive_a_too_small_capacity():
