@@ -103,6 +103,32 @@ __device__ unsigned long long g_stats[16];
     do {                 \
     } while (0)
 #endif
+// Optional per-workgroup log of the two full-frame compositing kernels (build with -DGS_WAVELOG; never in the
+// shipped library; scripts/wave_timeline.py): record blockIdx.x = {start, end (100 MHz s_memrealtime),
+// HW_ID | XCC_ID << 32, tile | list length << 32}.
+#ifdef GS_WAVELOG
+constexpr int kWaveLog = 65536;
+__device__ unsigned long long g_wavelog[4 * kWaveLog];
+#define GS_WLOG_T0 const unsigned long long wlog_t0 = wall_clock64();
+#define GS_WLOG_T1(tile, len)                                                                              \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < kWaveLog) {                                                   \
+            unsigned int hw, xcc;                                                                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                               \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                             \
+            unsigned long long *r = &g_wavelog[4 * blockIdx.x];                                            \
+            r[0] = wlog_t0;                                                                                \
+            r[1] = wall_clock64();                                                                         \
+            r[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);                               \
+            r[3] = (unsigned long long)(unsigned int)(tile) | ((unsigned long long)(unsigned int)(len) << 32); \
+        }                                                                                                  \
+    } while (0)
+#else
+#define GS_WLOG_T0
+#define GS_WLOG_T1(tile, len) \
+    do {                      \
+    } while (0)
+#endif
 __device__ __forceinline__ float qnan() { return __uint_as_float(0x7fc00000u); }
 
 struct __attribute__((aligned(16))) SRec {
@@ -251,11 +277,16 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     __shared__ SRec stage[kChunk + 1];
     __shared__ uint64_t exp_tab[EXACT ? kExpTabLds : 1];
 #if GS_FWD_QWALK
-    __shared__ __attribute__((aligned(16))) uint8_t fq[4 * kChunk + 16];   // [group][rank] -> slot
+    // [group][rank] -> the slot's BYTE OFFSET in stage[] (slot * 48) as a 32-bit word: the step's record address is
+    // the queue word itself — no zero-extension, no multiply per step (round 6: 45 -> 43 VALU per step)
+    __shared__ __attribute__((aligned(16))) uint32_t fq[4 * kChunk + 16];
+    constexpr uint32_t kFqFill = (uint32_t)(kChunk * sizeof(SRec));   // the sentinel slot
+    static_assert(sizeof(SRec) == 48, "the last-contributor conversion divides by 48");
 #endif
     const int lane = threadIdx.x;
     int tile, qx0, qy0;
     if (!decode_wave<1>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, qx0, qy0)) return;
+    GS_WLOG_T0
     if (bg_dev) {  // background handed over as a device tensor (no host copy, no sync)
         bg0 = bg_dev[0]; bg1 = bg_dev[1]; bg2 = bg_dev[2];
     }
@@ -296,6 +327,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
     };
     int last = -1;   // list index of the last composited entry
     int le = -1;     // ... as a slot of the current chunk (turned into an index once per chunk)
+    const uint32_t *lq = nullptr;   // ... as a place in the group's queue (queue walk)
+    (void)le; (void)lq;
 
     const int2 range = bins[tile];
     const int ox = qx0 & (GS_TILE - 1), oy = qy0 & (GS_TILE - 1);   // the quadrant's offset in its tile
@@ -331,7 +364,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         }
         // (a walk specialised per chunk on "no staged entry's rectangle cuts its sigma_max ellipse" — two
         // VALU and a branch less per step, as in the backward — measured 185.1 against 185.8 us: the
-        // general walk is the one that runs; the switch stays for the next look)
+        // general walk is the one that runs; the switch stays for the next look.  Round 6: a rectangle of three
+        // sigmas cuts the sigma_max ellipse of every Gaussian with an opacity above ~0.35 — at C2 hardly a chunk is
+        // free of them)
         constexpr bool kChunkBinds = false;
         const bool chunk_binds = !kChunkBinds ||
             __builtin_amdgcn_ballot_w64(touch != 0u && (__float_as_uint(n1.z) & 1u) != 0u) != 0ull;
@@ -348,13 +383,16 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         // is one byte read with a per-group address instead of four scalar find-first-set chains
         int nsteps = 0;
         {
-            reinterpret_cast<uint32_t *>(fq)[lane] = kChunk * 0x01010101u;
-            if (lane < 4) reinterpret_cast<uint32_t *>(fq)[kChunk + lane] = kChunk * 0x01010101u;
+            fq[lane] = kFqFill;
+            fq[kChunk + lane] = kFqFill;
+            fq[2 * kChunk + lane] = kFqFill;
+            fq[3 * kChunk + lane] = kFqFill;
+            if (lane < 16) fq[4 * kChunk + lane] = kFqFill;
 #define GS_FQ(g, m)                                                                                         \
     if (__builtin_amdgcn_inverse_ballot_w64(m))                                                             \
         fq[(g) * kChunk + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32),                             \
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u))] =   \
-            (uint8_t)lane;
+            (uint32_t)(lane * (int)sizeof(SRec));
             GS_FQ(0, m0) GS_FQ(1, m1) GS_FQ(2, m2) GS_FQ(3, m3)
 #undef GS_FQ
             nsteps = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
@@ -376,12 +414,13 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
           constexpr bool BINDS = decltype(binds_tag)::value;
           constexpr bool HOT = CK && decltype(hot_tag)::value;
 #if GS_FWD_QWALK
-          const uint8_t *myq = &fq[grp * kChunk];
-          int e_next = myq[0];
+          const uint32_t *myq = &fq[grp * kChunk];
+          int e_next = (int)myq[0];
           for (int k = 0; k < nsteps; k++) {
-            const int e = e_next;
-            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
-            e_next = myq[k + 1];
+            const int e = e_next;   // (a byte offset: see fq)
+            const SRec &rec = *reinterpret_cast<const SRec *>(reinterpret_cast<const char *>(stage) + e);
+            const float4 q0 = rec.p0, q1 = rec.p1, q2 = rec.p2;
+            e_next = (int)myq[k + 1];
 #else
           uint32_t ep_next;
           { GS_WALK_PACK(ep0_) ep_next = ep0_; }
@@ -438,7 +477,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a2 = a2 + w * q2.z;
             if (HOT && __builtin_amdgcn_ballot_w64(alpha > 0.99f) != 0ull) rebase(alpha, T, q2);
             T = nT;
+#if GS_FWD_QWALK
+            lq = ok ? myq + k + 1 : lq;   // (the address the walk holds anyway: e dies with its reads, no copy)
+#else
             le = ok ? e : le;
+#endif
           }
         };
         // Two entries of a group's list per step: the second entry's sigma / exponential / alpha do not
@@ -454,12 +497,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
           // (the queue holds the group's slots in list order, the sentinel slot behind them: entries 2k and
           // 2k + 1 of the queue are this step's pair — on a frame of lone waves every instruction of a step
           // counts, and the forty scalar ones of the two mask walks were half of them)
-          const uint16_t *myq2 = reinterpret_cast<const uint16_t *>(&fq[grp * kChunk]);
-          uint32_t pair_next = myq2[0];
+          const uint2 *myq2 = reinterpret_cast<const uint2 *>(&fq[grp * kChunk]);
+          uint2 pair_next = myq2[0];
           for (int k = 0; k < (nsteps + 1) / 2; k++) {
-            const int ea = (int)(pair_next & 0xFFu), eb = (int)(pair_next >> 8);
-            const float4 qa0 = stage[ea].p0, qa1 = stage[ea].p1, qa2 = stage[ea].p2;
-            const float4 qb0 = stage[eb].p0, qb1 = stage[eb].p1, qb2 = stage[eb].p2;
+            const int ea = (int)pair_next.x, eb = (int)pair_next.y;   // (byte offsets: see fq)
+            const SRec &ra = *reinterpret_cast<const SRec *>(reinterpret_cast<const char *>(stage) + ea);
+            const SRec &rb = *reinterpret_cast<const SRec *>(reinterpret_cast<const char *>(stage) + eb);
+            const float4 qa0 = ra.p0, qa1 = ra.p1, qa2 = ra.p2;
+            const float4 qb0 = rb.p0, qb1 = rb.p1, qb2 = rb.p2;
             pair_next = myq2[k + 1];
 #else
           uint32_t epa_next, epb_next;
@@ -534,7 +579,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a2 = a2 + wb * qb2.z;
             if (HOT && __builtin_amdgcn_ballot_w64(ab > 0.99f) != 0ull) rebase(ab, nTa, qb2);
             T = nTb;
+#if GS_FWD_QWALK
+            lq = okb ? &myq2[k + 1].x : (oka ? &myq2[k].y : lq);   // (one word past the entry's, as in walk)
+#else
             le = okb ? eb : (oka ? ea : le);
+#endif
           }
         };
         // (kChunkBinds is off: the general walk)  A chunk none of whose entries has an opacity above 0.99 cannot
@@ -544,7 +593,14 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         } else {
             if (chunk_hot) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
         }
+#if GS_FWD_QWALK
+        // (lq: one word past the queue word of the lane's last composited entry; the word is a stage offset, a
+        // multiple of 48 up to 63 * 48: the slot by multiply-and-shift, once per chunk)
+        if (lq) last = c0 + (int)((lq[-1] * 43691u) >> 21);
+        lq = nullptr;
+#else
         last = le >= 0 ? c0 + le : last;
+#endif
         le = -1;
     }
     if (inimg) {
@@ -562,6 +618,7 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         final_idx[pix] = last;
         if (CK) ckpt[0] = record(invG);
     }
+    GS_WLOG_T1(tile, range.y - range.x);
 }
 
 
@@ -1366,7 +1423,11 @@ struct __attribute__((aligned(16))) SRecQ {
     float4 p0, p1, p2;   // {x y A' B' | C' o s_hi s_lo | r g b C}   (A' = A log2 e ...; C unscaled for the rare paths)
 };
 constexpr int kQChunk = 64;
-constexpr int kAccRec = 10;   // floats per accumulator record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}
+// floats per accumulator record: {c0 c4 | c1 c5 | c2 c6 | c3 c7 | c8 -}.  (Round 6: 48-byte records — the stride of
+// the staged records, the claim word inside: one multiply per step addresses all three, four VALU less — measured
+// SLOWER, 0.2411 against 0.2342 ms at C2, 1.616 against 1.601 at C3: with a stride of twelve dwords the records of
+// slots e and e + 8 share their banks, with ten dwords e and e + 16, and the claim's accesses are what collides.)
+constexpr int kAccRec = 10;
 // dword of component c in an accumulator record
 __device__ __forceinline__ int acc_dword(int c) { return c < 8 ? 2 * (c & 3) + (c >> 2) : 8; }
 // accumulator copies: 1, or 2 = one per checkerboard colour of the blocks — neighbouring blocks hold the same
@@ -1376,13 +1437,25 @@ __device__ __forceinline__ int acc_dword(int c) { return c < 8 ? 2 * (c & 3) + (
 #define GS_BWDQ_COPIES 1
 #endif
 constexpr int kQCopies = GS_BWDQ_COPIES;
+// (Round 6: a wave of this kernel walks 2.6 .. 3.0 list entries per us whether two or four waves share its SIMD
+// — one wave gets a quarter of a SIMD's issue slots at most — and a C2 launch spends its last 40 % with two waves per
+// SIMD: scripts/wave_timeline.py, profiles/r06/wave_timeline_*.json.  A walk software-pipelined by one step — the
+// next staged record read a step ahead, the sums of step k claimed and added under the passes of step k + 1, the four
+// passes' threshold decisions behind ONE branch, 128 VGPRs — was built, bit-identical, and SLOWER: 0.262 against
+// 0.247 ms at C2, 1.80 against 1.65 ms at C3; the oldest wave of a SIMD walked 2.99 instead of 3.04 entries per
+// us: what a wave waits for is not its LDS round trips but its own issue slots, and the pipelined walk issues more
+// instructions.  profiles/HISTORY.md.)
+// the claim word.  (A byte-sized tag array kept QLds at 8128 bytes — TWENTY waves per CU instead of eighteen — and
+// launch_bounds(64, 4) gave sixteen; measured in round 6, same box, three interleaved bench lines each: 0.2484 /
+// 0.2476 and 0.2461 / 0.2453 against 0.2456 / 0.2478 ms at C2: the kernel does not react to 16 .. 20 waves per CU.)
+typedef unsigned int qtag_t;
 struct QLds {
     SRecQ stage[kQChunk + 1];
     float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
     alignas(16) uint8_t queue[16 * kQChunk + 16];      // [block][rank] -> slot; (+16: the read one step ahead)
     alignas(16) float acc[kQCopies][(kQChunk + 1) * kAccRec];    // per-entry sums (entry-major)
     int sid[kQChunk];
-    unsigned int tag[kQCopies][kQChunk + 1];           // the claim: which block adds to an entry this round
+    qtag_t tag[kQCopies][kQChunk + 1];                 // the claim: which block adds to an entry this round
 };
 
 template <bool EXACT, bool DET>
@@ -1533,8 +1606,8 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 e_next = myq[k + 1];
                 // the claim's first round: issued here, looked at after the passes
                 const bool active = e < CH;   // (an exhausted group has nothing to add; its dx is NaN)
-                unsigned int *mytag = &lds.tag[copy][e];
-                if (active) __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                qtag_t *mytag = &lds.tag[copy][e];
+                if (active) __hip_atomic_store(mytag, (qtag_t)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
@@ -1641,7 +1714,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                     wave_sync();
                     bool w = false;
                     if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
-                        __hip_atomic_store(mytag, (unsigned int)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(mytag, (qtag_t)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         w = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == grp;
                         a01 = *r2;
                         a8 = rec[8];
@@ -1781,8 +1854,10 @@ k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *
     __shared__ QLds lds;
     int tile, wx0, wy0;
     if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
+    GS_WLOG_T0
     backward_wave_q<EXACT, DET>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
                                 final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+    GS_WLOG_T1(tile, bins[tile].y - bins[tile].x);
 }
 // ... and with the few outlying lists of a frame taken by four waves of one pixel per lane each, exactly as in
 // k_rasterize_backward_mixed (one LDS allocation serves either layout).
@@ -1985,6 +2060,15 @@ extern "C" int gs_debug_stats(unsigned long long *host16, int reset) {
         unsigned long long z[16] = {0};
         GS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs::g_stats), z, 16 * 8));
     }
+    return GS_OK;
+}
+#endif
+#ifdef GS_WAVELOG
+// the per-workgroup log of the LAST forward / backward_q launch: n records of four words (see GS_WLOG_T1)
+extern "C" int gs_debug_wavelog(unsigned long long *host, int n) {
+    GS_HIP_CHECK(hipDeviceSynchronize());
+    if (!host || n < 0 || n > gs::kWaveLog) return GS_ERR_INVALID_ARGUMENT;
+    GS_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(gs::g_wavelog), (size_t)n * 32));
     return GS_OK;
 }
 #endif
