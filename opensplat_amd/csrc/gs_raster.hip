@@ -77,6 +77,12 @@ constexpr int kChunk = 64;  // entries staged per pass == wave width
 #ifndef GS_FWD_COMPACT
 #define GS_FWD_COMPACT 0   // 1: full frames take k_rasterize_forward_c (round 6; measured, not the default)
 #endif
+// 1: full-frame chunks without a binding rectangle walk without looking for one — two VALU and a branch less per
+// step; measured twice, lost twice (round 4: 185.1 against 185.8 us; round 6, same box, three interleaved lines each:
+// 0.1604 against 0.1578 ms at C2 — the per-chunk ballot and a second copy of the walk cost more than they save)
+#ifndef GS_FWD_CHUNK_BINDS
+#define GS_FWD_CHUNK_BINDS 0
+#endif
 #ifndef GS_FWD_QWALK
 #define GS_FWD_QWALK 1
 #endif
@@ -367,11 +373,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         // general walk is the one that runs; the switch stays for the next look.  Round 6: a rectangle of three
         // sigmas cuts the sigma_max ellipse of every Gaussian with an opacity above ~0.35 — at C2 hardly a chunk is
         // free of them)
-        constexpr bool kChunkBinds = false;
+        constexpr bool kChunkBinds = GS_FWD_CHUNK_BINDS != 0 && ILP == 1 && !CK;
         const bool chunk_binds = !kChunkBinds ||
             __builtin_amdgcn_ballot_w64(touch != 0u && (__float_as_uint(n1.z) & 1u) != 0u) != 0ull;
-        static_assert(!kChunkBinds, "the walks below are instantiated for the general case only");
-        (void)chunk_binds;
         const bool chunk_hot = CK && __builtin_amdgcn_ballot_w64(touch != 0u && n1.y > 0.99f) != 0ull;
         // a block whose 16 pixels are all finished walks nothing
         uint64_t m0 = (alive & 0x000000000000FFFFull) ? __builtin_amdgcn_ballot_w64((touch & 1u) != 0u) : 0ull;
@@ -591,7 +595,9 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         if constexpr (ILP == 2) {
             if (chunk_hot) walk2(std::true_type{}, std::true_type{}); else walk2(std::true_type{}, std::false_type{});
         } else {
-            if (chunk_hot) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{});
+            if (chunk_hot) walk(std::true_type{}, std::true_type{});
+            else if (chunk_binds) walk(std::true_type{}, std::false_type{});
+            else walk(std::false_type{}, std::false_type{});
         }
 #if GS_FWD_QWALK
         // (lq: one word past the queue word of the lane's last composited entry; the word is a stage offset, a
@@ -1605,9 +1611,12 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const float4 q0 = lds.stage[e].p0, q1 = lds.stage[e].p1, q2 = lds.stage[e].p2;
                 e_next = myq[k + 1];
                 // the claim's first round: issued here, looked at after the passes
-                const bool active = e < CH;   // (an exhausted group has nothing to add; its dx is NaN)
+                // (an exhausted group has nothing to add; its dx is NaN.  The predicate lives as a scalar mask from here
+                // to the claim: as a bool it crossed the passes in a VGPR, two VALU per step to put it there and back)
+                const uint64_t actm = __builtin_amdgcn_ballot_w64(e < CH);
                 qtag_t *mytag = &lds.tag[copy][e];
-                if (active) __hip_atomic_store(mytag, (qtag_t)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_inverse_ballot_w64(actm))
+                    __hip_atomic_store(mytag, (qtag_t)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t sbits = __float_as_uint(q1.z);
                 GS_STAT(8, 1);
                 const float dx = q0.x - pxf;
@@ -1688,7 +1697,6 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
                 // ---- add to the entry's record: plain read-add-write by the group that holds the claim ----
                 // (lane masks as scalars: the loop's exit test is one s_cmp)
-                const uint64_t actm = __builtin_amdgcn_ballot_w64(active);
                 uint64_t winm = actm & __builtin_amdgcn_ballot_w64(won == grp);
                 uint64_t pendm = actm & ~winm;
                 float2 a01 = make_float2(0.0f, 0.0f);
