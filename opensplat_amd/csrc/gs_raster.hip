@@ -1455,6 +1455,18 @@ constexpr int kQCopies = GS_BWDQ_COPIES;
 // launch_bounds(64, 4) gave sixteen; measured in round 6, same box, three interleaved bench lines each: 0.2484 /
 // 0.2476 and 0.2461 / 0.2453 against 0.2456 / 0.2478 ms at C2: the kernel does not react to 16 .. 20 waves per CU.)
 typedef unsigned int qtag_t;
+// GS_BWDQ_PK: the four pixel passes of a step as two PACKED ones (v_pk_add / mul / fma_f32 on the rows 2 j, 2 j + 1).
+// A wave is bound by the instructions it issues (round 6, scripts/wave_timeline.py): 44 packed instructions replace
+// 88 plain ones per step; a saturated SIMD pays ~1.6 plain ones for a packed one (profiles/valu_calib_r06.json).
+#ifndef GS_BWDQ_PK
+#define GS_BWDQ_PK 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+// waves per SIMD the q kernels are compiled for: the packed passes want a few more registers than 96 (no gain or loss
+// from 16 against 18 .. 20 resident waves per CU: measured, profiles/HISTORY.md)
+#ifndef GS_BWDQ_WAVES
+#define GS_BWDQ_WAVES (GS_BWDQ_PK ? 4 : GS_BWD_WAVES)
+#endif
 struct QLds {
     SRecQ stage[kQChunk + 1];
     float4 rare[kQChunk + 1];                          // {rx, ry, A, B}: rectangle words, unscaled conic (rare paths, flush)
@@ -1535,6 +1547,20 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
         stage_sentinel(&lds.stage[CH]);
         lds.rare[CH] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+#if GS_BWDQ_PK
+    // per-pixel state of rows 2 j, 2 j + 1 side by side (even-aligned register pairs: packed fp32 operands)
+    static_assert(PX == 4, "two packed passes");
+    v2f pyf2[2], T2[2], D2[2], vo0_2[2], vo1_2[2], vo2_2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        pyf2[j] = v2f{pyf[2 * j], pyf[2 * j + 1]};
+        T2[j] = v2f{T[2 * j], T[2 * j + 1]};
+        D2[j] = v2f{D[2 * j], D[2 * j + 1]};
+        vo0_2[j] = v2f{vo0[2 * j], vo0[2 * j + 1]};
+        vo1_2[j] = v2f{vo1[2 * j], vo1[2 * j + 1]};
+        vo2_2[j] = v2f{vo2[2 * j], vo2[2 * j + 1]};
+    }
+#endif
     const int copy = kQCopies > 1 ? ((brow + bcol) & 1) : 0;
     float2 *myrec = reinterpret_cast<float2 *>(&lds.acc[0][lane * kAccRec]);   // (8-byte aligned: 40-byte records)
     float2 *myrec1 = reinterpret_cast<float2 *>(&lds.acc[kQCopies - 1][lane * kAccRec]);
@@ -1623,10 +1649,95 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
                 const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
                 const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
+#if !GS_BWDQ_PK
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
+#endif
                 const int won = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 float *rec = &lds.acc[copy][e * kAccRec];
                 float2 *r2 = reinterpret_cast<float2 *>(rec + 2 * c0);
+#if GS_BWDQ_PK
+                // The four pixel passes as TWO packed ones (rows 2 j and 2 j + 1 in the halves of 64-bit register
+                // pairs): every add / multiply / fma of a pass is one v_pk_*_f32 for two rows, the compares, the
+                // exponential, the reciprocal and the selects stay per row.  Same operations per pixel; the six sums
+                // over the block's rows are formed as (row 0 + row 2) + (row 1 + row 3).
+                v2f su2 = {-0.0f, -0.0f}, suy2 = su2, suyy2 = su2, gr2 = su2, gg2 = su2, gb2 = su2;
+#pragma unroll
+                for (int j = 0; j < PX / 2; j++) {
+                    const v2f dy = q0.y - pyf2[j];
+                    v2f sg = __builtin_elementwise_fma(hC * dy, dy, (v2f)(hAdxdx));
+                    sg = __builtin_elementwise_fma((v2f)(Bdx), dy, sg);
+                    float vish[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int p = 2 * j + h;
+                        const float dyh = h ? dy.y : dy.x;
+                        float sgh = h ? sg.y : sg.x;
+                        if (any_binds) {
+                            asm volatile("; rectangle binds");
+                            if (sbits & 1u) {
+                                // decide exactly like the forward: its op order for sigma, rectangle applied
+                                const float4 q3 = lds.rare[e];
+                                float se = ((q3.z * dx) * dx) + (q2.w * dyh) * dyh;
+                                se = 0.5f * se;
+                                se = se + (q3.w * dx) * dyh;
+                                const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y);
+                                const uint32_t pyu = (uint32_t)(py0 + p);
+                                const bool in = (uint32_t)px >= (rx & 0xFFFFu) && (uint32_t)px < (rx >> 16) &&
+                                                pyu >= (ry & 0xFFFFu) && pyu < (ry >> 16);
+                                sgh = in ? (se + 0.0f) * kLog2e : qnan();
+                            }
+                        }
+                        const uint64_t mneed = __builtin_amdgcn_ballot_w64(e >= last[p]) &
+                                               __builtin_amdgcn_ballot_w64(__float_as_uint(sgh) <= sbits);
+                        GS_STAT(9, 1);
+                        GS_STAT(10, __builtin_popcountll(mneed));
+                        float vis = __builtin_amdgcn_exp2f(-sgh);   // sg = sigma log2(e)
+                        uint64_t mok;
+                        if (EXACT) {
+                            const uint64_t bhi = __builtin_amdgcn_ballot_w64(sgh <= q1.w);
+                            mok = mneed & bhi;
+                            if (mok != mneed) {   // some lane sits in the band
+                                asm volatile("; threshold ambiguous");
+                                bool in = false;
+                                if (__builtin_amdgcn_inverse_ballot_w64(mneed & ~bhi)) {
+                                    const float4 q3 = lds.rare[e];
+                                    float se = ((q3.z * dx) * dx) + (q2.w * dyh) * dyh;
+                                    se = 0.5f * se;
+                                    se = se + (q3.w * dx) * dyh;
+                                    vis = expf_glibc_cmem(-se);
+                                    in = q1.y * vis >= (1.0f / 255.0f);
+                                }
+                                mok |= __builtin_amdgcn_ballot_w64(in);
+                            }
+                        } else {
+                            mok = mneed & __builtin_amdgcn_ballot_w64(q1.y * vis >= (1.0f / 255.0f));
+                        }
+                        vish[h] = __builtin_amdgcn_inverse_ballot_w64(mok) ? vis : 0.0f;
+                    }
+                    const v2f vis = {vish[0], vish[1]};
+                    v2f alpha = q1.y * vis;
+                    alpha.x = fminf(alpha.x, 0.99f);
+                    alpha.y = fminf(alpha.y, 0.99f);
+                    const v2f om = 1.0f - alpha;
+                    const v2f ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                    T2[j] = T2[j] * ra;
+                    const v2f fac = alpha * T2[j];
+                    gr2 = __builtin_elementwise_fma(fac, vo0_2[j], gr2);
+                    gg2 = __builtin_elementwise_fma(fac, vo1_2[j], gg2);
+                    gb2 = __builtin_elementwise_fma(fac, vo2_2[j], gb2);
+                    const v2f cv = __builtin_elementwise_fma(
+                        (v2f)(q2.z), vo2_2[j], __builtin_elementwise_fma((v2f)(q2.y), vo1_2[j], q2.x * vo0_2[j]));
+                    const v2f v_alpha = __builtin_elementwise_fma(T2[j], cv, ra * D2[j]);
+                    D2[j] = __builtin_elementwise_fma(-fac, cv, D2[j]);
+                    const v2f u = vis * v_alpha;
+                    const v2f uy = u * dy;
+                    su2 += u;
+                    suy2 += uy;
+                    suyy2 = __builtin_elementwise_fma(uy, dy, suyy2);
+                }
+                const float su = su2.x + su2.y, suy = suy2.x + suy2.y, suyy = suyy2.x + suyy2.y;
+                const float gr = gr2.x + gr2.y, gg = gg2.x + gg2.y, gb = gb2.x + gb2.y;
+#else
 #pragma unroll
                 for (int p = 0; p < PX; p++) {
                     const float dy = q0.y - pyf[p];
@@ -1692,6 +1803,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                     suy += uy;
                     suyy = fmaf(uy, dy, suyy);
                 }
+#endif
                 const float ux = su * dx;
                 float s0, s1, s2;
                 orbit_reduce9(ux, suy, ux * dx, suy * dx, suyy, gr, gg, gb, su, s0, s1, s2);
@@ -1851,7 +1963,7 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
 }
 // The full-frame default since round 5: every tile one wave of sixteen four-lane groups (backward_wave_q).
 template <bool EXACT, bool DET>
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+__global__ void __launch_bounds__(64, GS_BWDQ_WAVES)
 k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
                        const int32_t *__restrict__ ids, const uint16_t *__restrict__ masks,
                        const int2 *__restrict__ bins, const float4 *__restrict__ packed, float bg0, float bg1,
@@ -1875,7 +1987,7 @@ struct ClassicLds {
     float acc[kAccFloats];
 };
 template <bool EXACT, bool DET>
-__global__ void __launch_bounds__(64, GS_BWD_WAVES)
+__global__ void __launch_bounds__(64, GS_BWDQ_WAVES)
 k_rasterize_backward_q_mixed(int W, int H, int tiles_x, int num_tiles, int long_len,
                              const int32_t *__restrict__ order, const int32_t *__restrict__ ids,
                              const uint16_t *__restrict__ masks, const int2 *__restrict__ bins,
