@@ -270,6 +270,30 @@ __device__ __forceinline__ void stage_sentinel(R *s) {
 // k is (S(end) - S(k)) / invG(end), S(k) = sum_{j < k} colour_j min(alpha_j, 0.99) T_fwd(j) invG(j):
 //   record k = {T_fwd(k) invG(k), S(k)},  record 0 = {invG(end), S(end)}.
 // Without hot entries invG = 1 and S is the image's own colour sum, bit for bit.
+// GS_BWD_PRIO: a backward wave sets its own issue priority (s_setprio) once per chunk.  The arbiter of a SIMD issues
+// oldest first among equal priorities and one wave gets a quarter of the SIMD's slots at most (scripts/wave_timeline.py),
+// so a launch of ~2 rounds of equal tiles (1080p: 8160 tiles on 4096 .. 4608 slots) ends with the YOUNGEST waves
+// walking alone.  Longest remaining work first is what minimises a makespan: the launch's FINAL residents — the last
+// `slots` workgroups, final_first = grid - slots — take the priority of the quarter of their list that is left
+// (3, 2, 1, 0: they progress together and end together); every wave in front of them keeps 3 (oldest first among
+// themselves: they finish staggered and hand their slots on early).  Round 6, same box: C2 backward 0.2257 -> 0.2112 ms,
+// C3 1.59 -> 1.57 ms; equalising ALL waves: 0.2123 at four per SIMD but 0.2346 at 4.5; the same in the forward
+// (six rounds of quadrant waves): nothing, left out.  profiles/HISTORY.md.
+#ifndef GS_BWD_PRIO
+#define GS_BWD_PRIO 1
+#endif
+__device__ __forceinline__ void wave_prio(int final_first, int rem, int tot) {
+#if GS_BWD_PRIO
+    if (final_first < 0) return;   // (launches that do not take part: pieces, small frames)
+    int q = 3;
+    if ((int)blockIdx.x >= final_first) q = (4 * rem > 3 * tot) ? 3 : (2 * rem > tot) ? 2 : (4 * rem > tot) ? 1 : 0;
+    q = __builtin_amdgcn_readfirstlane(q);
+    if (q == 3) __builtin_amdgcn_s_setprio(3);
+    else if (q == 2) __builtin_amdgcn_s_setprio(2);
+    else if (q == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 template <bool EXACT, int ILP, bool CK>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
@@ -997,7 +1021,7 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
               const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
               const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
               float *__restrict__ gacc, unsigned long long *__restrict__ gfix,
-              const ListPiece piece = ListPiece{0, 0, nullptr, nullptr}) {
+              const ListPiece piece = ListPiece{0, 0, nullptr, nullptr}, int final_first = -1) {
     using G = WaveGeom<PX>;
     const int lane = threadIdx.x;
     if (bg_dev) {
@@ -1123,6 +1147,7 @@ backward_wave(int tile, int wx0, int wy0, SRecB *__restrict__ stage, int *__rest
     for (int hi = wave_last; hi >= range.x; hi -= kChunk) {
 #pragma unroll
         for (int p = 0; p < PX; p++) last[p] -= kChunk;   // now relative to this chunk's first slot
+        wave_prio(final_first, hi - range.x + 1, wave_last - range.x + 1);
         __syncthreads();
         const uint32_t touch = ntouch;
         bool binds_t = false;   // this lane's entry needs the per-pixel rectangle test
@@ -1454,7 +1479,14 @@ constexpr int kQCopies = GS_BWDQ_COPIES;
 // the claim word.  (A byte-sized tag array kept QLds at 8128 bytes — TWENTY waves per CU instead of eighteen — and
 // launch_bounds(64, 4) gave sixteen; measured in round 6, same box, three interleaved bench lines each: 0.2484 /
 // 0.2476 and 0.2461 / 0.2453 against 0.2456 / 0.2478 ms at C2: the kernel does not react to 16 .. 20 waves per CU.)
+#ifndef GS_BWDQ_TAG8
+#define GS_BWDQ_TAG8 0
+#endif
+#if GS_BWDQ_TAG8
+typedef unsigned char qtag_t;
+#else
 typedef unsigned int qtag_t;
+#endif
 // GS_BWDQ_PK: the four pixel passes of a step as two PACKED ones (v_pk_add / mul / fma_f32 on the rows 2 j, 2 j + 1).
 // A wave is bound by the instructions it issues (round 6, scripts/wave_timeline.py): 44 packed instructions replace
 // 88 plain ones per step; a saturated SIMD pays ~1.6 plain ones for a packed one (profiles/valu_calib_r06.json).
@@ -1484,7 +1516,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                 const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                 const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+                float *__restrict__ gacc, unsigned long long *__restrict__ gfix, int final_first) {
     static_assert((GS_BWD_LOG2E & GS_BWD_SIGMA_THRESH) != 0, "the Q walk is written for the sigma' thresholds");
     constexpr int CH = kQChunk;
     constexpr int PX = 4;
@@ -1579,6 +1611,7 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
     for (int hi = wave_last; hi >= range.x; hi -= CH) {
 #pragma unroll
         for (int p = 0; p < PX; p++) last[p] -= CH;   // now relative to this chunk's first slot
+        wave_prio(final_first, hi - range.x + 1, wave_last - range.x + 1);
         __syncthreads();
         const uint32_t msk = nmask;
         bool binds_t = false;
@@ -1904,14 +1937,15 @@ k_rasterize_backward(int W, int H, int tiles_x, int num_tiles, const int32_t *__
                      const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                      const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                      const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                     float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+                     float *__restrict__ gacc, unsigned long long *__restrict__ gfix, int final_first) {
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
     __shared__ float acc[kAccFloats];
     int tile, wx0, wy0;
     if (!decode_wave<PX>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
     backward_wave<EXACT, DET, PX>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
-                                  bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+                                  bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix,
+                                  ListPiece{0, 0, nullptr, nullptr}, final_first);
 }
 
 // The default: four pixels per lane — one wave per tile — amortise the per-step reduction best, but leave
@@ -1931,7 +1965,7 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
                            const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                            const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                            const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                           float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+                           float *__restrict__ gacc, unsigned long long *__restrict__ gfix, int final_first) {
     __shared__ SRecB stage[kChunk + 1];
     __shared__ int sid[kChunk];
     __shared__ float acc[kAccFloats];
@@ -1945,7 +1979,8 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
         const int wx0 = (tile % tiles_x) * GS_TILE + 8 * (part & 1), wy0 = (tile / tiles_x) * GS_TILE + 8 * (part >> 1);
         if (wx0 >= W || wy0 >= H) return;
         backward_wave<EXACT, DET, 1>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1,
-                                     bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+                                     bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix,
+                                     ListPiece{0, 0, nullptr, nullptr}, final_first);
         return;
     }
     // (decode_wave<4> on the remaining workgroups; the slot decides whether the tile was taken above)
@@ -1959,7 +1994,8 @@ k_rasterize_backward_mixed(int W, int H, int tiles_x, int num_tiles, int long_le
     }
     const int wx0 = (tile % tiles_x) * GS_TILE, wy0 = (tile / tiles_x) * GS_TILE;
     backward_wave<EXACT, DET, 4>(tile, wx0, wy0, stage, sid, acc, W, H, ids, masks, bins, packed, bg0, bg1, bg2,
-                                 bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+                                 bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix,
+                                 ListPiece{0, 0, nullptr, nullptr}, final_first);
 }
 // The full-frame default since round 5: every tile one wave of sixteen four-lane groups (backward_wave_q).
 template <bool EXACT, bool DET>
@@ -1970,13 +2006,13 @@ k_rasterize_backward_q(int W, int H, int tiles_x, int num_tiles, const int32_t *
                        float bg2, const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                        const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                        const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                       float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+                       float *__restrict__ gacc, unsigned long long *__restrict__ gfix, int final_first) {
     __shared__ QLds lds;
     int tile, wx0, wy0;
     if (!decode_wave<4>(blockIdx.x, num_tiles, tiles_x, W, H, order, tile, wx0, wy0)) return;
     GS_WLOG_T0
     backward_wave_q<EXACT, DET>(tile, wx0, wy0, lds, W, H, ids, masks, bins, packed, bg0, bg1, bg2, bg_dev,
-                                final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);
+                                final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix, final_first);
     GS_WLOG_T1(tile, bins[tile].y - bins[tile].x);
 }
 // ... and with the few outlying lists of a frame taken by four waves of one pixel per lane each, exactly as in
@@ -1995,7 +2031,7 @@ k_rasterize_backward_q_mixed(int W, int H, int tiles_x, int num_tiles, int long_
                              const float *__restrict__ bg_dev, const float *__restrict__ final_Ts,
                              const int32_t *__restrict__ final_idx, const float *__restrict__ v_out,
                              const float *__restrict__ v_out_alpha, const float *__restrict__ img_raw,
-                             float *__restrict__ gacc, unsigned long long *__restrict__ gfix) {
+                             float *__restrict__ gacc, unsigned long long *__restrict__ gfix, int final_first) {
     constexpr size_t kBytes = sizeof(QLds) > sizeof(ClassicLds) ? sizeof(QLds) : sizeof(ClassicLds);
     __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
     const int b = blockIdx.x;
@@ -2010,7 +2046,7 @@ k_rasterize_backward_q_mixed(int W, int H, int tiles_x, int num_tiles, int long_
         ClassicLds &c = *reinterpret_cast<ClassicLds *>(raw);
         backward_wave<EXACT, DET, 1>(tile, wx0, wy0, c.stage, c.sid, c.acc, W, H, ids, masks, bins, packed, bg0,
                                      bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
-                                     gfix);
+                                     gfix, ListPiece{0, 0, nullptr, nullptr}, final_first);
         return;
     }
     const int bb = b - 4 * kLongSlots;
@@ -2024,7 +2060,7 @@ k_rasterize_backward_q_mixed(int W, int H, int tiles_x, int num_tiles, int long_
     const int wx0 = (tile % tiles_x) * GS_TILE, wy0 = (tile / tiles_x) * GS_TILE;
     backward_wave_q<EXACT, DET>(tile, wx0, wy0, *reinterpret_cast<QLds *>(raw), W, H, ids, masks, bins, packed,
                                 bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,
-                                gfix);
+                                gfix, final_first);
 }
 // Frames of few tiles (the reduced resolutions a training run starts with, small captures): four waves per
 // tile leave most of the chip's wave slots empty, and a lone wave issues one instruction every four cycles
@@ -2255,6 +2291,19 @@ extern "C" size_t gs_rasterize_backward_workspace_bytes_det(int N) {
 // to 2560 tiles (measured: 640x480 119 -> 105 us, 1008x756 114 -> 103 us at 20 000 Gaussians, level at
 // 1504x1000; pieces: 752x500 234 -> 171 us, 1008x756 290 -> 282 us, 1504x1000 330 -> 581 us).
 constexpr int kWaveSlots = 5120;
+// one-wave workgroups of a kernel the chip holds at once (occupancy x CUs; asked once per kernel)
+template <class K>
+static int resident_slots(K kernel) {
+    static const int slots = [&] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu <= 0)
+            return kWaveSlots;
+        return per_cu * cus;
+    }();
+    return slots;
+}
 
 static bool checkpoint_args_ok(const void *checkpoints, size_t checkpoint_bytes, int32_t seg_len,
                                int32_t max_segments, int tiles) {
@@ -2488,11 +2537,15 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
     const float *bg_dev = gs::on_device(background) ? background : nullptr;
     const float bg0 = bg_dev ? 0.f : background[0], bg1 = bg_dev ? 0.f : background[1],
                 bg2 = bg_dev ? 0.f : background[2];
+    // first workgroup of the launch's final residents (wave_prio): grid - slots; a launch of less than two rounds of
+    // waves has nothing to stagger — everybody equalises
+#define GS_FINAL_FIRST(K) std::max(units - resident_slots(K), 0)
     gs::ev_before(s);
 #define GS_BWD_LAUNCH3(EX, DT, PXN)                                                                       \
     GS_LAUNCH((gs::k_rasterize_backward<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x, \
                        tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,      \
-                       bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix)
+                       bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix,              \
+                       GS_FINAL_FIRST((gs::k_rasterize_backward<EX, DT, PXN>)))
 #define GS_SEG_LAUNCH3(EX, DT, PXN)                                                                       \
     GS_LAUNCH((gs::k_rasterize_backward_seg<EX, DT, PXN>), dim3(units), dim3(64), 0, s, W, H, tiles_x,     \
               tiles, seg_shift, (int)max_segments, ck, tile_order, gaussian_ids_sorted, block_masks, bins, \
@@ -2503,11 +2556,12 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
             GS_LAUNCH((gs::k_rasterize_backward_q_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H,      \
                       tiles_x, tiles, long_len, tile_order, gaussian_ids_sorted, block_masks, bins, pk,   \
                       bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc,      \
-                      gfix);                                                                              \
+                      gfix, GS_FINAL_FIRST((gs::k_rasterize_backward_q_mixed<EX, DT>)));                  \
         else                                                                                              \
             GS_LAUNCH((gs::k_rasterize_backward_q<EX, DT>), dim3(units), dim3(64), 0, s, W, H, tiles_x,   \
                       tiles, tile_order, gaussian_ids_sorted, block_masks, bins, pk, bg0, bg1, bg2,       \
-                      bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix);              \
+                      bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, gacc, gfix,               \
+                      GS_FINAL_FIRST((gs::k_rasterize_backward_q<EX, DT>)));                              \
     } while (0)
 #define GS_BWD_LAUNCH(EX, DT)                                                                              \
     do {                                                                                                   \
@@ -2522,7 +2576,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
             GS_LAUNCH((gs::k_rasterize_backward_mixed<EX, DT>), dim3(units), dim3(64), 0, s, W, H, \
                                tiles_x, tiles, long_len, tile_order, gaussian_ids_sorted, block_masks, bins, \
                                pk, bg0, bg1, bg2, bg_dev, final_Ts, final_idx, v_out, v_out_alpha, img_raw, \
-                               gacc, gfix);                                                                \
+                               gacc, gfix, GS_FINAL_FIRST((gs::k_rasterize_backward_mixed<EX, DT>)));      \
     } while (0)
     if (det) {
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, true); else GS_BWD_LAUNCH(true, true);
@@ -2530,6 +2584,7 @@ extern "C" int gs_rasterize_backward_ckpt(int W, int H, int N, const int32_t *ga
         if (flags & GS_FLAG_FAST_EXP) GS_BWD_LAUNCH(false, false); else GS_BWD_LAUNCH(true, false);
     }
 #undef GS_BWD_LAUNCH3
+#undef GS_FINAL_FIRST
 #undef GS_Q_LAUNCH3
 #undef GS_SEG_LAUNCH3
 #undef GS_BWD_LAUNCH
