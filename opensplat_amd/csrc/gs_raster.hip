@@ -1681,7 +1681,11 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 const float dx = q0.x - pxf;
                 const float Adxdx = (q0.z * dx) * dx, Bdx = q0.w * dx;
                 const float hAdxdx = 0.5f * Adxdx, hC = 0.5f * q1.x;
-                const bool any_binds = BINDS && __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) != 0ull;
+                // (a scalar mask, not a bool: as a bool it crossed the passes in a VGPR — v_cndmask / v_cmp per step)
+                const uint64_t bindm = BINDS ? __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) : 0ull;
+#if !GS_BWDQ_PK
+                const bool any_binds = bindm != 0ull;
+#endif
 #if !GS_BWDQ_PK
                 float su = -0.0f, suy = -0.0f, suyy = -0.0f, gr = -0.0f, gg = -0.0f, gb = -0.0f;
 #endif
@@ -1694,20 +1698,33 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 // exponential, the reciprocal and the selects stay per row.  Same operations per pixel; the six sums
                 // over the block's rows are formed as (row 0 + row 2) + (row 1 + row 3).
                 v2f su2 = {-0.0f, -0.0f}, suy2 = su2, suyy2 = su2, gr2 = su2, gg2 = su2, gb2 = su2;
+                // sigma' of all four rows in front of the per-row decisions: in the block that loaded the record the
+                // per-entry scalars fold into the packed instructions' op_sel (behind the branches the compiler
+                // copied them into register pairs: four v_mov per step)
+                v2f dy2[PX / 2], sg2[PX / 2];
 #pragma unroll
                 for (int j = 0; j < PX / 2; j++) {
-                    const v2f dy = q0.y - pyf2[j];
-                    v2f sg = __builtin_elementwise_fma(hC * dy, dy, (v2f)(hAdxdx));
-                    sg = __builtin_elementwise_fma((v2f)(Bdx), dy, sg);
+                    dy2[j] = q0.y - pyf2[j];
+                    sg2[j] = __builtin_elementwise_fma(hC * dy2[j], dy2[j], (v2f)(hAdxdx));
+                    sg2[j] = __builtin_elementwise_fma((v2f)(Bdx), dy2[j], sg2[j]);
+                    asm volatile("" : "+v"(sg2[j]), "+v"(dy2[j]));   // (stays here: the machine sinker moved it back)
+                }
+#pragma unroll
+                for (int j = 0; j < PX / 2; j++) {
+                    const v2f dy = dy2[j];
+                    const v2f sg = sg2[j];
                     float vish[2];
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int p = 2 * j + h;
                         const float dyh = h ? dy.y : dy.x;
                         float sgh = h ? sg.y : sg.x;
-                        if (any_binds) {
+                        uint64_t bm = bindm;
+                        asm volatile("" : "+s"(bm));   // (every row tests the mask itself: one s_cmp; a shared i1 was
+                                                       //  inverted through a VGPR)
+                        if (bm != 0ull) {
                             asm volatile("; rectangle binds");
-                            if (sbits & 1u) {
+                            if (__builtin_amdgcn_inverse_ballot_w64(bindm)) {
                                 // decide exactly like the forward: its op order for sigma, rectangle applied
                                 const float4 q3 = lds.rare[e];
                                 float se = ((q3.z * dx) * dx) + (q2.w * dyh) * dyh;
@@ -1844,8 +1861,9 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                 // (lane masks as scalars: the loop's exit test is one s_cmp)
                 uint64_t winm = actm & __builtin_amdgcn_ballot_w64(won == grp);
                 uint64_t pendm = actm & ~winm;
-                float2 a01 = make_float2(0.0f, 0.0f);
-                float a8 = 0.0f;
+                float2 a01;
+                float a8;
+                asm volatile("" : "=v"(a01.x), "=v"(a01.y), "=v"(a8));   // (defined, without three v_mov per step)
                 bool loaded = false;   // (wave-uniform)
                 for (;;) {
                     if (__builtin_amdgcn_inverse_ballot_w64(winm)) {
@@ -1865,15 +1883,17 @@ backward_wave_q(int tile, int tx0, int ty0, QLds &lds, int W, int H, const int32
                     // model — a wavefront-scope release / acquire pair (no instruction on gfx950) keeps the
                     // compiler from forwarding or hoisting across it.
                     wave_sync();
-                    bool w = false;
+                    int tagv;
+                    asm volatile("" : "=v"(tagv));   // (defined; the lanes that do not read it are masked below)
                     if (__builtin_amdgcn_inverse_ballot_w64(pendm)) {
                         __hip_atomic_store(mytag, (qtag_t)grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        w = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == grp;
+                        tagv = (int)__hip_atomic_load(mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         a01 = *r2;
                         a8 = rec[8];
                     }
                     loaded = true;
-                    winm = __builtin_amdgcn_ballot_w64(w);
+                    // (the compare outside the masked block: as a bool set inside it went through a VGPR)
+                    winm = pendm & __builtin_amdgcn_ballot_w64(tagv == grp);
                     pendm &= ~winm;
                 }
             }
