@@ -1479,14 +1479,7 @@ constexpr int kQCopies = GS_BWDQ_COPIES;
 // the claim word.  (A byte-sized tag array kept QLds at 8128 bytes — TWENTY waves per CU instead of eighteen — and
 // launch_bounds(64, 4) gave sixteen; measured in round 6, same box, three interleaved bench lines each: 0.2484 /
 // 0.2476 and 0.2461 / 0.2453 against 0.2456 / 0.2478 ms at C2: the kernel does not react to 16 .. 20 waves per CU.)
-#ifndef GS_BWDQ_TAG8
-#define GS_BWDQ_TAG8 0
-#endif
-#if GS_BWDQ_TAG8
-typedef unsigned char qtag_t;
-#else
 typedef unsigned int qtag_t;
-#endif
 // GS_BWDQ_PK: the four pixel passes of a step as two PACKED ones (v_pk_add / mul / fma_f32 on the rows 2 j, 2 j + 1).
 // A wave is bound by the instructions it issues (round 6, scripts/wave_timeline.py): 44 packed instructions replace
 // 88 plain ones per step; a saturated SIMD pays ~1.6 plain ones for a packed one (profiles/valu_calib_r06.json).
