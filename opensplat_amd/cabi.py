@@ -319,11 +319,23 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
     return b
 
 
+def _wait_event(ev) -> None:
+    """Host wait for an event that is a fraction of a millisecond away: poll it.  Event.synchronize() sleeps
+    once the wait is longer than the runtime's spin phase, and the wake-up then comes with the host's timer tick:
+    at BASELINE config 3 (the scan is 0.8 ms into the step) every step of a timed loop took 4.000 ms — 250 Hz —
+    whatever the kernels took (round 6).  GSPLAT_EVENT_WAIT=block restores the blocking wait."""
+    if os.environ.get("GSPLAT_EVENT_WAIT") == "block":
+        ev.synchronize()
+        return
+    while not ev.query():
+        pass
+
+
 def validate_binning(b: Binned) -> bool:
     """After a speculative bin_and_sort (typically once the forward kernel has been enqueued behind
     it): wait until the scan kernel has stored the intersection count — an event wait, the stream
     keeps running — and compare it with the capacity the id list was given."""
-    b.workspace.scan_done.synchronize()
+    _wait_event(b.workspace.scan_done)
     M = int(b.m_host[0])
     b.num_isects = M
     b.workspace.list_stats[0], b.workspace.list_stats[1] = M, int(b.m_host[1])

@@ -294,6 +294,10 @@ __device__ __forceinline__ void wave_prio(int final_first, int rem, int tot) {
     else __builtin_amdgcn_s_setprio(0);
 #endif
 }
+#ifndef GS_FWD_EARLY_ALIVE
+#define GS_FWD_EARLY_ALIVE 48
+#endif
+constexpr int kEarlyAlive = GS_FWD_EARLY_ALIVE;
 template <bool EXACT, int ILP, bool CK>
 __global__ void __launch_bounds__(64)
 k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__restrict__ order,
@@ -388,8 +392,12 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         __syncthreads();  // previous chunk fully consumed (single-wave workgroup: cheap)
         const uint32_t touch = ntouch;
         if (touch) {
+            // (the staged C carries the "rectangle binds" flag — bit 0 of the threshold word — in its SIGN as well:
+            // C > 0, the walks take |C| (a source modifier) and the one-entry walk tests the flag with ONE integer
+            // compare instead of and + compare)
             stage[lane].p0 = n0;
-            stage[lane].p1 = n1;
+            stage[lane].p1 = make_float4(__uint_as_float(__float_as_uint(n1.x) | (__float_as_uint(n1.z) << 31)),
+                                         n1.y, n1.z, n1.w);
             stage[lane].p2 = n2;
         }
         // (a walk specialised per chunk on "no staged entry's rectangle cuts its sigma_max ellipse" — two
@@ -438,35 +446,28 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
                 n0 = packed[3 * g + 0]; n1 = packed[3 * g + 1]; n2 = packed[3 * g + 2];
             }
         }
-        auto walk = [&](auto binds_tag, auto hot_tag) {
+        auto walk = [&](auto binds_tag, auto hot_tag, auto early_tag) {
           constexpr bool BINDS = decltype(binds_tag)::value;
           constexpr bool HOT = CK && decltype(hot_tag)::value;
-#if GS_FWD_QWALK
-          const uint32_t *myq = &fq[grp * kChunk];
-          int e_next = (int)myq[0];
-          for (int k = 0; k < nsteps; k++) {
-            const int e = e_next;   // (a byte offset: see fq)
+          constexpr bool EARLY = decltype(early_tag)::value;
+          static_assert(GS_FWD_QWALK != 0, "the one-entry walk reads its queue (the scalar walk: walk2 only)");
+          // One step: the group's next entry (e: the staged record's byte offset, see fq).  The walk takes the queue
+          // words in PAIRS (one 8-byte LDS read and one address increment per two steps) and runs two steps per
+          // iteration: the transmittance of step 2 k + 1 lands in the register step 2 k read it from (a single-step
+          // loop copied it every step), and the last contributor is remembered as the queue WORD, which is in a
+          // register anyway (round 6: 44 -> 42.5 VALU per step).
+          const auto step = [&](const int e, const uint32_t *const qnext) {
             const SRec &rec = *reinterpret_cast<const SRec *>(reinterpret_cast<const char *>(stage) + e);
             const float4 q0 = rec.p0, q1 = rec.p1, q2 = rec.p2;
-            e_next = (int)myq[k + 1];
-#else
-          uint32_t ep_next;
-          { GS_WALK_PACK(ep0_) ep_next = ep0_; }
-          while (ep_next != kWalkDone) {
-            const uint32_t ep = ep_next;
-            const int e = (int)((ep >> gsh) & 0xFFu);
-            const float4 q0 = stage[e].p0, q1 = stage[e].p1, q2 = stage[e].p2;
-            { GS_WALK_PACK(ep1_) ep_next = ep1_; asm volatile("" : "+s"(ep_next)); }
-#endif
             const uint32_t sbits = __float_as_uint(q1.z);
             GS_STAT(0, 1);
             const float dx = q0.x - pxf, dy = q0.y - pyf;
             // sigma = 0.5f * (A*x*x + C*y*y) + B*x*y, gsplat_cpu.cpp:213-217 (same op order)
-            float sg = (q0.z * dx) * dx + (q1.x * dy) * dy;
+            float sg = (q0.z * dx) * dx + (__builtin_fabsf(q1.x) * dy) * dy;
             sg = 0.5f * sg;
             sg = sg + (q0.w * dx) * dy;
             // (lane predicates as 64-bit scalar masks + inverse_ballot: one compare per predicate)
-            const uint64_t mbinds = BINDS ? __builtin_amdgcn_ballot_w64((sbits & 1u) != 0u) : 0ull;
+            const uint64_t mbinds = BINDS ? __builtin_amdgcn_ballot_w64((int)__float_as_uint(q1.x) < 0) : 0ull;
             if (BINDS && mbinds != 0ull) {
                 // rare: some group's Gaussian has a rectangle that cuts its sigma_max ellipse —
                 // apply the rectangle per pixel (and turn -0.0 into +0.0, see gs_pack_splats)
@@ -480,8 +481,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             }
             // 0 <= sigma <= sigma_max as ONE unsigned compare of the bit patterns
             const uint64_t mneed = __builtin_amdgcn_ballot_w64(__float_as_uint(sg) <= sbits);
-            if (mneed == 0ull) continue;
-            GS_STAT(1, 1);
+            // Nobody needs the entry: 0.05 % of the steps at C2, 10 % at C3 (quadrants most of whose pixels are
+            // finished).  The exit's join keeps the transmittance in two registers — a copy per step — so only the
+            // walk of such chunks (EARLY) has it.
+            if (EARLY && mneed == 0ull) return;
+            GS_STAT(1, mneed != 0ull);
             GS_STAT(2, __builtin_popcountll(mneed));
             // every lane evaluates the exponential (masking lanes off saves no issue cycle); lanes
             // that do not need the entry — sigma possibly NaN — are discarded by `ok`
@@ -505,11 +509,30 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             a2 = a2 + w * q2.z;
             if (HOT && __builtin_amdgcn_ballot_w64(alpha > 0.99f) != 0ull) rebase(alpha, T, q2);
             T = nT;
-#if GS_FWD_QWALK
-            lq = ok ? myq + k + 1 : lq;   // (the address the walk holds anyway: e dies with its reads, no copy)
-#else
+            // the last contributor: the queue word (in a register pair for two steps anyway) — or, where the word is
+            // read one step ahead, the address the walk holds: that e dies with its reads, no copy at the back edge
+            (void)qnext;
             le = ok ? e : le;
-#endif
+          };
+          // four steps per iteration on two register pairs that swap roles (a pair carried across a two-step
+          // iteration was copied at its back edge)
+          const uint2 *myq2 = reinterpret_cast<const uint2 *>(&fq[grp * kChunk]);
+          uint2 pa = myq2[0];
+          int k = 0;
+          for (; k + 3 < nsteps; k += 4) {
+            const uint2 pb = myq2[(k >> 1) + 1];
+            step((int)pa.x, nullptr);
+            step((int)pa.y, nullptr);
+            pa = myq2[(k >> 1) + 2];
+            step((int)pb.x, nullptr);
+            step((int)pb.y, nullptr);
+          }
+          if (k < nsteps) {   // one to three steps left (nsteps is wave-uniform)
+            step((int)pa.x, nullptr);
+            if (k + 1 < nsteps) {
+                step((int)pa.y, nullptr);
+                if (k + 2 < nsteps) step((int)myq2[(k >> 1) + 1].x, nullptr);
+            }
           }
         };
         // Two entries of a group's list per step: the second entry's sigma / exponential / alpha do not
@@ -549,8 +572,8 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             const uint32_t sba = __float_as_uint(qa1.z), sbb = __float_as_uint(qb1.z);
             GS_STAT(0, 1);
             const float dxa = qa0.x - pxf, dya = qa0.y - pyf, dxb = qb0.x - pxf, dyb = qb0.y - pyf;
-            float sga = (qa0.z * dxa) * dxa + (qa1.x * dya) * dya;
-            float sgb = (qb0.z * dxb) * dxb + (qb1.x * dyb) * dyb;
+            float sga = (qa0.z * dxa) * dxa + (__builtin_fabsf(qa1.x) * dya) * dya;   // (|C|: see the staging)
+            float sgb = (qb0.z * dxb) * dxb + (__builtin_fabsf(qb1.x) * dyb) * dyb;
             sga = 0.5f * sga;
             sgb = 0.5f * sgb;
             sga = sga + (qa0.w * dxa) * dya;
@@ -619,14 +642,18 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
         if constexpr (ILP == 2) {
             if (chunk_hot) walk2(std::true_type{}, std::true_type{}); else walk2(std::true_type{}, std::false_type{});
         } else {
-            if (chunk_hot) walk(std::true_type{}, std::true_type{});
-            else if (chunk_binds) walk(std::true_type{}, std::false_type{});
-            else walk(std::false_type{}, std::false_type{});
+            // (fewer than kEarlyAlive pixels of the quadrant still open: the walk that leaves a step nobody needs)
+            const bool early = __builtin_popcountll(alive) < kEarlyAlive;
+            if (chunk_hot) walk(std::true_type{}, std::true_type{}, std::true_type{});
+            else if (!chunk_binds) walk(std::false_type{}, std::false_type{}, std::true_type{});
+            else if (early) walk(std::true_type{}, std::false_type{}, std::true_type{});
+            else walk(std::true_type{}, std::false_type{}, std::false_type{});
         }
 #if GS_FWD_QWALK
-        // (lq: one word past the queue word of the lane's last composited entry; the word is a stage offset, a
-        // multiple of 48 up to 63 * 48: the slot by multiply-and-shift, once per chunk)
+        // (the last composited entry as its queue word — walk: le — or one word past it — walk2: lq —; the word is
+        // a stage offset, a multiple of 48 up to 63 * 48: the slot by multiply-and-shift, once per chunk)
         if (lq) last = c0 + (int)((lq[-1] * 43691u) >> 21);
+        else if (ILP == 1 && le >= 0) last = c0 + (int)(((uint32_t)le * 43691u) >> 21);
         lq = nullptr;
 #else
         last = le >= 0 ? c0 + le : last;
