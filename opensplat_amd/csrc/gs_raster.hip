@@ -60,6 +60,12 @@
 // block (backward_wave_q: orbit reduction, claimed plain read-add-write instead of LDS atomics), the four-group
 // backward_wave below stays for frames of few tiles, the pieces, outlying lists and big splats.
 //
+// Round 6: (a) the backward waves set their own issue priority (wave_prio: the launch's final residents by the work
+// they have left, everyone in front of them at the top) — the tail of a launch of ~2 rounds of equal tiles, taken from
+// the arbiter's side: C2 backward -5.5 %; (b) both walks read from `hipcc -S`: the q walk 135 -> 125 VALU per step
+// (C3 -3.2 %), the forward walk four steps per iteration on two swapping pairs of queue words, 44 -> ~41.5 (C2 / C3
+// -2.6 %); (c) packed fp32 passes in the q walk; same bits throughout.
+//
 // Roofline: HBM traffic is one 48-byte gather per entry (per wave of the tile, served by L2) plus
 // 20 B per pixel; DESIGN.md states the algorithmic bytes used for roofline.achieved and the VALU
 // accounting.  Measured history of both kernels: DESIGN.md 4.1, profiles/.
@@ -452,11 +458,11 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
           constexpr bool EARLY = decltype(early_tag)::value;
           static_assert(GS_FWD_QWALK != 0, "the one-entry walk reads its queue (the scalar walk: walk2 only)");
           // One step: the group's next entry (e: the staged record's byte offset, see fq).  The walk takes the queue
-          // words in PAIRS (one 8-byte LDS read and one address increment per two steps) and runs two steps per
-          // iteration: the transmittance of step 2 k + 1 lands in the register step 2 k read it from (a single-step
-          // loop copied it every step), and the last contributor is remembered as the queue WORD, which is in a
-          // register anyway (round 6: 44 -> 42.5 VALU per step).
-          const auto step = [&](const int e, const uint32_t *const qnext) {
+          // words in PAIRS (one 8-byte LDS read and one address increment per two steps) and runs FOUR steps per
+          // iteration: without a join between two steps the transmittance of a step lands in the register the step
+          // before read it from (a single-step loop copied it every step), and the last contributor is remembered as
+          // the queue WORD, which is in a register anyway (round 6: 44 -> ~41.5 VALU per step, profiles/HISTORY.md).
+          const auto step = [&](const int e) {
             const SRec &rec = *reinterpret_cast<const SRec *>(reinterpret_cast<const char *>(stage) + e);
             const float4 q0 = rec.p0, q1 = rec.p1, q2 = rec.p2;
             const uint32_t sbits = __float_as_uint(q1.z);
@@ -511,7 +517,6 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
             T = nT;
             // the last contributor: the queue word (in a register pair for two steps anyway) — or, where the word is
             // read one step ahead, the address the walk holds: that e dies with its reads, no copy at the back edge
-            (void)qnext;
             le = ok ? e : le;
           };
           // four steps per iteration on two register pairs that swap roles (a pair carried across a two-step
@@ -521,17 +526,17 @@ k_rasterize_forward(int W, int H, int tiles_x, int num_tiles, const int32_t *__r
           int k = 0;
           for (; k + 3 < nsteps; k += 4) {
             const uint2 pb = myq2[(k >> 1) + 1];
-            step((int)pa.x, nullptr);
-            step((int)pa.y, nullptr);
+            step((int)pa.x);
+            step((int)pa.y);
             pa = myq2[(k >> 1) + 2];
-            step((int)pb.x, nullptr);
-            step((int)pb.y, nullptr);
+            step((int)pb.x);
+            step((int)pb.y);
           }
           if (k < nsteps) {   // one to three steps left (nsteps is wave-uniform)
-            step((int)pa.x, nullptr);
+            step((int)pa.x);
             if (k + 1 < nsteps) {
-                step((int)pa.y, nullptr);
-                if (k + 2 < nsteps) step((int)myq2[(k >> 1) + 1].x, nullptr);
+                step((int)pa.y);
+                if (k + 2 < nsteps) step((int)myq2[(k >> 1) + 1].x);
             }
           }
         };
