@@ -100,11 +100,13 @@ def test_ten_argument_call_matches_the_oracle(name, restated):
     got2d = dict(v_xy=np_(p[0].grad), v_conic=np_(p[3].grad), v_colors=np_(rgb.grad),
                  v_opacity=np_(P["opac"].grad).ravel())
     if name == "needles":
-        # A needle thousands of pixels long: sigma = 0.5 (A dx^2 + C dy^2) + B dx dy cancels four orders of
-        # magnitude, so its fp32 value depends on the association — the backward kernel evaluates it with
-        # fused multiply-adds (the DECISIONS are the forward's, exactly: image and final_Ts above are
-        # bit-exact), gsplat-cpu rounds every product; neither is closer to the real number.  The needles'
-        # own gradients agree to 1e-3 of the largest, every other Gaussian's to summation order.
+        # A needle thousands of pixels long: in v_xy = sum over pixels of v_sigma (A dx + B dy) the two products cancel
+        # four orders of magnitude.  gsplat-cpu forms the bracket per pixel, the backward kernel sums the moments
+        # sum(v_sigma dx), sum(v_sigma dy) per entry and combines them once: the cancellation amplifies different
+        # roundings, neither is closer to the real number (the DECISIONS are the forward's, exactly: image and final_Ts
+        # above are bit-exact; sigma itself is not the cause — measured in round 6 with the reference's own unfused
+        # sigma in the kernel: same error to eight digits).  The needles' own gradients agree to 1e-3 of the largest
+        # (measured: v_xy 2.3e-4, the others <= 1.1e-5), every other Gaussian's to summation order.
         rest = np.ones(s.N, bool)
         rest[s.extra["needles"]] = False
         for k, a in got2d.items():
