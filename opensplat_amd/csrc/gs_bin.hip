@@ -751,6 +751,61 @@ __device__ __forceinline__ void sort_in_global(uint4 *__restrict__ recs, int n, 
 //      depths — pathological) the whole segment is re-sorted with the bitonic network instead.
 // CAP: segment capacity in keys; B: buckets; NT: threads.  LDS: 10*CAP + 4*B (+ a few words).
 constexpr int kMaxBucket = 24;
+// Bucket of a depth key.  Rounds 1 - 5: (key - min) >> shift — linear in the float's BITS, i.e. logarithmic in the depth:
+// depths spread evenly between 1 and 100 put a third of the keys into the twelfth of the buckets that the top binade
+// owns, and the lanes that own those buckets finish them alone (insertion sort, a chain of LDS round trips).  Round 6
+// (GS_SORT_LINEAR): linear in the DEPTH — bucket = (int)((depth - nearest) * B / (farthest - nearest)), every step of
+// which is monotone in the depth (rounded subtraction, multiplication by a positive constant, truncation), so the
+// buckets are still ordered; whenever nearest / farthest are not finite or too close for the scale the bit-linear
+// map stays.  The sorted lists are the same either way (ties and in-bucket order by the full (depth key, id) key).
+// Measured (profiles/r06/exp_sort_linear/): the long class on the hot-spot scene 27.3 -> 15.8 us, at 4K 47.6 -> 23.4 us.
+#ifndef GS_SORT_LINEAR
+#define GS_SORT_LINEAR 1
+#endif
+struct BucketMap {
+    uint32_t mn;
+    int shift;
+    float fmin, scale;   // scale > 0: the linear map
+    int last;
+};
+__device__ __forceinline__ float key_depth(uint32_t k) {   // inverse of the order-preserving image of a float
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+template <bool LIN>
+__device__ __forceinline__ BucketMap bucket_map(uint32_t mn, uint32_t mx, int B) {
+    BucketMap m;
+    m.mn = mn;
+    m.last = B - 1;
+    const uint32_t span = mx - mn;
+    int shift = 0;
+    while ((span >> shift) >= (uint32_t)B) shift++;
+    m.shift = shift;
+    m.fmin = 0.0f;
+    m.scale = 0.0f;
+    if (LIN && GS_SORT_LINEAR) {
+        const float lo = key_depth(mn), hi = key_depth(mx);
+        const float width = hi - lo;
+        if (mx > mn && fabsf(lo) < 3.0e38f && fabsf(hi) < 3.0e38f && width > 1.0e-30f && width < 3.0e38f) {
+            const float sc = (float)B / width;
+            if (sc < 3.0e38f) {
+                m.fmin = lo;
+                m.scale = sc;
+            }
+        }
+    }
+    return m;
+}
+template <bool LIN>
+__device__ __forceinline__ int bucket_of(const BucketMap &m, uint32_t key) {
+    if (LIN && GS_SORT_LINEAR) {
+        if (m.scale > 0.0f) return min((int)((key_depth(key) - m.fmin) * m.scale), m.last);
+    }
+    return (int)((key - m.mn) >> m.shift);
+}
+// buckets of the 8192-key class (k_bucket_sort_tiles<8192, B, 1024>)
+#ifndef GS_LONG_BUCKETS
+#define GS_LONG_BUCKETS 8192
+#endif
 
 template <int NT>
 __device__ __forceinline__ void block_minmax(uint32_t &mn, uint32_t &mx, uint32_t *scratch) {
@@ -784,16 +839,13 @@ __device__ __forceinline__ void insertion_sort_bucket(uint64_t *out, uint16_t *o
 }
 
 template <int CAP, int B, int NT>
-__global__ void __launch_bounds__(NT)
-k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict__ bins,
-                    uint4 *__restrict__ keys, int32_t *__restrict__ ids_sorted,
-                    uint16_t *__restrict__ masks) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void bucket_sort_one_tile(const int2 range, int lo_n, int hi_n, int32_t capacity,
+                                                     uint4 *__restrict__ keys, int32_t *__restrict__ ids_sorted,
+                                                     uint16_t *__restrict__ masks, unsigned char *smem) {
     uint64_t *out = reinterpret_cast<uint64_t *>(smem);           // CAP keys
     int32_t *cnt = reinterpret_cast<int32_t *>(out + CAP);         // B counters / cursors
     uint32_t *scratch = reinterpret_cast<uint32_t *>(cnt + B);     // 2 * NT/64 + NT/64 + 1 words (64 reserved)
     uint16_t *outm = reinterpret_cast<uint16_t *>(scratch + 64);   // CAP masks
-    const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
     if (n <= lo_n) return;
@@ -803,21 +855,35 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
         return;
     }
     const uint4 *src = keys + start;
+    // the records ONCE into registers (CAP / NT per thread, all loads in flight together): the three passes below
+    // used to read them from global memory one after the other — three round trips of a lone workgroup
+    static_assert(CAP % NT == 0, "k_bucket_sort_tiles: CAP must be a multiple of the block size");
+    constexpr int PL = CAP / NT;
+    uint4 rr[PL];
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        const int i = j * NT + tid;
+        rr[j] = i < n ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
     // 1. range of the depth keys
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (int i = tid; i < n; i += NT) {
-        const uint32_t d = src[i].x;
-        mn = min(mn, d);
-        mx = max(mx, d);
-    }
+#pragma unroll
+    for (int j = 0; j < PL; j++)
+        if (j * NT + tid < n) {
+            mn = min(mn, rr[j].x);
+            mx = max(mx, rr[j].x);
+        }
     block_minmax<NT>(mn, mx, scratch);
-    const uint32_t span = mx - mn;
-    int shift = 0;
-    while ((span >> shift) >= (uint32_t)B) shift++;
+    const BucketMap bm = bucket_map<true>(mn, mx, B);
     // 2. histogram
     for (int i = tid; i < B; i += NT) cnt[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += NT) atomicAdd(&cnt[(src[i].x - mn) >> shift], 1);
+    int bk[PL];   // (the bucket of each record, kept for the scatter pass)
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+        bk[j] = bucket_of<true>(bm, rr[j].x);
+        if (j * NT + tid < n) atomicAdd(&cnt[bk[j]], 1);
+    }
     __syncthreads();
     //    exclusive scan of the B counters: each thread owns B/NT consecutive ones
     constexpr int PER = B / NT;
@@ -853,12 +919,13 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
     __syncthreads();
     if (longest > kMaxBucket) atomicOr(flag, 1u);
     // 3. scatter into bucket order
-    for (int i = tid; i < n; i += NT) {
-        const uint4 r = src[i];
-        const int pos = atomicAdd(&cnt[(r.x - mn) >> shift], 1);
-        out[pos] = rec_key(r);
-        outm[pos] = (uint16_t)r.z;
-    }
+#pragma unroll
+    for (int j = 0; j < PL; j++)
+        if (j * NT + tid < n) {
+            const int pos = atomicAdd(&cnt[bk[j]], 1);
+            out[pos] = rec_key(rr[j]);
+            outm[pos] = (uint16_t)rr[j].z;
+        }
     __syncthreads();
     if (*flag) {
         // many equal / clustered depths: bitonic network on the LDS copy (virtual padding)
@@ -881,6 +948,39 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, const int2 *__restrict
     }
 }
 
+// One workgroup per tile (order == nullptr: grid = tiles; a tile outside (lo_n, ...] costs its workgroup's dispatch:
+// 8160 x 16 waves launched to find nine lists beyond 1024 entries on the hot-spot scene, 3 of the launch's 33 us there,
+// 39 us for the 256-thread class of round 2 at 4K), or — round 6 — a SMALL grid that walks the head of `tile_order`: the scan leaves the tiles sorted by descending class
+// (length >> order_shift(longest)), so the lists of this size class are its first entries and a workgroup stops at
+// the first tile of a lower class than lo_n + 1's (tiles of that class itself may be on either side of lo_n: skipped).
+// The class and the stop test use the UNCLAMPED length, as the order does; the shift follows from order[0], which is
+// in the longest list's class.
+template <int CAP, int B, int NT>
+__global__ void __launch_bounds__(NT)
+k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles, const int32_t *__restrict__ order,
+                    const int2 *__restrict__ bins, uint4 *__restrict__ keys, int32_t *__restrict__ ids_sorted,
+                    uint16_t *__restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!order) {
+        bucket_sort_one_tile<CAP, B, NT>(bins[blockIdx.x], lo_n, hi_n, capacity, keys, ids_sorted, masks, smem);
+        return;
+    }
+    // (On a frame whose id list is too small the short class clamps overflowing ranges to {min(start, capacity),
+    // capacity} — behind this launch today, but nothing here relies on that: a range that ends at `capacity` may be a
+    // clamped one, its length then says nothing about its class.  Such a tile never stops the walk, and if it is
+    // order[0] nothing does: the frame is repeated anyway, what counts is that no list is left unsorted.)
+    const int2 first = bins[order[0]];
+    const bool can_stop = first.y != capacity;
+    const int shift = order_shift(first.y - first.x);
+    const int stop_class = (lo_n + 1) >> shift;
+    for (int i = blockIdx.x; i < tiles; i += gridDim.x) {
+        const int2 range = bins[order[i]];
+        if (can_stop && range.y != capacity && ((range.y - range.x) >> shift) < stop_class) break;
+        bucket_sort_one_tile<CAP, B, NT>(range, lo_n, hi_n, capacity, keys, ids_sorted, masks, smem);
+        __syncthreads();   // the LDS buffers are the next tile's
+    }
+}
+
 // Single-wave variant for the common short segments (n <= 64*PL keys): the records are loaded ONCE
 // into registers (PL per lane), bucket b is owned by lane b % 64 (conflict-free LDS access), the
 // exclusive scan is B/64 DPP wave scans.  LDS: 10*64*PL + 4*B bytes (7 KiB for PL = 8, B = 512),
@@ -898,15 +998,19 @@ __device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     }
-    const uint32_t span = mx - mn;
-    int shift = 0;
-    while ((span >> shift) >= (uint32_t)B) shift++;
+    // (the linear map where a launch is ONE round of waves that each wait for their slowest lane — the 512-key class at
+    // C2: 27.0 -> 24.7 us; the 1024-key class, ten rounds of waves at C3, measured 5 % SLOWER with it: 243 -> 255 us)
+    constexpr bool LIN = PL <= 8;
+    const BucketMap bm = bucket_map<LIN>(mn, mx, B);
 #pragma unroll
     for (int j = 0; j < PER; j++) cnt[j * 64 + lane] = 0;
     __syncthreads();
+    int bk[PL];   // (the bucket of each record, kept for the scatter pass)
 #pragma unroll
-    for (int j = 0; j < PL; j++)
-        if (j * 64 + lane < n) atomicAdd(&cnt[((uint32_t)(kk[j] >> 32) - mn) >> shift], 1);
+    for (int j = 0; j < PL; j++) {
+        bk[j] = bucket_of<LIN>(bm, (uint32_t)(kk[j] >> 32));
+        if (j * 64 + lane < n) atomicAdd(&cnt[bk[j]], 1);
+    }
     __syncthreads();
     // exclusive scan, bucket b = j*64 + lane
     int32_t local[PER];
@@ -924,7 +1028,7 @@ __device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const
 #pragma unroll
     for (int j = 0; j < PL; j++)
         if (j * 64 + lane < n) {
-            const int pos = atomicAdd(&cnt[((uint32_t)(kk[j] >> 32) - mn) >> shift], 1);
+            const int pos = atomicAdd(&cnt[bk[j]], 1);
             out[pos] = kk[j];
             outm[pos] = (uint16_t)(mm[j >> 1] >> (16 * (j & 1)));
         }
@@ -1548,9 +1652,11 @@ static BinLayout bin_layout(int N, int64_t capacity, int W, int H) {
 
 // The per-tile sorts of section 4 over every tile's segment of `keys`: which size classes are launched follows
 // the previous frame's statistics.
+// order: the frame's tile_order if the scan has written it (nullptr otherwise): the long class then walks its head
+// with a small grid instead of launching a 1024-thread workgroup for every tile (k_bucket_sort_tiles).
 static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_stats, int2 *bins_rw,
                              uint4 *keys, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
-                             hipStream_t s) {
+                             hipStream_t s, const int32_t *order = nullptr) {
     const int2 *bins = bins_rw;
     // Every class also moves the coverage masks (third word of the records) along with the keys.
     // segments <= 512 keys: one wave, keys in registers, 512 buckets (6 KiB LDS); <= 1024 keys:
@@ -1581,9 +1687,16 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     // few tiles, long lists: the 8192 class for what is beyond 1024 keys and the 1024 class for everything else
     // (20 000 Gaussians at 384x288: 30 + 28 + 19 us with the 512 class as a third launch)
     const bool few_long = have_stats && !no_long && tiles <= 1024;
-    // (Launching the classes side by side on helper streams — they work on disjoint tiles, every class clamps the
-    // ranges it reads by `capacity` itself — was built and measured in round 5: each launch got slower by what it
-    // shared, the stage 0.233 -> 0.251 ms on the hot-spot scene.  In a row.)
+    // (Launching the classes side by side on streams of the library's own — they work on disjoint tiles, every class
+    // clamps the ranges it reads by `capacity` itself — was built and measured twice: in round 5 as three full grids
+    // (each launch got slower by what it shared, the stage 0.233 -> 0.251 ms on the hot-spot scene), in round 6 with
+    // the long class as the small-grid walk below and the mid class on a second stream (fork / join events around
+    // them: the step 0.682 against 0.681 ms on the hot-spot scene, the instrumented stage 0.226 against 0.216 — what
+    // the overlap gains the cross-stream waits cost).  In a row.)
+    // The long class walks the head of tile_order on a small grid.  (A longest list of 2^20 entries and more:
+    // order_shift is then so wide that the class of 1025 is the lowest one and nothing can stop the walk — one
+    // workgroup per tile as before.)
+    const bool walk = !no_long && order != nullptr && !(have_stats && list_stats[1] >= (1 << 20));
     if (!only_short && !few_long) {
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
                            capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
@@ -1593,13 +1706,13 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
         // 1024 threads per tile: the few tiles of this class are latency chains of one workgroup each —
         // with 256 threads 77 us for the nine 5 - 8 k-entry lists of the hot-spot scene, 36 us with 1024
         // (bin_sort 0.272 -> 0.233 ms there)
-        constexpr int CAP = 8192, B = 4096, NT = 1024;
+        constexpr int CAP = 8192, B = GS_LONG_BUCKETS, NT = 1024;
         const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
         GS_HIP_CHECK(hipFuncSetAttribute(
             reinterpret_cast<const void *>(k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GS_LAUNCH((k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024,
-                           CAP, capacity, bins, keys, gaussian_ids_sorted, block_masks);
+        GS_LAUNCH((k_bucket_sort_tiles<CAP, B, NT>), dim3(walk ? (tiles < 256 ? tiles : 256) : tiles), dim3(NT), lds,
+                  s, 1024, CAP, capacity, tiles, walk ? order : nullptr, bins, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
@@ -1859,12 +1972,12 @@ extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float 
             GS_LAUNCH_CHECK();
         }
         if (!no_long) {
-            constexpr int CAP = 8192, B = 4096, NT = 1024;
+            constexpr int CAP = 8192, B = GS_LONG_BUCKETS, NT = 1024;
             const size_t lds = 8 * CAP + 4 * B + 256 + 2 * CAP;
             GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_bucket_sort_tiles<CAP, B, NT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            GS_LAUNCH((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024, CAP, capacity, bins,
-                      keys, gaussian_ids_sorted, block_masks);
+            GS_LAUNCH((gs::k_bucket_sort_tiles<CAP, B, NT>), dim3(tiles), dim3(NT), lds, s, 1024, CAP, capacity, tiles,
+                      (const int32_t *)nullptr, bins, keys, gaussian_ids_sorted, block_masks);
             GS_LAUNCH_CHECK();
         }
 #undef GS_FUSED
@@ -1922,7 +2035,7 @@ extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const f
               num_isects_host, tile_order, keys);
     GS_LAUNCH_CHECK();
     return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
-                                 gaussian_ids_sorted, block_masks, s);
+                                 gaussian_ids_sorted, block_masks, s, tile_order);
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "hot"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "hot", "c3hot"])
     ap.add_argument("--iters", type=int, default=200)
     args = ap.parse_args()
     import torch
@@ -29,8 +29,9 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cabi.lib()
-    if args.config == "c3":
-        scene = scenes.camera_scene(5_000_000, 3840, 2160, K=16, seed=2, sigma_px=(1.0, 8.0), name="C3")
+    if args.config in ("c3", "c3hot"):
+        scene = scenes.camera_scene(5_000_000, 3840, 2160, K=16, seed=2, sigma_px=(1.0, 8.0), name="C3",
+                                    hot=(0.004 if args.config == "c3hot" else 0.0, 48))
     else:
         scene = scenes.camera_scene(1_000_000, 1920, 1080, K=16, seed=1, sigma_px=(0.5, 4.0), name="C2",
                                     hot=(0.02 if args.config == "hot" else 0.0, 48))

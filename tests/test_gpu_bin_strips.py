@@ -180,3 +180,30 @@ def test_strips_with_no_visible_gaussian_and_with_none():
     e = torch.empty((0, 12), device="cuda"), torch.empty((0,), device="cuda")
     a = _bin("strips", s.W, s.H, e[0], e[1], 64)
     assert a["M"] == 0 and not a["bins"].any()
+
+
+def test_long_class_walks_tile_order_on_a_full_frame():
+    """gs_bin_speculative launches the long sort class (> 1024 entries) as a small grid walking the head of tile_order
+    (k_bucket_sort_tiles, round 6) — here next to the mid and the short class on a 3600-tile frame with a hot spot; the
+    reference for the lists is the two-call path (gs_bin_scan + gs_bin_sort), whose long class visits every tile."""
+    s = scenes.camera_scene(300_000, 1280, 720, K=0, seed=41, hot=(0.03, 48))
+    packed, depths, tiles_hit = _packed(s)
+    M = int(np_(tiles_hit).sum())
+    b = _bin("tiles", s.W, s.H, packed, depths, M)
+    lens = b["bins"][:, 1] - b["bins"][:, 0]
+    assert (lens > 1024).sum() >= 4 and ((lens > 512) & (lens <= 1024)).sum() >= 1 and (lens <= 512).sum() > 3000
+    for stats in [None, (M, 300), (M, 800), (M, b["longest"])]:      # no, stale and exact statistics
+        _same_lists(_bin("speculative", s.W, s.H, packed, depths, M + 5, list_stats=stats), b, tiles_hit)
+    # the id list too small (the frame a caller repeats): true M, clamped bins, and every list that ends below the
+    # capacity sorted — the walk must not stop at a clamped range
+    cap = int(b["bins"][np.argmax(lens), 1]) + 700       # ends inside the tile row behind the longest list
+    assert cap < M
+    a = _bin("speculative", s.W, s.H, packed, depths, cap, list_stats=(M, b["longest"]))
+    assert a["M"] == a["M_dev"] == M
+    assert int(a["bins"].max()) <= cap and (a["bins"][:, 1] >= a["bins"][:, 0]).all()
+    whole = b["bins"][:, 1] <= cap
+    assert (lens[whole] > 1024).sum() >= 1
+    assert np.array_equal(a["bins"][whole], b["bins"][whole])
+    last = int(b["bins"][whole, 1].max())
+    assert np.array_equal(a["ids"][:last], b["ids"][:last])
+    assert np.array_equal(a["masks"][:last], b["masks"][:last])
