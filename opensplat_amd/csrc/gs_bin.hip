@@ -802,6 +802,12 @@ __device__ __forceinline__ int bucket_of(const BucketMap &m, uint32_t key) {
     }
     return (int)((key - m.mn) >> m.shift);
 }
+// buckets of the 512-key wave class: with the masks out of LDS (wave_bucket_sort) 256 buckets make 4096 + 1024 = 5120
+// bytes per wave — 32 waves per CU, the whole 8160-wave launch of a 1080p frame resident at once; 512 buckets: 26
+#ifndef GS_SHORT_BUCKETS
+#define GS_SHORT_BUCKETS 256
+#endif
+constexpr int kShortBuckets = GS_SHORT_BUCKETS;
 // buckets of the 8192-key class (k_bucket_sort_tiles<8192, B, 1024>)
 #ifndef GS_LONG_BUCKETS
 #define GS_LONG_BUCKETS 8192
@@ -837,6 +843,29 @@ __device__ __forceinline__ void insertion_sort_bucket(uint64_t *out, uint16_t *o
         outm[q + 1] = km;
     }
 }
+
+// keys only (the wave sorts: the masks stay in registers until the final positions are known)
+__device__ __forceinline__ void insertion_sort_keys(uint64_t *out, int s0, int e) {
+    for (int i = s0 + 1; i < e; i++) {
+        const uint64_t k = out[i];
+        int q = i - 1;
+        while (q >= s0 && out[q] > k) {
+            out[q + 1] = out[q];
+            q--;
+        }
+        out[q + 1] = k;
+    }
+}
+struct LdsKeys {
+    uint64_t *k;
+    int n;
+    __device__ __forceinline__ uint64_t key(int i) const { return i < n ? k[i] : ~0ull; }
+    __device__ __forceinline__ void swap(int i, int j) {
+        const uint64_t a = k[i];
+        k[i] = k[j];
+        k[j] = a;
+    }
+};
 
 template <int CAP, int B, int NT>
 __device__ __forceinline__ void bucket_sort_one_tile(const int2 range, int lo_n, int hi_n, int32_t capacity,
@@ -991,7 +1020,7 @@ k_bucket_sort_tiles(int lo_n, int hi_n, int32_t capacity, int tiles, const int32
 template <int PL, int B>
 __device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const uint32_t (&mm)[PL / 2],
                                                  uint32_t mn, uint32_t mx, int n, int lane, uint64_t *out,
-                                                 int32_t *cnt, uint16_t *outm, int32_t *__restrict__ ids_dst,
+                                                 int32_t *cnt, int32_t *__restrict__ ids_dst,
                                                  uint16_t *__restrict__ masks_dst) {
     constexpr int PER = B / 64;
     for (int off = 32; off > 0; off >>= 1) {
@@ -1030,30 +1059,38 @@ __device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const
         if (j * 64 + lane < n) {
             const int pos = atomicAdd(&cnt[bk[j]], 1);
             out[pos] = kk[j];
-            outm[pos] = (uint16_t)(mm[j >> 1] >> (16 * (j & 1)));
         }
     __syncthreads();
     if (pathological) {
         int P = 2;
         while (P < n) P <<= 1;  // P <= CAP because n <= CAP and CAP is a power of two
-        LdsRecs m{out, outm, n};
+        LdsKeys m{out, n};
         bitonic_sort(m, P, lane, 64);
     } else {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             if (local[j] < 2) continue;
             const int e = cnt[j * 64 + lane];  // cursor == end of the bucket
-            insertion_sort_bucket(out, outm, e - local[j], e);
+            insertion_sort_keys(out, e - local[j], e);
         }
         __syncthreads();
     }
+    // Only the KEYS went through LDS (round 6: the 2 bytes of mask per slot were the difference between 22 and 26 ... 32
+    // waves per CU — the 512-key class of a 1080p frame is 8160 waves).  Every lane now looks up where each of ITS
+    // records ended: inside its bucket (the cursors are the buckets' ends, a bucket starts where the one before it
+    // ends; keys are unique), and writes id and mask there itself.
 #pragma unroll
     for (int j = 0; j < PL; j++) {
-        const int i = j * 64 + lane;
-        if (i < n) {
-            ids_dst[i] = (int32_t)(uint32_t)out[i];
-            masks_dst[i] = outm[i];
+        if (j * 64 + lane >= n) continue;
+        const int b = bk[j];
+        int lo = b > 0 ? cnt[b - 1] : 0, hi = cnt[b];
+        while (hi - lo > 1) {   // (a bucket of one key: no read at all)
+            const int mid = (lo + hi) >> 1;
+            if (out[mid] <= kk[j]) lo = mid;
+            else hi = mid;
         }
+        ids_dst[lo] = (int32_t)(uint32_t)kk[j];
+        masks_dst[lo] = (uint16_t)(mm[j >> 1] >> (16 * (j & 1)));
     }
 }
 
@@ -1065,7 +1102,6 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
     constexpr int CAP = 64 * PL;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
-    __shared__ uint16_t outm[CAP];
     const int2 range = bins[blockIdx.x];
     const int start = range.x;
     const int n = min(range.y, capacity) - start;
@@ -1102,7 +1138,7 @@ k_bucket_sort_wave(int lo_n, int hi_n, int32_t capacity, int clamp_bins, int tak
             mx = max(mx, r.x);
         }
     }
-    wave_bucket_sort<PL, B>(kk, mm, mn, mx, n, lane, out, cnt, outm, ids_sorted + start, masks + start);
+    wave_bucket_sort<PL, B>(kk, mm, mn, mx, n, lane, out, cnt, ids_sorted + start, masks + start);
 }
 
 // ---- 5. coverage masks ------------------------------------------------------------------------
@@ -1414,7 +1450,6 @@ k_tile_gather_sort(int cells, int cells_x, int tiles_x, int32_t capacity, int ta
     constexpr int CAP = 64 * PL;
     __shared__ uint64_t out[CAP];
     __shared__ int32_t cnt[B];
-    __shared__ uint16_t outm[CAP];
     uint32_t *queue = reinterpret_cast<uint32_t *>(out);   // kept record indices, until the sort needs `out`
     // consecutive workgroups go to the 8 XCDs in turn: the sixteen waves of a strip are 8 apart
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
@@ -1517,7 +1552,7 @@ k_tile_gather_sort(int cells, int cells_x, int tiles_x, int32_t capacity, int ta
             mx = max(mx, d);
         }
     }
-    wave_bucket_sort<PL, B>(kk, mm, mn, mx, nfit, lane, out, cnt, outm, ids_sorted + start, masks + start);
+    wave_bucket_sort<PL, B>(kk, mm, mn, mx, nfit, lane, out, cnt, ids_sorted + start, masks + start);
 }
 
 // the same order from finished tile_bins (strip binning: the tile counts only exist once the strips have been
@@ -1720,7 +1755,7 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
                            1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     else
-        GS_LAUNCH((k_bucket_sort_wave<8, 512>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
+        GS_LAUNCH((k_bucket_sort_wave<8, kShortBuckets>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
                            1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -1963,7 +1998,7 @@ extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float 
         } else if (few_long) {
             GS_FUSED(16, 1024, 0);
         } else {
-            GS_FUSED(8, 512, only_short ? 1 : 0);
+            GS_FUSED(8, gs::kShortBuckets, only_short ? 1 : 0);
         }
         GS_LAUNCH_CHECK();
         if (!only_mid && !only_short && !few_long) {
