@@ -207,3 +207,44 @@ def test_long_class_walks_tile_order_on_a_full_frame():
     last = int(b["bins"][whole, 1].max())
     assert np.array_equal(a["ids"][:last], b["ids"][:last])
     assert np.array_equal(a["masks"][:last], b["masks"][:last])
+
+
+@pytest.mark.parametrize("dist", ["uniform", "log_wide", "two_clusters", "all_equal", "mixed_sign", "with_inf",
+                                  "tiny_range", "huge_range"])
+def test_sorted_lists_for_awkward_depth_distributions(dist):
+    """The per-tile sorts bucket the keys linearly in the DEPTH between a tile's nearest and farthest entry (round 6;
+    the bit-linear map where that range is not finite or too narrow).  Whatever the depths look like, every list must
+    come out ordered by (depth, id) — checked here against numpy, not against another path of the library — on a
+    frame with short lists (the 512-key wave class), 1024-key lists and lists beyond (the workgroup class)."""
+    import zlib
+
+    rng = np.random.RandomState(zlib.crc32(dist.encode()) % 1000)
+    s = scenes.camera_scene(60_000, 320, 200, K=0, seed=77, hot=(0.15, 40))
+    packed, depths, tiles_hit = _packed(s)
+    N = s.N
+    d = {
+        "uniform": lambda: rng.uniform(1.0, 100.0, N),
+        "log_wide": lambda: np.exp(rng.uniform(np.log(1e-3), np.log(1e6), N)),
+        "two_clusters": lambda: np.where(rng.rand(N) < 0.5, 2.0 + 1e-4 * rng.rand(N), 9.0e4 + rng.rand(N)),
+        "all_equal": lambda: np.full(N, 3.25),
+        "mixed_sign": lambda: rng.uniform(-50.0, 50.0, N),
+        "with_inf": lambda: np.where(rng.rand(N) < 0.01, np.inf, rng.uniform(1.0, 10.0, N)),
+        "tiny_range": lambda: 5.0 + rng.randint(0, 6, N) * np.float64(np.spacing(np.float32(5.0))),   # six adjacent floats
+        "huge_range": lambda: np.where(rng.rand(N) < 0.5, rng.uniform(1e-38, 1e-30, N), rng.uniform(1e30, 3e38, N)),
+    }[dist]().astype(np.float32)
+    dd = to_dev(d)
+    M = int(np_(tiles_hit).sum())
+    for which, stats in [("speculative", None), ("speculative", (M, 100000)), ("tiles", None)]:
+        r = _bin(which, s.W, s.H, packed, dd, M + 3, list_stats=stats)
+        assert r["M"] == M
+        lens = r["bins"][:, 1] - r["bins"][:, 0]
+        assert (lens > 1024).any() and ((lens > 512) & (lens <= 1024)).any() and ((lens > 0) & (lens <= 512)).any()
+        ids = r["ids"][:M]
+        assert ids.min() >= 0 and ids.max() < N
+        # the order-preserving image of the float: negatives flipped, non-negatives with the sign bit set (gs_bin.hip)
+        bits = d.view(np.uint32).astype(np.uint64)
+        key = np.where(bits & 0x80000000, ~bits & 0xFFFFFFFF, bits | 0x80000000)
+        full = (key[ids] << np.uint64(32)) | ids.astype(np.uint64)
+        for t in np.flatnonzero(lens > 1):
+            seg = full[r["bins"][t, 0]:r["bins"][t, 1]]
+            assert (seg[1:] > seg[:-1]).all(), (dist, which, int(t), int(lens[t]))
