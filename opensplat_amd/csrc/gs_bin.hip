@@ -1732,7 +1732,14 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     // order_shift is then so wide that the class of 1025 is the lowest one and nothing can stop the walk — one
     // workgroup per tile as before.)
     const bool walk = !no_long && order != nullptr && !(have_stats && list_stats[1] >= (1 << 20));
-    if (!only_short && !few_long) {
+    // A frame of mostly short lists (mean <= 300) with a few long ones — the hot-spot scene: thirty-odd lists of 513 ...
+    // 1024 entries next to nine long ones: the walking workgroups take those as well (lo_n = 512) and the 1024-key wave
+    // class — 26 us of ONE wave's latency chain per tile, a launch of its own — is not launched at all.  (Where lists
+    // of that length are the bulk of the frame, 4K with a hot spot, the wave class keeps them: 256 workgroups walking
+    // twenty thousand tiles would take ten times as long.)
+    const bool merge_mid = walk && have_stats && !few_long && !only_short &&
+                           (int64_t)list_stats[0] <= 300 * (int64_t)tiles;
+    if (!only_short && !few_long && !merge_mid) {
         GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
                            capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
@@ -1747,7 +1754,8 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
             reinterpret_cast<const void *>(k_bucket_sort_tiles<CAP, B, NT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         GS_LAUNCH((k_bucket_sort_tiles<CAP, B, NT>), dim3(walk ? (tiles < 256 ? tiles : 256) : tiles), dim3(NT), lds,
-                  s, 1024, CAP, capacity, tiles, walk ? order : nullptr, bins, keys, gaussian_ids_sorted, block_masks);
+                  s, merge_mid ? 512 : 1024, CAP, capacity, tiles, walk ? order : nullptr, bins, keys, gaussian_ids_sorted,
+                  block_masks);
         GS_LAUNCH_CHECK();
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
