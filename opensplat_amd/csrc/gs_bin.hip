@@ -808,6 +808,13 @@ __device__ __forceinline__ int bucket_of(const BucketMap &m, uint32_t key) {
 #define GS_SHORT_BUCKETS 256
 #endif
 constexpr int kShortBuckets = GS_SHORT_BUCKETS;
+// buckets of the 1024-key wave class (8192 bytes of keys + 4 per bucket).  Frames of MANY tiles, where the class runs in
+// rounds (4K: ten) and residency is what counts: 512 buckets, linear in the depth — 10 KiB, 16 waves per CU instead of
+// 13: C3 235.9 -> 224.3 us, with the linear map (which lost 5 % at 1024 buckets) 211.6 us.  Frames of few tiles, where a
+// wave is alone on its SIMD and waits for its slowest lane's insertion sorts: 1024 buckets, bit-linear as before
+// (end-to-end training on 384 x 288: 3450 / 3684 / 3430 it/s against 3381 / 3594 / 3425 with 512).
+constexpr int kMidBuckets = 512, kMidBucketsFewTiles = 1024;
+constexpr int kMidBucketsTiles = 4096;   // frames beyond: kMidBuckets
 // buckets of the 8192-key class (k_bucket_sort_tiles<8192, B, 1024>)
 #ifndef GS_LONG_BUCKETS
 #define GS_LONG_BUCKETS 8192
@@ -1027,9 +1034,9 @@ __device__ __forceinline__ void wave_bucket_sort(const uint64_t (&kk)[PL], const
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
     }
-    // (the linear map where a launch is ONE round of waves that each wait for their slowest lane — the 512-key class at
-    // C2: 27.0 -> 24.7 us; the 1024-key class, ten rounds of waves at C3, measured 5 % SLOWER with it: 243 -> 255 us)
-    constexpr bool LIN = PL <= 8;
+    // (the linear map: the 512-key class at C2 27.0 -> 24.7 us.  The 1024-key class, ten rounds of waves at C3, measured
+    // 5 % SLOWER with it at 1024 buckets (243 -> 255 us) and 6 % faster at 512 (224.3 -> 211.6): kMidBuckets)
+    constexpr bool LIN = PL <= 8 || B < 1024;
     const BucketMap bm = bucket_map<LIN>(mn, mx, B);
 #pragma unroll
     for (int j = 0; j < PER; j++) cnt[j * 64 + lane] = 0;
@@ -1714,8 +1721,12 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     const bool only_mid = no_long && !only_short &&
                           ((int64_t)list_stats[0] > 300 * (int64_t)tiles || tiles <= 1024);
     if (only_mid) {
-        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024,
-                           capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        if (tiles > kMidBucketsTiles)
+            GS_LAUNCH((k_bucket_sort_wave<16, kMidBuckets>), dim3(tiles), dim3(64), 0, s, 0, 1024,
+                               capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        else
+            GS_LAUNCH((k_bucket_sort_wave<16, kMidBucketsFewTiles>), dim3(tiles), dim3(64), 0, s, 0, 1024,
+                               capacity, 1, 1, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
         return GS_OK;
     }
@@ -1740,8 +1751,12 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     const bool merge_mid = walk && have_stats && !few_long && !only_short &&
                            (int64_t)list_stats[0] <= 300 * (int64_t)tiles;
     if (!only_short && !few_long && !merge_mid) {
-        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024,
-                           capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        if (tiles > kMidBucketsTiles)
+            GS_LAUNCH((k_bucket_sort_wave<16, kMidBuckets>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+                               capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        else
+            GS_LAUNCH((k_bucket_sort_wave<16, kMidBucketsFewTiles>), dim3(tiles), dim3(64), 0, s, 512, 1024,
+                               capacity, 0, no_long ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
         GS_LAUNCH_CHECK();
     }
     if (!no_long) {
@@ -1760,8 +1775,8 @@ static int launch_tile_sorts(int tiles, int32_t capacity, const int32_t *list_st
     }
     // (the short class last: it also clamps overflowing ranges, after the others have read them)
     if (few_long)
-        GS_LAUNCH((k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
-                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
+        GS_LAUNCH((k_bucket_sort_wave<16, kMidBucketsFewTiles>), dim3(tiles), dim3(64), 0, s, 0, 1024, capacity,
+                           1, 0, bins_rw, keys, gaussian_ids_sorted, block_masks);   // (few_long: at most 1024 tiles)
     else
         GS_LAUNCH((k_bucket_sort_wave<8, kShortBuckets>), dim3(tiles), dim3(64), 0, s, 0, 512, capacity,
                            1, only_short ? 1 : 0, bins_rw, keys, gaussian_ids_sorted, block_masks);
@@ -2002,15 +2017,15 @@ extern "C" int gs_bin_strips(int W, int H, int N, int32_t capacity, const float 
     GS_LAUNCH((gs::k_tile_gather_sort<PL, B>), dim3(waves), dim3(64), 0, s, L.cells, L.cells_x, tiles_x,       \
               capacity, TAKE, cell_bins, filt, recs, pk, bins, keys, gaussian_ids_sorted, block_masks)
         if (only_mid) {
-            GS_FUSED(16, 1024, 1);
+            GS_FUSED(16, gs::kMidBucketsFewTiles, 1);
         } else if (few_long) {
-            GS_FUSED(16, 1024, 0);
+            GS_FUSED(16, gs::kMidBucketsFewTiles, 0);
         } else {
             GS_FUSED(8, gs::kShortBuckets, only_short ? 1 : 0);
         }
         GS_LAUNCH_CHECK();
         if (!only_mid && !only_short && !few_long) {
-            GS_LAUNCH((gs::k_bucket_sort_wave<16, 1024>), dim3(tiles), dim3(64), 0, s, 512, 1024, capacity, 0,
+            GS_LAUNCH((gs::k_bucket_sort_wave<16, gs::kMidBucketsFewTiles>), dim3(tiles), dim3(64), 0, s, 512, 1024, capacity, 0,
                       no_long ? 1 : 0, bins, keys, gaussian_ids_sorted, block_masks);
             GS_LAUNCH_CHECK();
         }
