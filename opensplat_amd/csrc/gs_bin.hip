@@ -628,19 +628,53 @@ k_scatter_scan(int N, int tiles, int tiles_x, int32_t capacity, int order_mult,
         const int wave = threadIdx.x >> 6;
         const int run_len = ((tiles + 15) / 16 + 63) / 64 * 64;
         const int lo = wave * run_len, hi = min(lo + run_len, tiles);
+        // (eight loads in flight at a time — a wave's whole run at 1080p: one after the other they were eight round
+        // trips in front of the first record, twice: the counters, then this workgroup's offsets)
         int32_t carry = 0;
-        for (int i0 = lo; i0 < hi; i0 += 64) {
-            const int i = i0 + lane;
-            const int32_t c = i < hi ? counts[i] : 0;
-            const int32_t incl = wave_inclusive_scan_i(c);
-            if (i < hi) h[i] = carry + incl - c;
-            carry += __builtin_amdgcn_readlane(incl, 63);
+        for (int i0 = lo; i0 < hi; i0 += 8 * 64) {
+            int32_t c[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * 64 + lane;
+                c[j] = i < hi ? counts[i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * 64 + lane;
+                const int32_t incl = wave_inclusive_scan_i(c[j]);
+                if (i < hi) h[i] = carry + incl - c[j];
+                carry += __builtin_amdgcn_readlane(incl, 63);
+            }
         }
         if (lane == 0) ws[wave] = carry;
+        // this workgroup's offsets: requested before the barrier, added behind it
+        int32_t mb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = lo + j * 64 + lane;
+            mb[j] = i < hi ? my_base[i] : 0;
+        }
         __syncthreads();
         int32_t off = 0;
         for (int w = 0; w < wave; w++) off += ws[w];
-        for (int i = lo + lane; i < hi; i += 64) h[i] += off + my_base[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = lo + j * 64 + lane;
+            if (i < hi) h[i] += off + mb[j];
+        }
+        for (int i0 = lo + 8 * 64; i0 < hi; i0 += 8 * 64) {   // (runs beyond 512 tiles per wave: 4K)
+            int32_t m2[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * 64 + lane;
+                m2[j] = i < hi ? my_base[i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * 64 + lane;
+                if (i < hi) h[i] += off + m2[j];
+            }
+        }
     }
     __syncthreads();
     for (; (int64_t)chunk * 64 < N; chunk += stride) {
