@@ -93,11 +93,11 @@ const char *gs_strerror(int status);
 const char *gs_last_hip_error(void); /* thread-local text of the last failing HIP call */
 /* ABI version of THIS header: 10000*major + 100*minor + patch.  Bumped whenever an entry point changes its
  * argument list or an entry point is added (0.3.0: block_masks / tile_bins_rows arguments of round 3; 0.4.0:
- * round 4; 0.4.2 / 0.4.3: gs_bin_strips, gs_bin_speculative, round 6).  A consumer
+ * round 4; 0.4.2 / 0.4.3: gs_bin_strips, gs_bin_speculative, 0.4.4: gs_bin_speculative_zero, round 6).  A consumer
  * compiled against another header must refuse the library instead of calling through shifted arguments:
  * opensplat_amd/cabi.py compares gs_version() with this constant when it loads the library, libgsplat_torch.so in
  * front of its first call into it (torch_ops.cpp: current_stream()). */
-#define GS_ABI_VERSION 403
+#define GS_ABI_VERSION 404
 int gs_version(void);                /* == GS_ABI_VERSION of the header the library was built from */
 
 /* ---------------------------------------------------------------------------------------------
@@ -234,6 +234,16 @@ int gs_bin_speculative(int W, int H, int N, int32_t capacity, const float *packe
                        int32_t *num_isects_host /*pinned host int32[2], nullable*/,
                        const int32_t *list_stats /*host int32[2] of an earlier frame, nullable*/, void *workspace,
                        size_t workspace_bytes, gs_stream_t stream);
+
+/* gs_bin_speculative that ALSO zeroes a buffer of the caller's (16-byte aligned, a multiple of 16 bytes) on the way:
+ * the gradient-record workspace of the gs_rasterize_backward that follows, which may then be given
+ * GS_FLAG_RECORDS_ZEROED and skips its fill (64 MB at 1 M Gaussians: a 12.6 us kernel of its own otherwise).  The stores
+ * are issued by the count pass, which waits for its atomics most of the time; the buffer is zero once the call's
+ * launches have run, in stream order. */
+int gs_bin_speculative_zero(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                            int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                            int32_t *tile_order, int32_t *num_isects_host, const int32_t *list_stats, void *workspace,
+                            size_t workspace_bytes, void *zero_ptr /*nullable*/, size_t zero_bytes, gs_stream_t stream);
 
 /* The same lists as gs_bin_scan + gs_bin_sort through a two-level partition (round 6), in ONE call and without a
  * host synchronisation: Gaussians -> strips of sixteen consecutive tiles of a tile row (32-byte records

@@ -18,7 +18,7 @@ from . import _build
 
 GS_TILE = 16
 GS_SPLAT_DWORDS = 12
-GS_ABI_VERSION = 403   # include/gsplat_hip.h
+GS_ABI_VERSION = 404   # include/gsplat_hip.h
 GS_FLAG_FAST_EXP = 1
 GS_FLAG_LOGIT_OPACITY = 2
 GS_FLAG_CLAMP_IMAGE = 4
@@ -33,7 +33,7 @@ GS_CAM_LOG_SCALES = 1
 SYMBOLS = [
     "gs_strerror", "gs_last_hip_error", "gs_version", "gs_project_forward", "gs_project_backward",
     "gs_sh_forward", "gs_sh_backward", "gs_sh_forward_fused", "gs_sh_backward_fused", "gs_pack_splats", "gs_bin_workspace_bytes", "gs_bin_scan", "gs_bin_num_isects_offset",
-    "gs_bin_sort", "gs_bin_strips", "gs_bin_speculative", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_checkpoint_plan", "gs_rasterize_forward_ckpt",
+    "gs_bin_sort", "gs_bin_strips", "gs_bin_speculative", "gs_bin_speculative_zero", "gs_bin_and_sort", "gs_block_masks", "gs_rasterize_forward", "gs_rasterize_backward", "gs_rasterize_checkpoint_plan", "gs_rasterize_forward_ckpt",
     "gs_rasterize_backward_ckpt", "gs_rasterize_backward_workspace_bytes", "gs_rasterize_backward_workspace_bytes_det", "gs_debug_expf",
     "gs_debug_timeline", "gs_debug_timeline_read", "gs_debug_row_reduce9", "gs_debug_group_reduce9", "gs_debug_backward_uses_mfma", "gs_debug_time_next_kernel", "gs_gaussian_forward", "gs_gaussian_backward",
     "gs_sh_backward_cameras",
@@ -242,14 +242,16 @@ _BIN_MODE = os.environ.get("GSPLAT_BIN", "tiles")
 
 def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None,
                  workspace: BinWorkspace | None = None, flags=0, speculative=False,
-                 packed=None) -> Binned:
+                 packed=None, zero=None) -> Binned:
     """pack -> count + scan -> scatter + per-tile sort.
 
     Default: gs_bin_and_sort (one stream sync to read the intersection count M, like the
     reference).  speculative=True: the id buffer keeps the capacity of earlier calls and NOTHING
     synchronises; the caller enqueues the forward kernel and then calls validate_binning(), which
     drains the stream and tells whether M fitted (if not: call again — the buffers have grown).
-    packed: records already built by gaussian_forward (xys .. cov2d are then ignored)."""
+    packed: records already built by gaussian_forward (xys .. cov2d are then ignored).
+    zero (speculative only): a uint8 device tensor zeroed on the way by the count pass (gs_bin_speculative_zero) — the
+    record workspace of the rasterize_backward that follows, which then takes GS_FLAG_RECORDS_ZEROED."""
     l = lib()
     N = depths.shape[0]
     dev = depths.device
@@ -278,6 +280,8 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
             # or — GSPLAT_BIN=strips — the two-level partition of round 6 (gs_bin_strips); GSPLAT_BIN=scan_sort: the
             # two calls of rounds 1 - 5
             if _BIN_MODE == "scan_sort":
+                if zero is not None:
+                    zero.zero_()
                 _check(l.gs_bin_scan(C.c_int(W), C.c_int(H), C.c_int(N), _p(packed), _p(tile_bins),
                                      _p(tile_order), C.c_void_p(m_host.data_ptr()), _p(ws),
                                      C.c_size_t(ws_bytes), _stream()), "gs_bin_scan")
@@ -285,10 +289,18 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                                      _p(depths), _p(tile_bins), _p(ids), _p(masks), w.list_stats, _p(ws),
                                      C.c_size_t(ws_bytes), _stream()), "gs_bin_sort")
             else:
-                fn = l.gs_bin_strips if _BIN_MODE == "strips" else l.gs_bin_speculative
-                _check(fn(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed), _p(depths),
-                          _p(tile_bins), _p(ids), _p(masks), _p(tile_order), C.c_void_p(m_host.data_ptr()),
-                          w.list_stats, _p(ws), C.c_size_t(ws_bytes), _stream()), "gs_bin_speculative")
+                args = (C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed), _p(depths),
+                        _p(tile_bins), _p(ids), _p(masks), _p(tile_order), C.c_void_p(m_host.data_ptr()),
+                        w.list_stats, _p(ws), C.c_size_t(ws_bytes))
+                if _BIN_MODE == "strips":
+                    if zero is not None:
+                        zero.zero_()
+                    _check(l.gs_bin_strips(*args, _stream()), "gs_bin_strips")
+                elif zero is not None:
+                    zb = zero.numel() * zero.element_size()
+                    _check(l.gs_bin_speculative_zero(*args, _p(zero), C.c_size_t(zb), _stream()), "gs_bin_speculative_zero")
+                else:
+                    _check(l.gs_bin_speculative(*args, _stream()), "gs_bin_speculative")
             if w.scan_done is None:
                 w.scan_done = torch.cuda.Event()
             # validate_binning waits for THIS, not for the whole stream: {M, longest list} are in pinned memory once

@@ -151,8 +151,19 @@ k_count_tiles_global(int N, int tiles_x, const float4 *__restrict__ packed,
 // and reserve its ranges with a second round of returning atomics (48 -> 33 us at C2).
 __global__ void __launch_bounds__(kPersistentThreads)
 k_count_tiles(int N, int tiles, int tiles_x, const float4 *__restrict__ packed,
-              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base) {
+              int32_t *__restrict__ counts, int32_t *__restrict__ wg_base, uint4 *__restrict__ zero_ptr,
+              size_t zero_n16) {
     extern __shared__ int32_t h[];
+    // zero_ptr (gs_bin_speculative_zero, round 6): a buffer of the CALLER's to be zeroed on the way — the gradient
+    // records of the compositing backward that follows, 64 MB at 1 M Gaussians, otherwise a 12.6 us fill kernel in
+    // front of that backward.  This kernel waits 73 % of its cycles and moves 65 MB in 19 us; the stores are issued
+    // first and drain under the walk.  (Where in the step the records are zeroed does not matter to the backward —
+    // measured with the fill moved in front of the binning / the forward: step and kernel level.)
+    if (zero_ptr) {
+        const size_t total = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n16; i += total)
+            zero_ptr[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // 64-Gaussian chunks dealt out wave by wave ACROSS the workgroups (chunk = wave-major), so that a
     // few thousand Gaussians with huge rectangles still keep every CU's waves busy.  A wave walks ~4
     // chunks at 1 M Gaussians: the rectangle of the NEXT chunk is requested before the current one is
@@ -1876,7 +1887,7 @@ extern "C" int gs_bin_scan(int W, int H, int N, const float *packed, int32_t *ti
             const int blocks = gs::persistent_blocks(N);
             GS_LAUNCH(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), lds, s, N, tiles, tiles_x,
                                reinterpret_cast<const float4 *>(packed), counts,
-                               reinterpret_cast<int32_t *>(base + L.wg_base));
+                               reinterpret_cast<int32_t *>(base + L.wg_base), (uint4 *)nullptr, (size_t)0);
         } else {
             GS_LAUNCH(gs::k_count_tiles_global, dim3((N + 255) / 256), dim3(256), 0, s, N,
                                tiles_x, reinterpret_cast<const float4 *>(packed), counts);
@@ -2084,7 +2095,19 @@ extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const f
                                   int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
                                   int32_t *tile_order, int32_t *num_isects_host, const int32_t *list_stats,
                                   void *workspace, size_t workspace_bytes, gs_stream_t stream) {
+    return gs_bin_speculative_zero(W, H, N, capacity, packed, depths, tile_bins, gaussian_ids_sorted, block_masks,
+                                   tile_order, num_isects_host, list_stats, workspace, workspace_bytes, nullptr, 0,
+                                   stream);
+}
+
+extern "C" int gs_bin_speculative_zero(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
+                                       int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
+                                       int32_t *tile_order, int32_t *num_isects_host, const int32_t *list_stats,
+                                       void *workspace, size_t workspace_bytes, void *zero_ptr, size_t zero_bytes,
+                                       gs_stream_t stream) {
     GS_TRACE("gs_bin_speculative");
+    if (zero_ptr && (((uintptr_t)zero_ptr & 15u) || (zero_bytes & 15u))) return GS_ERR_INVALID_ARGUMENT;
+    if (!zero_ptr) zero_bytes = 0;
     if (N < 0 || capacity < 0 || W <= 0 || H <= 0) return GS_ERR_INVALID_ARGUMENT;
     if (W > 65535 || H > 65535) return GS_ERR_UNSUPPORTED;
     if (!tile_bins || !workspace) return GS_ERR_INVALID_ARGUMENT;
@@ -2096,6 +2119,8 @@ extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const f
     static const bool own_launch = [] { const char *e = getenv("GSPLAT_BIN_SCAN_LAUNCH"); return e && e[0] == '1'; }();
     if (own_launch || N == 0 || capacity == 0 || lds > gs::kMaxTileLds || !packed || !depths ||
         !gaussian_ids_sorted || !block_masks) {
+        // (the two-call path: the caller's buffer by a plain fill)
+        if (zero_bytes) GS_HIP_CHECK(hipMemsetAsync(zero_ptr, 0, zero_bytes, (hipStream_t)stream));
         int rc = gs_bin_scan(W, H, N, packed, tile_bins, tile_order, num_isects_host, workspace, workspace_bytes,
                              stream);
         if (rc != GS_OK) return rc;
@@ -2111,6 +2136,15 @@ extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const f
     int32_t *wg_base = reinterpret_cast<int32_t *>(base + L.wg_base);
     uint4 *keys = reinterpret_cast<uint4 *>(base + L.keys);
     const float4 *pk = reinterpret_cast<const float4 *>(packed);
+    // The count pass carries the caller's zeroes only where it has the slack: at 1 M Gaussians (64 MB) it gets 2.5 us
+    // longer and a 12 us fill kernel goes away (step 0.591 -> 0.582 ms); at 5 M (320 MB) it is a streaming kernel itself
+    // — 76 -> 150 us against the fill's 41 (measured) — and the fill stays a launch of its own.
+    constexpr size_t kZeroInCountMax = (size_t)96 << 20;
+    if (zero_bytes > kZeroInCountMax) {
+        GS_HIP_CHECK(hipMemsetAsync(zero_ptr, 0, zero_bytes, s));
+        zero_ptr = nullptr;
+        zero_bytes = 0;
+    }
     gs::timeline_before(s);
     GS_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)tiles, s));
     gs::timeline_after("memset(tile counters)", s);
@@ -2118,7 +2152,7 @@ extern "C" int gs_bin_speculative(int W, int H, int N, int32_t capacity, const f
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_count_tiles),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));
     GS_LAUNCH(gs::k_count_tiles, dim3(blocks), dim3(gs::kPersistentThreads), sizeof(int32_t) * (size_t)tiles, s, N,
-              tiles, tiles_x, pk, counts, wg_base);
+              tiles, tiles_x, pk, counts, wg_base, static_cast<uint4 *>(zero_ptr), zero_bytes / 16);
     GS_LAUNCH_CHECK();
     GS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gs::k_scatter_scan),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)gs::kMaxTileLds));

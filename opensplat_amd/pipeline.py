@@ -114,6 +114,11 @@ class HotPath:
         ws_bytes = (cabi.lib().gs_rasterize_backward_workspace_bytes_det(N) if flags & cabi.GS_FLAG_DETERMINISTIC
                     else cabi.lib().gs_rasterize_backward_workspace_bytes(N))
         self.bwd_ws = torch.empty((ws_bytes + 64,), device=dev, dtype=torch.uint8)
+        # the 64-byte gradient records are zeroed by the binning's count pass on the way (gs_bin_speculative_zero: no fill
+        # kernel in front of the compositing backward); GSPLAT_RECORDS_MEMSET=1 keeps the fill (measurement)
+        rec_bytes = cabi.lib().gs_rasterize_backward_workspace_bytes(N)
+        self.rec_zero = None if (flags & cabi.GS_FLAG_DETERMINISTIC or os.environ.get("GSPLAT_RECORDS_MEMSET") == "1"
+                                 or rec_bytes % 16) else self.bwd_ws[:rec_bytes]
         self.g2d = torch.zeros(N * 9, **f)
         self.grads = dist.GradBuffer(N, K, dev)
         # the opacity gradient goes straight into the flat all-reduce buffer
@@ -259,7 +264,7 @@ class HotPath:
                                       projmat_dev=self.pm_dev)
             mark()
             b = cabi.bin_and_sort(s.W, s.H, None, g["depths"], None, None, None, None, None, self.ws,
-                                  speculative=True, packed=g["packed"])
+                                  speculative=True, packed=g["packed"], zero=self.rec_zero)
             mark()
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_forward"])
@@ -272,7 +277,9 @@ class HotPath:
             if kernel_events is not None:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"], f["final_idx"],
-                                    self.v_out, self.flags | KEEP | ckf, workspace=self.bwd_ws, checkpoints=ck)
+                                    self.v_out, self.flags | KEEP | ckf |
+                                    (cabi.GS_FLAG_RECORDS_ZEROED if self.rec_zero is not None else 0),
+                                    workspace=self.bwd_ws, checkpoints=ck)
             mark()
             ACC = cabi.GS_FLAG_ACCUMULATE_GRADS if accumulate else 0
             gout = self.gout
@@ -345,7 +352,7 @@ class HotPath:
                                             self.features_rest, L.cam_pos, s.degrees_to_use, 0, out=L.gfwd,
                                             viewmat_dev=L.vm_dev, projmat_dev=L.pm_dev)
                 L.b = cabi.bin_and_sort(s.W, s.H, None, L.g["depths"], None, None, None, None, None, L.ws,
-                                        speculative=True, packed=L.g["packed"])
+                                        speculative=True, packed=L.g["packed"], zero=None if det else L.rec_zero)
                 L.f = cabi.rasterize_forward(s.W, s.H, L.b, self.background, self.flags, out=L.fwd)
 
         def validate(L):
@@ -357,7 +364,9 @@ class HotPath:
         def back(L, j, prev):
             with torch.cuda.stream(L.stream):
                 cabi.rasterize_backward(s.W, s.H, s.N, L.b, self.background, L.f["final_Ts"], L.f["final_idx"],
-                                        self.v_out, self.flags | KEEP, workspace=L.bwd_ws)
+                                        self.v_out, self.flags | KEEP |
+                                        (cabi.GS_FLAG_RECORDS_ZEROED if (not det and L.rec_zero is not None) else 0),
+                                        workspace=L.bwd_ws)
                 if prev is not None:
                     L.stream.wait_event(prev.done)     # the flat gradient buffer: camera order
                 gout, acc = self.gout, (cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0)
@@ -399,6 +408,9 @@ class CameraLane:
             self.fwd["img_clamped"] = torch.empty((H, W, 3), **f)
         self.bwd_ws = torch.zeros((cabi.lib().gs_rasterize_backward_workspace_bytes_det(N) + 64,),
                                   device=dev, dtype=torch.uint8)
+        rec_bytes = cabi.lib().gs_rasterize_backward_workspace_bytes(N)
+        self.rec_zero = None if (os.environ.get("GSPLAT_RECORDS_MEMSET") == "1" or rec_bytes % 16) \
+            else self.bwd_ws[:rec_bytes]    # (zeroed by the binning's count pass: HotPath.__init__)
         if loss:         # the image loss of the lane's camera (train.Trainer.train_step_batch)
             self.loss_ws = torch.empty(cabi.lib().gs_loss_workspace_bytes(W, H), device=dev, dtype=torch.uint8)
             self.loss_out = (torch.empty(3, **f), torch.empty((H, W, 3), **f))

@@ -25,6 +25,8 @@ optimiser-state surgery and the alpha reset, all on the device (include/gsplat_d
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -197,6 +199,10 @@ class Trainer:
         ws_bytes = (cabi.lib().gs_rasterize_backward_workspace_bytes_det(N) if self.deterministic
                     else cabi.lib().gs_rasterize_backward_workspace_bytes(N))
         self.bwd_ws = torch.zeros((ws_bytes + 64,), device=dev, dtype=torch.uint8)
+        # (the records are zeroed by the binning's count pass on the way — gs_bin_speculative_zero — instead of by a fill
+        # kernel in front of the compositing backward; not in deterministic mode, whose sums live elsewhere)
+        self._rec_zero = None if (self.deterministic or ws_bytes % 16 or os.environ.get("GSPLAT_RECORDS_MEMSET") == "1") \
+            else self.bwd_ws[:ws_bytes]
         self.v_xy = torch.zeros((N, 2), **f)     # d loss / d xys: the densification statistics' input
         self.rgrads = dict(v_xy=self.v_xy)
         self.gout = dict(v_means=self.grads.v_means, v_scales=self.grads.v_scales,
@@ -249,7 +255,7 @@ class Trainer:
                                       self.features_rest if self.K > 1 else None, cam_pos,
                                       degrees_to_use, flags, out=self.proj)
             b = cabi.bin_and_sort(W, H, None, p["depths"], None, None, None, None, None, self.bin_ws,
-                                  speculative=True, packed=p["packed"])
+                                  speculative=True, packed=p["packed"], zero=self._rec_zero)
             f = cabi.rasterize_forward(W, H, b, background, flags, out=self.fwd, checkpoints=ck)
             if cabi.validate_binning(b):   # id-list capacity guess was large enough
                 break
@@ -259,6 +265,7 @@ class Trainer:
         # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
         # no gradient and afterTrain returns at once (model.cpp:315)
         self._visible = b.num_isects > 0
+        self._records_clean = self._rec_zero is not None
         self._ctx = (gcam, cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
         return f["img_clamped"]
 
@@ -266,6 +273,9 @@ class Trainer:
         """d loss / d parameters into self.grads (overwritten), from d loss / d (clamped rgb)."""
         gcam, cam_pos, p, rgb_raw, b, f, flags, deg, background, W, H = self._ctx
         keep = cabi.GS_FLAG_KEEP_RECORDS | (cabi.GS_FLAG_DETERMINISTIC if self.deterministic else 0)
+        if self._rec_zero is not None and self._records_clean:
+            keep |= cabi.GS_FLAG_RECORDS_ZEROED      # (render()'s binning zeroed them; a second backward() of the same
+        self._records_clean = False                  #  render lets the library fill them as before)
         cabi.rasterize_backward(W, H, self.N, b, background, f["final_Ts"], f["final_idx"], v_rgb,
                                 flags | keep, workspace=self.bwd_ws, img_raw=f["img"],
                                 checkpoints=f.get("checkpoints"))

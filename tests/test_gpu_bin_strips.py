@@ -248,3 +248,40 @@ def test_sorted_lists_for_awkward_depth_distributions(dist):
         for t in np.flatnonzero(lens > 1):
             seg = full[r["bins"][t, 0]:r["bins"][t, 1]]
             assert (seg[1:] > seg[:-1]).all(), (dist, which, int(t), int(lens[t]))
+
+
+@pytest.mark.parametrize("mbytes", [3, 100])
+def test_speculative_binning_zeroes_a_buffer_on_the_way(mbytes):
+    """gs_bin_speculative_zero: the count pass also zeroes a buffer of the caller's (the gradient records of the
+    compositing backward that follows — no fill kernel in front of it); beyond 96 MB the library fills it with a
+    launch of its own.  Same lists as without, the whole buffer zero, nothing next to it touched."""
+    import torch
+
+    from opensplat_amd import cabi
+
+    s = scenes.camera_scene(40_000, 640, 400, K=0, seed=13)
+    packed, depths, tiles_hit = _packed(s)
+    M = int(np_(tiles_hit).sum())
+    ref = _bin("speculative", s.W, s.H, packed, depths, M + 9)
+    n = mbytes << 20
+    buf = torch.full((n + 64,), 0xA5, device="cuda", dtype=torch.uint8)
+    w = cabi.BinWorkspace()
+    for _ in range(3):
+        b = cabi.bin_and_sort(s.W, s.H, None, depths, None, None, None, None, None, w, speculative=True,
+                              packed=packed, zero=buf[16:16 + n])
+        if cabi.validate_binning(b):
+            break
+        buf.fill_(0xA5)
+    torch.cuda.synchronize()
+    assert int(buf[16:16 + n].max()) == 0
+    assert int(buf[:16].min()) == 0xA5 and int(buf[16 + n:].min()) == 0xA5
+    assert b.num_isects == M
+    assert np.array_equal(np_(b.gaussian_ids_sorted), ref["ids"][:M]) and np.array_equal(np_(b.tile_bins), ref["bins"])
+    # a misaligned buffer is refused, not half-zeroed
+    l = cabi.lib()
+    rc = l.gs_bin_speculative_zero(C.c_int(s.W), C.c_int(s.H), C.c_int(s.N), C.c_int32(M), cabi._p(packed),
+                                   cabi._p(depths), cabi._p(b.tile_bins), cabi._p(b.gaussian_ids_sorted),
+                                   cabi._p(b.block_masks), C.c_void_p(0), C.c_void_p(0), None, cabi._p(w.get(
+                                       "ws", (1,), torch.uint8, depths.device)), C.c_size_t(1),
+                                   C.c_void_p(buf.data_ptr() + 4), C.c_size_t(64), cabi._stream())
+    assert rc == -1
