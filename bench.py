@@ -236,7 +236,7 @@ def kernel_tables(N, K, M, P, stage_ms, kernel_ms, kernel_live, profiled_name):
                          if K == 16 else N * (44 + 12 * K + 112)),
         "bin_sort": ("k_count_tiles + k_scan_tiles + k_scatter + k_bucket_sort_*", N * 52 + 24 * M),
         "rasterize_fwd": ("k_rasterize_forward", 40 * M + 20 * P),
-        "rasterize_bwd": ("k_rasterize_backward (+ record memset)", 40 * M + 20 * P + 36 * N),
+        "rasterize_bwd": ("k_rasterize_backward (the records are zeroed by the binning's count pass: gs_bin_speculative_zero)", 40 * M + 20 * P + 36 * N),
         "gaussian_bwd": ("k_gaussian_backward", N * (124 + 44 + 12 * K)),
     }
     for st, (kname, nbytes) in alg.items():

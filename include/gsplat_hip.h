@@ -239,7 +239,11 @@ int gs_bin_speculative(int W, int H, int N, int32_t capacity, const float *packe
  * the gradient-record workspace of the gs_rasterize_backward that follows, which may then be given
  * GS_FLAG_RECORDS_ZEROED and skips its fill (64 MB at 1 M Gaussians: a 12.6 us kernel of its own otherwise).  The stores
  * are issued by the count pass, which waits for its atomics most of the time; the buffer is zero once the call's
- * launches have run, in stream order. */
+ * launches have run, in stream order.  Returns GS_OK_NOT_ZEROED (1: the lists are built, the buffer is UNTOUCHED) for
+ * buffers beyond 96 MB — at 5 M Gaussians the count pass has no slack for 320 MB of stores and a fill of that size is
+ * best left where it was, right in front of the backward's atomics: the caller then simply does not pass
+ * GS_FLAG_RECORDS_ZEROED. */
+#define GS_OK_NOT_ZEROED 1
 int gs_bin_speculative_zero(int W, int H, int N, int32_t capacity, const float *packed, const float *depths,
                             int32_t *tile_bins, int32_t *gaussian_ids_sorted, uint16_t *block_masks,
                             int32_t *tile_order, int32_t *num_isects_host, const int32_t *list_stats, void *workspace,

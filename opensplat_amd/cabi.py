@@ -275,6 +275,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
         ws = w.get("ws", (ws_bytes,), torch.uint8, dev)
         ids = w.get("ids_sorted", (cap,), torch.int32, dev)
         masks = w.get("block_masks", (cap,), torch.int16, dev)
+        zeroed = zero is not None     # (the fallback modes below fill it themselves)
         if speculative:
             # one call, nothing synchronises: gs_bin_speculative (tile-level kernels, the scan folded into the scatter)
             # or — GSPLAT_BIN=strips — the two-level partition of round 6 (gs_bin_strips); GSPLAT_BIN=scan_sort: the
@@ -298,7 +299,9 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
                     _check(l.gs_bin_strips(*args, _stream()), "gs_bin_strips")
                 elif zero is not None:
                     zb = zero.numel() * zero.element_size()
-                    _check(l.gs_bin_speculative_zero(*args, _p(zero), C.c_size_t(zb), _stream()), "gs_bin_speculative_zero")
+                    rc = l.gs_bin_speculative_zero(*args, _p(zero), C.c_size_t(zb), _stream())
+                    zeroed = rc == 0         # 1 = GS_OK_NOT_ZEROED: too large to ride along, the backward fills it
+                    _check(0 if rc == 1 else rc, "gs_bin_speculative_zero")
                 else:
                     _check(l.gs_bin_speculative(*args, _stream()), "gs_bin_speculative")
             if w.scan_done is None:
@@ -313,6 +316,7 @@ def bin_and_sort(W, H, xys, depths, radii, conics, colors, opacities, cov2d=None
             b = Binned(packed, tiles_hit, -1, ids, tile_bins, masks)
             b.tile_order = tile_order
             b.m_host, b.capacity, b.workspace = m_host, cap, w
+            b.zeroed = zeroed             # `zero` is zero once this call's launches have run
             b.list_stats = w.list_stats   # from the previous validated frame
             return b
         rc = l.gs_bin_and_sort(C.c_int(W), C.c_int(H), C.c_int(N), C.c_int32(cap), _p(packed),

@@ -2139,9 +2139,13 @@ extern "C" int gs_bin_speculative_zero(int W, int H, int N, int32_t capacity, co
     // The count pass carries the caller's zeroes only where it has the slack: at 1 M Gaussians (64 MB) it gets 2.5 us
     // longer and a 12 us fill kernel goes away (step 0.591 -> 0.582 ms); at 5 M (320 MB) it is a streaming kernel itself
     // — 76 -> 150 us against the fill's 41 (measured) — and the fill stays a launch of its own.
+    // Nor does a fill of that size belong anywhere near the binning: in front of the count pass it pushed the records
+    // that pass reads out of the last-level cache (74 -> 99 us), behind the sorts it cost the compositing kernels 20 us
+    // each.  The call then returns GS_OK_NOT_ZEROED and the caller leaves the fill to gs_rasterize_backward, right in
+    // front of its atomics, as before.
     constexpr size_t kZeroInCountMax = (size_t)96 << 20;
-    if (zero_bytes > kZeroInCountMax) {
-        GS_HIP_CHECK(hipMemsetAsync(zero_ptr, 0, zero_bytes, s));
+    const bool not_zeroed = zero_bytes > kZeroInCountMax;
+    if (not_zeroed) {
         zero_ptr = nullptr;
         zero_bytes = 0;
     }
@@ -2160,8 +2164,10 @@ extern "C" int gs_bin_speculative_zero(int W, int H, int N, int32_t capacity, co
               gs::order_multiplier(tiles), pk, depths, counts, wg_base, reinterpret_cast<int2 *>(tile_bins), total_dev,
               num_isects_host, tile_order, keys);
     GS_LAUNCH_CHECK();
-    return gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
-                                 gaussian_ids_sorted, block_masks, s, tile_order);
+    const int rc = gs::launch_tile_sorts(tiles, capacity, list_stats, reinterpret_cast<int2 *>(tile_bins), keys,
+                                         gaussian_ids_sorted, block_masks, s, tile_order);
+    if (rc != GS_OK) return rc;
+    return not_zeroed ? GS_OK_NOT_ZEROED : GS_OK;
 }
 
 extern "C" int gs_bin_and_sort(int W, int H, int N, int32_t capacity, const float *packed,

@@ -278,7 +278,7 @@ class HotPath:
                 cabi.time_next_kernel(*kernel_events["k_rasterize_backward"])
             cabi.rasterize_backward(s.W, s.H, s.N, b, self.background, f["final_Ts"], f["final_idx"],
                                     self.v_out, self.flags | KEEP | ckf |
-                                    (cabi.GS_FLAG_RECORDS_ZEROED if self.rec_zero is not None else 0),
+                                    (cabi.GS_FLAG_RECORDS_ZEROED if getattr(b, "zeroed", False) else 0),
                                     workspace=self.bwd_ws, checkpoints=ck)
             mark()
             ACC = cabi.GS_FLAG_ACCUMULATE_GRADS if accumulate else 0
@@ -365,7 +365,7 @@ class HotPath:
             with torch.cuda.stream(L.stream):
                 cabi.rasterize_backward(s.W, s.H, s.N, L.b, self.background, L.f["final_Ts"], L.f["final_idx"],
                                         self.v_out, self.flags | KEEP |
-                                        (cabi.GS_FLAG_RECORDS_ZEROED if (not det and L.rec_zero is not None) else 0),
+                                        (cabi.GS_FLAG_RECORDS_ZEROED if getattr(L.b, "zeroed", False) else 0),
                                         workspace=L.bwd_ws)
                 if prev is not None:
                     L.stream.wait_event(prev.done)     # the flat gradient buffer: camera order

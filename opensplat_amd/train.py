@@ -265,7 +265,7 @@ class Trainer:
         # no visible Gaussian: Model::forward returns the bare background (model.cpp:173), xys gets
         # no gradient and afterTrain returns at once (model.cpp:315)
         self._visible = b.num_isects > 0
-        self._records_clean = self._rec_zero is not None
+        self._records_clean = getattr(b, "zeroed", False)
         self._ctx = (gcam, cam_pos, p, p["rgb_raw"], b, f, flags, degrees_to_use, background, W, H)
         return f["img_clamped"]
 
