@@ -582,7 +582,8 @@ class Trainer:
                 L.g = cabi.gaussian_forward(gcam, self.means, self.log_scales, self.quats, self.opacity_logits,
                                             self.features_dc, rest, cam_pos, degrees_to_use, flags, out=L.gfwd)
                 L.b = cabi.bin_and_sort(W, H, None, L.g["depths"], None, None, None, None, None, L.ws,
-                                        speculative=True, packed=L.g["packed"])
+                                        speculative=True, packed=L.g["packed"],
+                                        zero=None if self.deterministic else L.rec_zero)
                 L.f = cabi.rasterize_forward(W, H, L.b, background, flags, out=L.fwd)
                 L.loss, L.v_rgb = cabi.main_loss(L.f["img_clamped"], gts[j], self.ssim_weight, scale, True,
                                                  out=L.loss_out, workspace=L.loss_ws)
@@ -592,7 +593,8 @@ class Trainer:
             with torch.cuda.stream(L.stream):
                 losses[j].copy_(L.loss)
                 cabi.rasterize_backward(W, H, N, L.b, background, L.f["final_Ts"], L.f["final_idx"], L.v_rgb,
-                                        flags | keep, workspace=L.bwd_ws, img_raw=L.f["img"])
+                                        flags | keep | (cabi.GS_FLAG_RECORDS_ZEROED if getattr(L.b, "zeroed", False) else 0),
+                                        workspace=L.bwd_ws, img_raw=L.f["img"])
                 if prev is not None:
                     L.stream.wait_event(prev.done)      # the flat gradient buffer and the statistics: camera order
                 gout, gflags = self.gout, flags | (cabi.GS_FLAG_ACCUMULATE_GRADS if j > 0 else 0)
